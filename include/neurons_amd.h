@@ -1,0 +1,158 @@
+/*
+ * neurons_amd.h — C ABI of libneurons_amd.so (MI355X / gfx950 only).
+ *
+ * The reference (xmed-lab/NEURONS) is pure Python: it has no FFI, so this header is the boundary a
+ * maintainer would bind from Python (ctypes stubs in INTEGRATION.md; the shipped binding is
+ * neurons_amd/_lib.py).  Each entry point names the reference interface it replaces.
+ *
+ * Conventions
+ *   - Every function returns nr_status (0 = NR_OK).  On failure nr_last_error() returns a message;
+ *     nothing is thrown across the boundary.
+ *   - All pointers named *_dev are device pointers owned by the caller (PyTorch allocations).  The
+ *     library owns: converted weights, one workspace arena sized at nr_net_plan(), a captured hipGraph.
+ *   - All work is enqueued on the hipStream_t passed in; no synchronisation except in nr_net_plan()
+ *     and nr_net_load_tensor().  A handle is not thread-safe; one handle per GPU / process.
+ *   - Activation tensors crossing this ABI between the two networks (ControlNet residuals) are
+ *     channels-last bf16:  [2B*F][h][w][C], frame-image index n = b*F + f.
+ *   - Latent-space tensors (sample, eps, controlnet_cond, mask) are fp32 NCFHW, exactly the
+ *     reference's torch layout "b c f h w".
+ */
+#ifndef NEURONS_AMD_H
+#define NEURONS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int nr_status;
+#define NR_OK 0
+#define NR_ERR_ARG 1
+#define NR_ERR_STATE 2
+#define NR_ERR_MISSING_WEIGHT 3
+#define NR_ERR_HIP 4
+#define NR_ERR_UNSUPPORTED 5
+
+typedef void* nr_stream; /* hipStream_t */
+typedef struct nr_net nr_net;
+
+#define NR_KIND_UNET3D 0     /* animatediff/models/unet.py:38 UNet3DConditionModel            */
+#define NR_KIND_SPARSECTRL 1 /* animatediff/models/sparse_controlnet.py:85 SparseControlNetModel */
+
+#define NR_MAX_LEVELS 4
+
+/* Mirrors the constructor arguments that reach the hot path (unet.py:42-90; SD-1.5 unet/config.json +
+ * configs/inference/inference-v3.yaml; sparse_controlnet.py:88-140 +
+ * configs/inference/sparsectrl/latent_condition.yaml). */
+typedef struct nr_net_config {
+  int32_t kind;                              /* NR_KIND_*                                         */
+  int32_t in_channels;                       /* 4                                                 */
+  int32_t out_channels;                      /* 4 (UNet only)                                     */
+  int32_t num_levels;                        /* len(block_out_channels) = 4                       */
+  int32_t block_out_channels[NR_MAX_LEVELS]; /* 320,640,1280,1280                                 */
+  int32_t down_block_has_attn[NR_MAX_LEVELS]; /* CrossAttnDownBlock3D=1, DownBlock3D=0  (1,1,1,0) */
+  int32_t up_block_has_attn[NR_MAX_LEVELS];  /* UpBlock3D=0, CrossAttnUpBlock3D=1       (0,1,1,1) */
+  int32_t layers_per_block;                  /* 2                                                 */
+  int32_t num_heads;                         /* "attention_head_dim" = 8 = number of heads        */
+  int32_t cross_attention_dim;               /* 768                                               */
+  int32_t norm_num_groups;                   /* 32                                                */
+  float norm_eps;                            /* 1e-5                                              */
+  int32_t use_motion_module;                 /* 1                                                 */
+  int32_t motion_num_heads;                  /* 8                                                 */
+  int32_t motion_num_attention_blocks;       /* 2 (UNet v3) / 1 (SparseCtrl)                      */
+  int32_t motion_pe_max_len;                 /* 24 (UNet default) / 32 (SparseCtrl)               */
+  int32_t motion_module_mid_block;           /* 0                                                 */
+  int32_t conditioning_channels;             /* SparseCtrl: 4 (+1 mask channel is implied)        */
+  int32_t set_noisy_sample_input_to_zero;    /* SparseCtrl: 1                                     */
+} nr_net_config;
+
+#define NR_DTYPE_F32 0
+#define NR_DTYPE_BF16 1
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+
+/* replaces UNet3DConditionModel.__init__ / SparseControlNetModel.__init__ */
+nr_status nr_net_create(const nr_net_config* cfg, nr_net** out);
+void nr_net_destroy(nr_net* h);
+const char* nr_last_error(void);
+
+/* replaces nn.Module.load_state_dict (animatediff/utils/util.py:120,139-144): one call per
+ * state-dict entry, reference key names, host fp32 data ([ndim] shape).  Unknown keys are kept and
+ * ignored; missing keys are reported at nr_net_plan(). */
+nr_status nr_net_load_tensor(nr_net* h, const char* key, const float* host_data, const int64_t* shape, int32_t ndim);
+
+/* Fix the problem size: batch = CFG-expanded batch (2B, <= 16), frames F, latent h x w, ctx_len =
+ * tokens of encoder_hidden_states (77 for CLIP).  Converts/uploads
+ * weights (first call), builds the launch plan and allocates the workspace arena.  May be called
+ * again with another shape. */
+nr_status nr_net_plan(nr_net* h, int32_t batch, int32_t frames, int32_t lat_h, int32_t lat_w, int32_t ctx_len);
+
+/* 1: run forward as a captured hipGraph (re-captured when an I/O pointer changes); 0: eager launches */
+nr_status nr_net_set_graph(nr_net* h, int32_t enable);
+
+/* bytes of workspace / converted weights held by the handle */
+int64_t nr_net_workspace_bytes(const nr_net* h);
+int64_t nr_net_weight_bytes(const nr_net* h);
+int32_t nr_net_num_residuals(const nr_net* h);                     /* 12 (+1 mid) for the default config */
+nr_status nr_net_residual_shape(const nr_net* h, int32_t i, int32_t* C, int32_t* hh, int32_t* ww); /* i == num -> mid */
+
+/* ---- forward -------------------------------------------------------------------------------- */
+
+/* replaces UNet3DConditionModel.forward (unet.py:320-475)
+ *   sample_dev   fp32 [batch][4][F][h][w]
+ *   timesteps    host fp32 [batch]  (the reference broadcasts a scalar: unet.py:371-384)
+ *   ctx_dev      fp32 [batch][ctx_len][cross_attention_dim]  encoder_hidden_states
+ *   down_res_dev NULL or num_residuals pointers, bf16 channels-last (down_block_additional_residuals)
+ *   mid_res_dev  NULL or bf16 channels-last                       (mid_block_additional_residual)
+ *   out_dev      fp32 [batch][4][F][h][w]                          (.sample)                        */
+nr_status nr_unet3d_forward(nr_net* h, nr_stream stream, const float* sample_dev, const float* timesteps,
+                            const float* ctx_dev, int32_t ctx_len, const void* const* down_res_dev,
+                            const void* mid_res_dev, float* out_dev);
+
+/* replaces SparseControlNetModel.forward (sparse_controlnet.py:450-581)
+ *   sample_dev   fp32 [batch][4][F][h][w]; may be NULL when set_noisy_sample_input_to_zero
+ *   cond_dev     fp32 [cond_batch][cond_ch][F][h][w]  controlnet_cond
+ *   mask_dev     fp32 [cond_batch][1][F][h][w]        conditioning_mask
+ *   cond_batch   batch of cond/mask; broadcast over the CFG halves as b % cond_batch
+ *   scale        conditioning_scale
+ *   out_down_dev num_residuals pointers, bf16 channels-last, written
+ *   out_mid_dev  bf16 channels-last, written                                                        */
+nr_status nr_sparsectrl_forward(nr_net* h, nr_stream stream, const float* sample_dev, const float* timesteps,
+                                const float* ctx_dev, int32_t ctx_len, const float* cond_dev, const float* mask_dev,
+                                int32_t cond_batch, float scale, void* const* out_down_dev, void* out_mid_dev);
+
+/* replaces the CFG combine + DDIMScheduler.step (pipeline_neuroclips.py:478-483; diffusers 0.11.1 DDIM eta=0)
+ *   eps_dev fp32 [2B or B][...], x_dev fp32 [B][...] -> x_out_dev (may alias x_dev); n = elements of x     */
+nr_status nr_cfg_ddim_step(nr_stream stream, const float* eps_dev, const float* x_dev, float* x_out_dev, int64_t n,
+                           float guidance_scale, int32_t do_cfg, double alpha_prod_t, double alpha_prod_t_prev);
+
+/* ---- debug / test hooks (activation taps by reference module name) --------------------------- */
+nr_status nr_net_set_debug(nr_net* h, int32_t keep_all_activations);
+int32_t nr_net_num_taps(const nr_net* h);
+const char* nr_net_tap_name(const nr_net* h, int32_t i);
+/* copies tap i (bf16 channels-last [rows][C]) to host as fp32; rows and C receive the shape */
+nr_status nr_net_read_tap(nr_net* h, int32_t i, float* host_out, int64_t capacity, int32_t* rows, int32_t* C);
+
+/* ---- single-op entry points (used by tests/ to check each kernel against the oracle) --------- */
+nr_status nr_op_gemm(nr_stream stream, const void* a_dev, int32_t lda, const void* w_dev, const float* bias_dev,
+                     const void* res_dev, int32_t ldr, void* out_dev, int32_t ldo, int32_t M, int32_t N, int32_t K,
+                     int32_t geglu);
+nr_status nr_op_conv3x3(nr_stream stream, const void* x0_dev, int32_t c0, const void* x1_dev, int32_t c1, int32_t nimg,
+                        int32_t H, int32_t W, int32_t stride, int32_t ups, const void* w_dev, const float* bias_dev,
+                        const float* rowvec_dev, int32_t rowvec_div, const void* res_dev, void* out_dev, int32_t Cout);
+nr_status nr_op_groupnorm(nr_stream stream, const void* x0_dev, int32_t c0, const void* x1_dev, int32_t c1, int32_t nimg,
+                          int32_t hw, int32_t groups, const float* gamma_dev, const float* beta_dev, float eps,
+                          int32_t silu, float* partial_ws_dev, void* out_dev);
+nr_status nr_op_layernorm(nr_stream stream, const void* x_dev, void* out_dev, int32_t M, int32_t C,
+                          const float* gamma_dev, const float* beta_dev, float eps, const float* pe_dev, int32_t pe_hw,
+                          int32_t pe_F);
+/* mode 0: spatial self ([nimg][L][3C] fused qkv), 1: cross (q [nimg][L][C], kv [nb_kv][Lk][2C], kv_div),
+ * 2: temporal self (fused qkv [(b f)][hw][3C], sequence over f) */
+nr_status nr_op_attention(nr_stream stream, int32_t mode, const void* q_dev, const void* kv_dev, void* out_dev,
+                          int32_t nimg, int32_t L, int32_t Lk, int32_t C, int32_t heads, int32_t frames, int32_t kv_div);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEURONS_AMD_H */

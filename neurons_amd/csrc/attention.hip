@@ -1,0 +1,188 @@
+// Flash-style softmax(scale * Q K^T) V on bf16 MFMA for every attention on the denoiser path:
+//   spatial self-attention  (L = h*w tokens per frame-image, heads 8, d = C/8 in {40,80,160})
+//   text cross-attention    (Lk = 77 keys shared by all frames of a clip)
+//   temporal self-attention (L = F frames per pixel; the "(b f) d c -> (b d) f c" regroup of
+//                            animatediff/models/motion_module.py:274-278,327 is done purely by the
+//                            q/k/v/out strides below - nothing is transposed in memory)
+// Reference arithmetic: diffusers-0.11.1 CrossAttention._attention, vendored at
+// animatediff/models/motion_module_new.py:258-287 (baddbmm(alpha=scale) -> softmax -> bmm) with the
+// head split of :181-193.  The score matrix is never materialised; softmax statistics are fp32.
+//
+// Work unit: one wave = 16 queries of one (batch, head).  The scores are computed TRANSPOSED,
+// S^T = K Q^T (keys on MFMA rows, queries on lanes), so a lane's accumulator registers are the
+// probabilities of ITS query for 8 keys - exactly the B-operand fragment the second product
+// O^T = V^T P^T needs (k-slot permutation applied identically to both operands), i.e. P never leaves
+// registers.  Row max / row sum are two xor-shuffles across the 4 lane groups.  V tiles are staged
+// transposed in a per-wave LDS region.
+#include "common.h"
+
+namespace {
+
+constexpr int KT = 32;        // keys per iteration
+constexpr int VT_LD = 36;     // LDS row stride (elements) of the transposed V tile: 72 B, conflict-free b64 reads
+
+// DK = ceil(d/32) k-steps for QK^T;  DT = ceil(d/16) row tiles of O^T
+template <int DK, int DT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(NrAttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) bf16 vt_all[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  bf16* vt = vt_all + (size_t)wave * (DT * 16) * VT_LD;   // [DT*16][VT_LD]
+  const int c = lane & 15, g = lane >> 4;
+
+  const int qtiles = (p.Lq + 15) >> 4;
+  const long long total = (long long)p.nbatch * p.heads * qtiles;
+  long long wid = (long long)blockIdx.x * 4 + wave;
+  const bool active = wid < total;
+  if (!active) wid = total - 1;   // keep the wave in step with the block barriers; results discarded
+  const int qt = (int)(wid % qtiles);
+  const int h = (int)((wid / qtiles) % p.heads);
+  const int nb = (int)(wid / ((long long)qtiles * p.heads));
+  const int nbkv = nb / p.kv_div;
+
+  const long long qbase = (long long)(nb / p.inner) * p.q_outer + (long long)(nb % p.inner) * p.q_inner_stride + (long long)h * p.d;
+  const long long obase = (long long)(nb / p.inner) * p.o_outer + (long long)(nb % p.inner) * p.o_inner_stride + (long long)h * p.d;
+  const long long kbase = (long long)(nbkv / p.kv_inner) * p.kv_outer + (long long)(nbkv % p.kv_inner) * p.kv_inner_stride + (long long)h * p.d;
+
+  const bf16x8 zero8 = bf16x8_zero();
+  const int qrow = qt * 16 + c;
+  const int qrow_c = min(qrow, p.Lq - 1);
+
+  // Q fragments (B operand of S^T = K Q^T): lane holds Q[query c][dim 32*ks + 8*g .. +7]
+  bf16x8 qf[DK];
+#pragma unroll
+  for (int ks = 0; ks < DK; ++ks) {
+    const int dim0 = ks * 32 + g * 8;
+    qf[ks] = dim0 < p.d ? *(const bf16x8*)(p.q + qbase + (long long)qrow_c * p.q_seq + dim0) : zero8;
+  }
+
+  f32x4 acc[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_i = -1e30f, l_i = 0.f;
+
+  const int chunks_per_key = p.d >> 3;
+  const int vchunks = KT * chunks_per_key;
+
+  for (int k0 = 0; k0 < p.Lk; k0 += KT) {
+    // ---- stage V tile transposed: vt[dv][key - k0] ----
+    __syncthreads();   // previous iteration's fragment reads are done
+    for (int id = lane; id < vchunks; id += 64) {
+      const int kk = id / chunks_per_key;
+      const int x0 = (id - kk * chunks_per_key) << 3;
+      const int key = k0 + kk;
+      bf16x8 vv = zero8;
+      if (key < p.Lk) vv = *(const bf16x8*)(p.v + kbase + (long long)key * p.kv_seq + x0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vt[(x0 + e) * VT_LD + kk] = vv[e];
+    }
+
+    // ---- S^T = K Q^T for two 16-key tiles ----
+    f32x4 s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int key = k0 + 16 * t + c;
+      const int keyc = min(key, p.Lk - 1);
+      const bf16* kp = p.k + kbase + (long long)keyc * p.kv_seq;
+#pragma unroll
+      for (int ks = 0; ks < DK; ++ks) {
+        const int dim0 = ks * 32 + g * 8;
+        const bf16x8 kf = dim0 < p.d ? *(const bf16x8*)(kp + dim0) : zero8;
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
+      }
+    }
+    // s[t][r]: key = k0 + 16t + 4g + r, query = c
+    float mx = -1e30f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = k0 + 16 * t + 4 * g + r;
+        const float v = key < p.Lk ? s[t][r] * p.scale : -1e30f;
+        s[t][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_i, mx);
+    const float alpha = __expf(m_i - m_new);
+    float rs = 0.f;
+    bf16x8 pf;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = k0 + 16 * t + 4 * g + r;
+        const float e = key < p.Lk ? __expf(s[t][r] - m_new) : 0.f;
+        rs += e;
+        pf[t * 4 + r] = (bf16)e;
+      }
+    rs += __shfl_xor(rs, 16, 64);
+    rs += __shfl_xor(rs, 32, 64);
+    l_i = l_i * alpha + rs;
+    m_i = m_new;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) acc[i] *= alpha;
+
+    __syncthreads();   // V tile visible
+    // ---- O^T += V^T P^T : A = V^T rows dv = 16*i + c, k-slot j -> key (j<4: 4g+j ; j>=4: 16+4g+j-4) ----
+#pragma unroll
+    for (int i = 0; i < DT; ++i) {
+      const int dv = i * 16 + c;
+      bf16x8 vf = zero8;
+      if (dv < p.d) {
+        const bf16x4 lo = *(const bf16x4*)(vt + dv * VT_LD + 4 * g);
+        const bf16x4 hi = *(const bf16x4*)(vt + dv * VT_LD + 16 + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+      }
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, acc[i], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: acc[i][r] = O[query c][dv = 16i + 4g + r] ----
+  if (active && qrow < p.Lq) {
+    const float inv = 1.0f / l_i;
+    bf16* op = p.out + obase + (long long)qrow * p.o_seq;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) {
+      const int dv0 = i * 16 + 4 * g;
+      if (dv0 < p.d) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[i][e] * inv);
+        *(bf16x4*)(op + dv0) = o;
+      }
+    }
+  }
+}
+
+template <int DK, int DT>
+int launch_attn(const NrAttnParams& p, hipStream_t stream) {
+  const int qtiles = (p.Lq + 15) / 16;
+  const long long total = (long long)p.nbatch * p.heads * qtiles;
+  const unsigned blocks = (unsigned)((total + 3) / 4);
+  const size_t shm = (size_t)4 * (DT * 16) * VT_LD * sizeof(bf16);
+  hipLaunchKernelGGL((attn_fwd_kernel<DK, DT>), dim3(blocks), dim3(256), shm, stream, p);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int nr_launch_attention(const NrAttnParams* pp, hipStream_t stream) {
+  const NrAttnParams& p = *pp;
+  if (p.d % 8 != 0 || p.d > 160 || p.d <= 0) return 1;
+  if (p.Lq <= 0 || p.Lk <= 0 || p.nbatch <= 0) return 2;
+  const int DK = (p.d + 31) / 32, DT = (p.d + 15) / 16;
+  // instantiate the head dims on the path (40, 80, 160) plus small ones used by reduced-width tests
+  if (DK == 1 && DT == 1) return launch_attn<1, 1>(p, stream);       // d = 8, 16
+  if (DK == 1 && DT == 2) return launch_attn<1, 2>(p, stream);       // d = 24, 32
+  if (DK == 2 && DT == 3) return launch_attn<2, 3>(p, stream);       // d = 40, 48
+  if (DK == 2 && DT == 4) return launch_attn<2, 4>(p, stream);       // d = 56, 64
+  if (DK == 3 && DT == 5) return launch_attn<3, 5>(p, stream);       // d = 72, 80
+  if (DK == 3 && DT == 6) return launch_attn<3, 6>(p, stream);       // d = 88, 96
+  if (DK == 4 && DT == 8) return launch_attn<4, 8>(p, stream);       // d = 120, 128
+  if (DK == 5 && DT == 10) return launch_attn<5, 10>(p, stream);     // d = 152, 160
+  return 3;
+}

@@ -1,0 +1,101 @@
+// Shared device/host helpers for the neurons_amd HIP library (gfx950 / CDNA4 only).
+//
+// Physical activation layout everywhere in this library: channels-last frame-images,
+//   act[n][y][x][c]  bf16,  n = b*F + f   (b = CFG-batch index, f = frame)
+// which is the reference's "(b f) (h w) c" token layout (animatediff/models/attention.py:99,109)
+// and also what its per-frame convolutions see after "b c f h w -> (b f) c h w"
+// (animatediff/models/resnet.py:14-16).  NCFHW fp32 exists only at the 4-channel latent boundary.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define NR_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+__device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }
+
+__device__ __forceinline__ bf16x8 bf16x8_zero() {
+  bf16x8 z;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) z[i] = (bf16)0.0f;
+  return z;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// exact (erf) GELU, as torch F.gelu default (reference: animatediff/models/motion_module_new.py:508-518)
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Launch-parameter structs shared between the kernels (*.hip) and the engine (engine.hip).
+// ----------------------------------------------------------------------------------------------
+
+// C[M][N] = epilogue( A[M][K] * W[N][K]^T ), A given as an implicit im2col view of an NHWC tensor
+// (ksize=1: plain row-major GEMM).  See gemm.hip.
+struct NrGemmParams {
+  const bf16* a0;      // first channel-concat source, pixel-major [pix][lda0]
+  const bf16* a1;      // second source (may be null); channels [c0, c0+c1)
+  int c0, c1;          // channels taken from a0 / a1 (c1 = 0 when a1 == null)
+  int lda0, lda1;      // pixel stride of a0 / a1 in elements
+  int H, W;            // source spatial size (before optional nearest-2x upsample)
+  int OH, OW;          // output spatial size
+  int ksize;           // 1 or 3 (3 => pad 1)
+  int stride;          // 1 or 2
+  int ups;             // 1: source is nearest-2x upsampled before the 3x3 conv
+  const bf16* w;       // [N][K] bf16, K = ksize*ksize*(c0+c1), tap-major (ky,kx,c)
+  int M, N, K;
+  const float* bias;   // [N] fp32 or null
+  const float* rowvec; // [M/rowvec_div][N] fp32 or null (time-embedding add)
+  int rowvec_div;      // row m uses rowvec[(m / rowvec_div) * rowvec_ld + n]
+  int rowvec_ld;
+  const bf16* res;     // residual [M][ldr] or null
+  int ldr;
+  bf16* out;           // [M][ldo]
+  int ldo;
+  float out_scale;     // (acc + bias + rowvec) * out_scale + res
+  int geglu;           // 1: W rows are (value16|gate16)-interleaved; out has N/2 columns
+};
+
+struct NrAttnParams {
+  const bf16* q; const bf16* k; const bf16* v; bf16* out;
+  // element offset of (batch nb, seq s, head h, dim x):
+  //   base(nb) + s*seq + h*d + x,   base(nb) = (nb / inner)*outer + (nb % inner)*inner_stride
+  long long q_outer, q_inner_stride, q_seq;
+  long long kv_outer, kv_inner_stride, kv_seq;
+  long long o_outer, o_inner_stride, o_seq;
+  int inner;       // inner batch extent for q/out (spatial: 1, temporal: h*w)
+  int kv_inner;    // inner batch extent for k/v
+  int kv_div;      // kv batch index = nb / kv_div (cross-attention: frames share one text context)
+  int nbatch, heads, d, Lq, Lk;
+  float scale;
+};
+
+// GroupNorm launch parameters (norm.hip)
+struct NrGnParams {
+  const bf16* x0; const bf16* x1;   // sources: channels [0,c0) from x0, [c0,c0+c1) from x1
+  int c0, c1, ld0, ld1;             // pixel strides in elements
+  int nimg, hw;                     // images, pixels per image
+  int groups;
+  int pix_per_blk, nchunk;          // pixel chunking: nchunk = ceil(hw / pix_per_blk)
+  float* partial;                   // [nimg][nchunk][groups][2]
+  const float* gamma; const float* beta;  // [C]
+  float eps;
+  int silu;
+  bf16* out; int ldo;               // [nimg*hw][ldo]
+};

@@ -1,0 +1,244 @@
+// Small / boundary kernels of the denoiser path (none of them GEMM-shaped enough for MFMA):
+//   conv_in_small   : 3x3 conv from the fp32 NCFHW latent boundary (Cin = 4, or 4+1 for the SparseCtrl
+//                     condition+mask) to channels-last bf16            (unet.py:405; sparse_controlnet.py:513-521)
+//   conv_out_small  : 3x3 conv from channels-last bf16 (already GN+SiLU'd) to fp32 NCFHW eps (unet.py:468-470)
+//   timestep_sincos : diffusers Timesteps(320, flip_sin_to_cos=True, freq_shift=0)  (unet.py:101,386; in-repo
+//                     twin: generative_models/sgm/modules/diffusionmodules/util.py:207-231)
+//   linear_small    : y = W act(x) + b for the handful-of-rows time-embedding MLPs (unet.py:392; resnet.py:191)
+//   cfg_ddim_step   : classifier-free guidance + DDIM eta=0 update           (pipeline_neuroclips.py:478-483)
+//   add_bf16        : out = a + b (ControlNet residual adds, unet.py:425-428,436-439)
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// conv_in_small: out[n][y][x][co] = bias[co] + sum_{ci,ky,kx} wT[(ci*9+ky*3+kx)][co] * in(ci, y+ky-1, x+kx-1)
+// sources: s0 fp32 [B][c0][F][H][W], s1 fp32 [B][c1][F][H][W] (may be null).  Source batch index = b % src_batch
+// (CFG halves share one latent; SparseCtrl condition has batch B while the net runs 2B).
+// grid (H, nimg), block 256; LDS patch [Cin][3][W+2]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_in_small_kernel(const float* __restrict__ s0, const float* __restrict__ s1,
+                                                            int c0, int c1, int src_batch, int F, int H, int W,
+                                                            const float* __restrict__ wT, const float* __restrict__ bias,
+                                                            const float* __restrict__ addend, int Cout,
+                                                            bf16* __restrict__ out) {
+  extern __shared__ float patch[];
+  const int Cin = c0 + c1;
+  const int y = blockIdx.x, n = blockIdx.y;
+  const int b = (n / F) % src_batch, f = n % F;
+  const int PW = W + 2;
+  for (int i = threadIdx.x; i < Cin * 3 * PW; i += 256) {
+    const int ci = i / (3 * PW);
+    const int r = i - ci * 3 * PW;
+    const int ky = r / PW, px = r - ky * PW;
+    const int iy = y + ky - 1, ix = px - 1;
+    float v = 0.f;
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+      const float* s; int cc, cs;
+      if (ci < c0) { s = s0; cc = ci; cs = c0; } else { s = s1; cc = ci - c0; cs = c1; }
+      v = s[((((size_t)b * cs + cc) * F + f) * H + iy) * W + ix];
+    }
+    patch[i] = v;
+  }
+  __syncthreads();
+  const int K = Cin * 9;
+  for (int idx = threadIdx.x; idx < W * Cout; idx += 256) {
+    const int x = idx / Cout, co = idx - x * Cout;
+    float acc = bias[co];
+    for (int k = 0; k < K; ++k) {
+      const int ci = k / 9, t = k - ci * 9;
+      const int ky = t / 3, kx = t - ky * 3;
+      acc += wT[(size_t)k * Cout + co] * patch[(ci * 3 + ky) * PW + x + kx];
+    }
+    if (addend) acc += addend[co];
+    out[(((size_t)n * H + y) * W + x) * Cout + co] = (bf16)acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv_out_small: one wave per output pixel, Cout <= 4.  w: [Cout][9][Cin] bf16.  out fp32 [B][Cout][F][H][W]
+// ---------------------------------------------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_out_small_kernel(const bf16* __restrict__ x, int Cin, int nimg, int F, int H,
+                                                             int W, const bf16* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long npix = (long long)nimg * H * W;
+  if (pix >= npix) return;
+  const int n = (int)(pix / (H * W));
+  const int r = (int)(pix - (long long)n * H * W);
+  const int y = r / W, xx = r - y * W;
+  const int CP = Cin >> 3;
+  float acc[COUT];
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+  for (int id = lane; id < 9 * CP; id += 64) {
+    const int tap = id / CP, cc = (id - tap * CP) << 3;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int iy = y + ky - 1, ix = xx + kx - 1;
+    if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+    const bf16x8 v = *(const bf16x8*)(x + (((size_t)n * H + iy) * W + ix) * Cin + cc);
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) {
+      const bf16x8 ww = *(const bf16x8*)(w + ((size_t)o * 9 + tap) * Cin + cc);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[o] += (float)v[e] * (float)ww[e];
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) acc[o] = wave_sum(acc[o]);
+  if (lane == 0) {
+    const int b = n / F, f = n - b * F;
+#pragma unroll
+    for (int o = 0; o < COUT; ++o)
+      out[((((size_t)b * COUT + o) * F + f) * H + y) * W + xx] = acc[o] + bias[o];
+  }
+}
+
+// t: [M] fp32 timesteps -> out [M][dim] = [cos(t*f_i) | sin(t*f_i)], f_i = exp(-ln(1e4) * i / half), half = dim/2
+__global__ void timestep_sincos_kernel(const float* __restrict__ t, int M, int dim, float* __restrict__ out) {
+  const int half = dim >> 1;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * half) return;
+  const int m = idx / half, i = idx - m * half;
+  const float freq = expf(-9.210340371976184f * (float)i / (float)half);
+  const float a = t[m] * freq;
+  out[(size_t)m * dim + i] = cosf(a);
+  out[(size_t)m * dim + half + i] = sinf(a);
+}
+
+// y[m][n] = sum_k act(x[m][k]) * W[n][k] + b[n];  one wave per n, M <= 16, K % 8 == 0.  act: 0 none, 1 SiLU (on input)
+// out_act: 0 none, 1 SiLU (on output)
+__global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ x, int M, int K,
+                                                           const bf16* __restrict__ W, const float* __restrict__ b, int N,
+                                                           int in_act, int out_act, float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float acc[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) acc[m] = 0.f;
+  for (int k0 = lane * 8; k0 < K; k0 += 64 * 8) {
+    const bf16x8 w = *(const bf16x8*)(W + (size_t)n * K + k0);
+    float wf[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wf[e] = (float)w[e];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      if (m < M) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float xv = x[(size_t)m * K + k0 + e];
+          if (in_act) xv = silu_f(xv);
+          acc[m] += xv * wf[e];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    if (m < M) {
+      float v = wave_sum(acc[m]);
+      if (lane == 0) {
+        v += b ? b[n] : 0.f;
+        if (out_act) v = silu_f(v);
+        y[(size_t)m * N + n] = v;
+      }
+    }
+  }
+}
+
+// eps: fp32 [2B][...] (uncond first, text second: pipeline_neuroclips.py:238,479); x: fp32 [B][...] updated in place
+// into x_out.  per = elements per batch entry.  DDIM eta=0 (diffusers 0.11.1 DDIMScheduler.step):
+//   x0 = (x - sqrt(1-a_t) * e) / sqrt(a_t);  x_prev = sqrt(a_prev) * x0 + sqrt(1-a_prev) * e
+__global__ void cfg_ddim_step_kernel(const float* __restrict__ eps, const float* __restrict__ x, float* __restrict__ x_out,
+                                     long long total, long long half_off, float guidance, int do_cfg, float sqrt_at,
+                                     float sqrt_1mat, float sqrt_ap, float sqrt_1map) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  float e;
+  if (do_cfg) {
+    const float eu = eps[i], et = eps[i + half_off];
+    e = eu + guidance * (et - eu);
+  } else {
+    e = eps[i];
+  }
+  const float xv = x[i];
+  const float x0 = (xv - sqrt_1mat * e) / sqrt_at;
+  x_out[i] = sqrt_ap * x0 + sqrt_1map * e;
+}
+
+__global__ void add_bf16_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ out,
+                                long long n8) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const bf16x8 va = ((const bf16x8*)a)[i], vb = ((const bf16x8*)b)[i];
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)va[e] + (float)vb[e]);
+  ((bf16x8*)out)[i] = o;
+}
+
+// fp32 [rows][C] -> bf16 [rows][C]
+__global__ void f32_to_bf16_kernel(const float* __restrict__ a, bf16* __restrict__ out, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (bf16)a[i];
+}
+
+}  // namespace
+
+extern "C" int nr_launch_conv_in_small(const float* s0, const float* s1, int c0, int c1, int src_batch, int nimg, int F,
+                                       int H, int W, const float* wT, const float* bias, const float* addend, int Cout,
+                                       bf16* out, hipStream_t stream) {
+  const size_t shm = (size_t)(c0 + c1) * 3 * (W + 2) * sizeof(float);
+  if (shm > 60000) return 1;
+  hipLaunchKernelGGL(conv_in_small_kernel, dim3(H, nimg), dim3(256), shm, stream, s0, s1, c0, c1, src_batch, F, H, W, wT,
+                     bias, addend, Cout, out);
+  return 0;
+}
+
+extern "C" int nr_launch_conv_out_small(const bf16* x, int Cin, int nimg, int F, int H, int W, const bf16* w,
+                                        const float* bias, int Cout, float* out, hipStream_t stream) {
+  if (Cin % 8 != 0) return 1;
+  const long long npix = (long long)nimg * H * W;
+  const unsigned blocks = (unsigned)((npix + 3) / 4);
+  if (Cout == 4)
+    hipLaunchKernelGGL((conv_out_small_kernel<4>), dim3(blocks), dim3(256), 0, stream, x, Cin, nimg, F, H, W, w, bias, out);
+  else
+    return 2;
+  return 0;
+}
+
+extern "C" int nr_launch_timestep_sincos(const float* t, int M, int dim, float* out, hipStream_t stream) {
+  const int total = M * (dim / 2);
+  hipLaunchKernelGGL(timestep_sincos_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, t, M, dim, out);
+  return 0;
+}
+
+extern "C" int nr_launch_linear_small(const float* x, int M, int K, const bf16* W, const float* b, int N, int in_act,
+                                      int out_act, float* y, hipStream_t stream) {
+  if (M > 16 || K % 8 != 0) return 1;
+  hipLaunchKernelGGL(linear_small_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, x, M, K, W, b, N, in_act, out_act, y);
+  return 0;
+}
+
+extern "C" int nr_launch_cfg_ddim_step(const float* eps, const float* x, float* x_out, long long total, float guidance,
+                                       int do_cfg, float sqrt_at, float sqrt_1mat, float sqrt_ap, float sqrt_1map,
+                                       hipStream_t stream) {
+  hipLaunchKernelGGL(cfg_ddim_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, eps, x, x_out,
+                     total, total, guidance, do_cfg, sqrt_at, sqrt_1mat, sqrt_ap, sqrt_1map);
+  return 0;
+}
+
+extern "C" int nr_launch_add_bf16(const bf16* a, const bf16* b, bf16* out, long long n, hipStream_t stream) {
+  if (n % 8 != 0) return 1;
+  const long long n8 = n / 8;
+  hipLaunchKernelGGL(add_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, stream, a, b, out, n8);
+  return 0;
+}
+
+extern "C" int nr_launch_f32_to_bf16(const float* a, bf16* out, long long n, hipStream_t stream) {
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, out, n);
+  return 0;
+}

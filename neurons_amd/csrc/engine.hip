@@ -1,0 +1,1102 @@
+// Denoiser-network engine behind the C ABI of include/neurons_amd.h.
+//
+// A handle owns (1) the state dict as loaded (host fp32, reference key names), (2) the converted
+// device weights (bf16, layouts the kernels want: tap-major conv weights, fused q|k|v, GEGLU
+// value/gate interleave, one concatenated time-embedding projection), (3) a launch plan: a flat
+// list of kernel launches over one workspace arena with plan-time buffer reuse, (4) optionally that
+// plan captured as a hipGraph.  forward() allocates nothing.
+//
+// The plan follows the reference module graph:
+//   UNet3DConditionModel.forward        animatediff/models/unet.py:357-475
+//   SparseControlNetModel.forward       animatediff/models/sparse_controlnet.py:467-581
+//   Cross/Down/Mid/Up blocks            animatediff/models/unet_blocks.py:271-278,382-421,493-521,621-667,735-760
+//   ResnetBlock3D                       animatediff/models/resnet.py:182-212
+//   Transformer3DModel / BasicTransformerBlock   animatediff/models/attention.py:95-142,256-300
+//   TemporalTransformer3DModel / Block / VersatileAttention   animatediff/models/motion_module.py:134-158,210-222,270-329
+#include "common.h"
+#include "../../include/neurons_amd.h"
+
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+extern "C" {
+int nr_launch_igemm(const NrGemmParams* pp, hipStream_t stream);
+int nr_gn_workspace_floats(int nimg, int hw, int groups, int* pix_per_blk_out, int* nchunk_out);
+int nr_launch_groupnorm(NrGnParams* pp, hipStream_t stream);
+int nr_launch_layernorm(const bf16* x, int ldx, bf16* out, int ldo, int M, int C, const float* gamma, const float* beta,
+                        float eps, const float* pe, int pe_hw, int pe_F, hipStream_t stream);
+int nr_launch_attention(const NrAttnParams* pp, hipStream_t stream);
+int nr_launch_conv_in_small(const float* s0, const float* s1, int c0, int c1, int src_batch, int nimg, int F, int H, int W,
+                            const float* wT, const float* bias, const float* addend, int Cout, bf16* out,
+                            hipStream_t stream);
+int nr_launch_conv_out_small(const bf16* x, int Cin, int nimg, int F, int H, int W, const bf16* w, const float* bias,
+                             int Cout, float* out, hipStream_t stream);
+int nr_launch_timestep_sincos(const float* t, int M, int dim, float* out, hipStream_t stream);
+int nr_launch_linear_small(const float* x, int M, int K, const bf16* W, const float* b, int N, int in_act, int out_act,
+                           float* y, hipStream_t stream);
+int nr_launch_cfg_ddim_step(const float* eps, const float* x, float* x_out, long long total, float guidance, int do_cfg,
+                            float sqrt_at, float sqrt_1mat, float sqrt_ap, float sqrt_1map, hipStream_t stream);
+int nr_launch_add_bf16(const bf16* a, const bf16* b, bf16* out, long long n, hipStream_t stream);
+int nr_launch_f32_to_bf16(const float* a, bf16* out, long long n, hipStream_t stream);
+}
+
+namespace {
+
+thread_local std::string g_err;
+void set_err(const std::string& s) { g_err = s; }
+
+struct NrError : std::runtime_error {
+  nr_status code;
+  NrError(nr_status c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define HIP_OK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess) throw NrError(NR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+#define LAUNCH_OK(expr)                                                                              \
+  do {                                                                                               \
+    int _r = (expr);                                                                                 \
+    if (_r != 0) throw NrError(NR_ERR_UNSUPPORTED, std::string(#expr) + " -> " + std::to_string(_r)); \
+  } while (0)
+
+inline uint16_t f2bf_host(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+struct HostTensor {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+  int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+// ---- plan-time arena allocator (offsets only; first fit with coalescing) ----
+struct Arena {
+  struct Blk { size_t off, size; };
+  std::vector<Blk> free_;
+  size_t top = 0, high = 0;
+  static size_t align(size_t b) { return (b + 255) & ~(size_t)255; }
+  size_t alloc(size_t bytes) {
+    bytes = align(bytes);
+    for (size_t i = 0; i < free_.size(); ++i) {
+      if (free_[i].size >= bytes) {
+        const size_t off = free_[i].off;
+        if (free_[i].size == bytes) free_.erase(free_.begin() + i);
+        else { free_[i].off += bytes; free_[i].size -= bytes; }
+        return off;
+      }
+    }
+    const size_t off = top;
+    top += bytes;
+    if (top > high) high = top;
+    return off;
+  }
+  void release(size_t off, size_t bytes) {
+    bytes = align(bytes);
+    size_t i = 0;
+    while (i < free_.size() && free_[i].off < off) ++i;
+    free_.insert(free_.begin() + i, Blk{off, bytes});
+    if (i + 1 < free_.size() && free_[i].off + free_[i].size == free_[i + 1].off) {
+      free_[i].size += free_[i + 1].size;
+      free_.erase(free_.begin() + i + 1);
+    }
+    if (i > 0 && free_[i - 1].off + free_[i - 1].size == free_[i].off) {
+      free_[i - 1].size += free_[i].size;
+      free_.erase(free_.begin() + i);
+    }
+    if (!free_.empty() && free_.back().off + free_.back().size == top) {
+      top = free_.back().off;
+      free_.pop_back();
+    }
+  }
+  void reset() { free_.clear(); top = 0; high = 0; }
+};
+
+struct Buf {
+  Arena* arena; size_t off, bytes; bool keep;
+  ~Buf() { if (!keep) arena->release(off, bytes); }
+};
+
+// channels-last activation [nimg][H][W][C] (row stride ld elements)
+struct Act {
+  std::shared_ptr<Buf> buf;
+  bf16* ptr = nullptr;
+  int nimg = 0, H = 0, W = 0, C = 0, ld = 0;
+  int64_t rows() const { return (int64_t)nimg * H * W; }
+  bool valid() const { return nimg > 0; }
+};
+
+struct Tap { std::string name; bf16* ptr; int64_t rows; int C, ld; };
+
+struct IO {
+  const float* sample = nullptr;
+  const float* ctx = nullptr;
+  float* out = nullptr;
+  const void* down_res[16] = {nullptr};
+  const void* mid_res = nullptr;
+  int has_res = 0;
+  const float* cond = nullptr;
+  const float* mask = nullptr;
+  int cond_batch = 1;
+  float scale = 1.f;
+  void* out_down[16] = {nullptr};
+  void* out_mid = nullptr;
+  bool operator==(const IO& o) const { return std::memcmp(this, &o, sizeof(IO)) == 0; }
+};
+
+struct TimestepVals { float v[16]; };
+__global__ void set_timesteps_kernel(float* dst, TimestepVals tv, int n) {
+  if (threadIdx.x < n) dst[threadIdx.x] = tv.v[threadIdx.x];
+}
+
+}  // namespace
+
+struct nr_net {
+  nr_net_config cfg;
+  std::map<std::string, HostTensor> host;
+  std::map<std::string, void*> dev;  // converted weights by derived name
+  size_t weight_bytes = 0;
+
+  // plan
+  int B2 = 0, F = 0, H = 0, W = 0, ctx_len = 0;
+  bool planned = false;
+  bool dry = false;
+  Arena arena;
+  char* arena_base = nullptr;
+  size_t arena_bytes = 0;
+  std::vector<std::function<void(hipStream_t)>> ops;
+  std::vector<Tap> taps;
+  bool keep_all = false;
+  IO io;
+  int n_res = 0;
+  struct ResShape { int C, h, w; };
+  std::vector<ResShape> res_shapes;  // n_res down + 1 mid
+
+  // small persistent fp32 buffers (allocated from the arena, pinned)
+  float* t_dev = nullptr;
+  int temb_total = 0;
+
+  // graph
+  bool use_graph = false;
+  hipGraphExec_t gexec = nullptr;
+  IO captured;
+  hipStream_t captured_stream = nullptr;
+
+  ~nr_net() {
+    for (auto& kv : dev) if (kv.second) (void)hipFree(kv.second);
+    if (arena_base) (void)hipFree(arena_base);
+    if (gexec) (void)hipGraphExecDestroy(gexec);
+  }
+
+  // ------------------------------------------------------------------ weights
+  const HostTensor& need(const std::string& key) const {
+    auto it = host.find(key);
+    if (it == host.end()) throw NrError(NR_ERR_MISSING_WEIGHT, "missing state-dict entry: " + key);
+    return it->second;
+  }
+  bool has(const std::string& key) const { return host.count(key) != 0; }
+
+  void* upload(const std::string& name, const void* data, size_t bytes) {
+    void* d = nullptr;
+    HIP_OK(hipMalloc(&d, bytes));
+    HIP_OK(hipMemcpy(d, data, bytes, hipMemcpyHostToDevice));
+    dev[name] = d;
+    weight_bytes += bytes;
+    return d;
+  }
+  template <class Fn>
+  void* cached(const std::string& name, Fn make) {
+    if (dry) return nullptr;
+    auto it = dev.find(name);
+    if (it != dev.end()) return it->second;
+    return make();
+  }
+  void check_shape(const std::string& key, const HostTensor& t, std::initializer_list<int64_t> want) const {
+    std::vector<int64_t> w(want);
+    int64_t nw = 1; for (auto s : w) nw *= s;
+    if (t.numel() != nw) {
+      std::string m = "state-dict entry " + key + " has " + std::to_string(t.numel()) + " elements, expected " + std::to_string(nw);
+      throw NrError(NR_ERR_ARG, m);
+    }
+  }
+
+  // nn.Linear / 1x1 conv weight [N][K] -> bf16 [N][K]
+  const bf16* w_linear(const std::string& key, int N, int K) {
+    const HostTensor& t = need(key);
+    check_shape(key, t, {N, K});
+    return (const bf16*)cached("lin:" + key, [&]() {
+      std::vector<uint16_t> h((size_t)N * K);
+      for (size_t i = 0; i < h.size(); ++i) h[i] = f2bf_host(t.data[i]);
+      return upload("lin:" + key, h.data(), h.size() * 2);
+    });
+  }
+  // rows of several [Ni][K] matrices concatenated (fused q|k|v, k|v)
+  const bf16* w_linear_cat(const std::vector<std::string>& keys, int Neach, int K) {
+    std::string name = "cat:";
+    for (auto& k : keys) { const HostTensor& t = need(k); check_shape(k, t, {Neach, K}); name += k + "|"; }
+    return (const bf16*)cached(name, [&]() {
+      std::vector<uint16_t> h((size_t)keys.size() * Neach * K);
+      size_t o = 0;
+      for (auto& k : keys) { const HostTensor& t = need(k); for (size_t i = 0; i < t.data.size(); ++i) h[o++] = f2bf_host(t.data[i]); }
+      return upload(name, h.data(), h.size() * 2);
+    });
+  }
+  // GEGLU projection [2*inner][K]: rows permuted so each 32-row group is 16 value rows then their 16 gate rows
+  const bf16* w_geglu(const std::string& key, int inner, int K) {
+    const HostTensor& t = need(key);
+    check_shape(key, t, {2 * inner, K});
+    return (const bf16*)cached("geglu:" + key, [&]() {
+      std::vector<uint16_t> h((size_t)2 * inner * K);
+      for (int n = 0; n < 2 * inner; ++n) {
+        const int q = n / 32, j = n % 32;
+        const int src = j < 16 ? q * 16 + j : inner + q * 16 + (j - 16);
+        for (int k = 0; k < K; ++k) h[(size_t)n * K + k] = f2bf_host(t.data[(size_t)src * K + k]);
+      }
+      return upload("geglu:" + key, h.data(), h.size() * 2);
+    });
+  }
+  const float* b_geglu(const std::string& key, int inner) {
+    const HostTensor& t = need(key);
+    check_shape(key, t, {2 * inner});
+    return (const float*)cached("geglub:" + key, [&]() {
+      std::vector<float> h((size_t)2 * inner);
+      for (int n = 0; n < 2 * inner; ++n) {
+        const int q = n / 32, j = n % 32;
+        h[n] = t.data[j < 16 ? q * 16 + j : inner + q * 16 + (j - 16)];
+      }
+      return upload("geglub:" + key, h.data(), h.size() * 4);
+    });
+  }
+  // conv weight [Cout][Cin][3][3] -> bf16 [Cout][ky][kx][Cin]
+  const bf16* w_conv3(const std::string& key, int Cout, int Cin) {
+    const HostTensor& t = need(key);
+    check_shape(key, t, {Cout, Cin, 3, 3});
+    return (const bf16*)cached("conv3:" + key, [&]() {
+      std::vector<uint16_t> h((size_t)Cout * 9 * Cin);
+      for (int o = 0; o < Cout; ++o)
+        for (int c = 0; c < Cin; ++c)
+          for (int k = 0; k < 9; ++k)
+            h[((size_t)o * 9 + k) * Cin + c] = f2bf_host(t.data[((size_t)o * Cin + c) * 9 + k]);
+      return upload("conv3:" + key, h.data(), h.size() * 2);
+    });
+  }
+  // small-Cin conv weight [Cout][Cin][3][3] -> fp32 [Cin*9][Cout]
+  const float* w_conv_in(const std::string& key, int Cout, int Cin) {
+    const HostTensor& t = need(key);
+    check_shape(key, t, {Cout, Cin, 3, 3});
+    return (const float*)cached("convin:" + key, [&]() {
+      std::vector<float> h((size_t)Cin * 9 * Cout);
+      for (int o = 0; o < Cout; ++o)
+        for (int k = 0; k < Cin * 9; ++k) h[(size_t)k * Cout + o] = t.data[(size_t)o * Cin * 9 + k];
+      return upload("convin:" + key, h.data(), h.size() * 4);
+    });
+  }
+  const float* w_f32(const std::string& key, int64_t n) {
+    const HostTensor& t = need(key);
+    check_shape(key, t, {n});
+    return (const float*)cached("f32:" + key, [&]() { return upload("f32:" + key, t.data.data(), t.data.size() * 4); });
+  }
+  // sinusoidal temporal PE table [max_len][C]  (motion_module.py:225-239), regenerated (non-persistent buffer)
+  const float* pe_table(int C, int max_len) {
+    const std::string name = "pe:" + std::to_string(C) + ":" + std::to_string(max_len);
+    return (const float*)cached(name, [&]() {
+      std::vector<float> h((size_t)max_len * C);
+      const float k = (float)(-std::log(10000.0) / (double)C);
+      for (int pos = 0; pos < max_len; ++pos)
+        for (int i = 0; i < C; i += 2) {
+          const float div = std::exp((float)i * k);
+          const float a = (float)pos * div;
+          h[(size_t)pos * C + i] = std::sin(a);
+          if (i + 1 < C) h[(size_t)pos * C + i + 1] = std::cos(a);
+        }
+      return upload(name, h.data(), h.size() * 4);
+    });
+  }
+
+  // ------------------------------------------------------------------ plan helpers
+  template <class T>
+  T* at(size_t off) const { return (T*)(arena_base + off); }
+
+  Act new_act(int nimg, int h, int w, int C) {
+    Act a;
+    const size_t bytes = (size_t)nimg * h * w * C * sizeof(bf16);
+    auto b = std::make_shared<Buf>();
+    b->arena = &arena; b->bytes = bytes; b->off = arena.alloc(bytes); b->keep = keep_all;
+    a.buf = b; a.ptr = at<bf16>(b->off); a.nimg = nimg; a.H = h; a.W = w; a.C = C; a.ld = C;
+    return a;
+  }
+  // raw pinned scratch (lives for the whole plan)
+  template <class T>
+  T* new_scratch(size_t count) { return at<T>(arena.alloc(count * sizeof(T))); }
+  // temporary fp32 scratch with lifetime of the returned handle
+  std::shared_ptr<Buf> new_tmp(size_t bytes) {
+    auto b = std::make_shared<Buf>();
+    b->arena = &arena; b->bytes = bytes; b->off = arena.alloc(bytes); b->keep = keep_all;
+    return b;
+  }
+  void emit(std::function<void(hipStream_t)> fn) { if (!dry) ops.push_back(std::move(fn)); }
+  void tap(const std::string& name, const Act& a) {
+    if (!dry && keep_all) taps.push_back(Tap{name, a.ptr, a.rows(), a.C, a.ld});
+  }
+
+  struct GemmOpt {
+    const float* bias = nullptr;
+    const float* rowvec = nullptr; int rowvec_div = 1, rowvec_ld = 0;
+    const Act* res = nullptr;
+    float scale = 1.f;
+    int geglu = 0;
+    Act* out = nullptr;      // write into this existing activation (may alias res)
+  };
+
+  // generic conv / linear.  x1: optional channel-concat second source.
+  Act conv(const Act& x0, const Act* x1, const bf16* w, int Cout, int ksize, int stride, int ups, const GemmOpt& o) {
+    NrGemmParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.a0 = x0.ptr; p.c0 = x0.C; p.lda0 = x0.ld;
+    if (x1) { p.a1 = x1->ptr; p.c1 = x1->C; p.lda1 = x1->ld; }
+    p.H = x0.H; p.W = x0.W;
+    int OH = x0.H, OW = x0.W;
+    if (ksize == 3) {
+      if (ups) { OH *= 2; OW *= 2; }
+      if (stride == 2) { OH = (OH - 1) / 2 + 1; OW = (OW - 1) / 2 + 1; }
+    }
+    p.OH = OH; p.OW = OW; p.ksize = ksize; p.stride = stride; p.ups = ups;
+    p.w = w;
+    p.M = x0.nimg * OH * OW; p.N = Cout; p.K = ksize * ksize * (p.c0 + p.c1);
+    p.bias = o.bias; p.rowvec = o.rowvec; p.rowvec_div = o.rowvec_div; p.rowvec_ld = o.rowvec_ld;
+    p.out_scale = o.scale; p.geglu = o.geglu;
+    const int outC = o.geglu ? Cout / 2 : Cout;
+    Act out = o.out ? *o.out : new_act(x0.nimg, OH, OW, outC);
+    if (out.C != outC || out.rows() != p.M) throw NrError(NR_ERR_STATE, "conv: output shape mismatch");
+    if (o.res) {
+      if (o.res->C != outC || o.res->rows() != p.M) throw NrError(NR_ERR_STATE, "conv: residual shape mismatch");
+      p.res = o.res->ptr; p.ldr = o.res->ld;
+    }
+    p.out = out.ptr; p.ldo = out.ld;
+    emit([p](hipStream_t s) { LAUNCH_OK(nr_launch_igemm(&p, s)); });
+    return out;
+  }
+  Act linear(const Act& x, const bf16* w, int N, const GemmOpt& o) { return conv(x, nullptr, w, N, 1, 1, 0, o); }
+
+  Act groupnorm(const Act& x0, const Act* x1, const std::string& prefix, float eps, int silu) {
+    const int C = x0.C + (x1 ? x1->C : 0);
+    NrGnParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.x0 = x0.ptr; p.c0 = x0.C; p.ld0 = x0.ld;
+    if (x1) { p.x1 = x1->ptr; p.c1 = x1->C; p.ld1 = x1->ld; }
+    p.nimg = x0.nimg; p.hw = x0.H * x0.W; p.groups = cfg.norm_num_groups;
+    p.gamma = w_f32(prefix + ".weight", C); p.beta = w_f32(prefix + ".bias", C);
+    p.eps = eps; p.silu = silu;
+    const int nfl = nr_gn_workspace_floats(p.nimg, p.hw, p.groups, nullptr, nullptr);
+    auto ws = new_tmp((size_t)nfl * sizeof(float));
+    p.partial = at<float>(ws->off);
+    Act out = new_act(x0.nimg, x0.H, x0.W, C);
+    p.out = out.ptr; p.ldo = out.ld;
+    emit([p](hipStream_t s) { NrGnParams q = p; LAUNCH_OK(nr_launch_groupnorm(&q, s)); });
+    return out;
+  }
+
+  Act layernorm(const Act& x, const std::string& prefix, const float* pe, int pe_F) {
+    const float* g = w_f32(prefix + ".weight", x.C);
+    const float* b = w_f32(prefix + ".bias", x.C);
+    Act out = new_act(x.nimg, x.H, x.W, x.C);
+    const bf16* xp = x.ptr; bf16* op = out.ptr;
+    const int ldx = x.ld, ldo = out.ld, M = (int)x.rows(), C = x.C, hw = x.H * x.W;
+    emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_layernorm(xp, ldx, op, ldo, M, C, g, b, 1e-5f, pe, hw, pe_F, s)); });
+    return out;
+  }
+
+  // mode 0 spatial self (qkv fused [M][3C]); 1 cross (q [M][C], kv [B2*ctx][2C]); 2 temporal self (qkv fused)
+  Act attention(int mode, const Act& q, const Act* kv, int C, int heads) {
+    NrAttnParams p;
+    std::memset(&p, 0, sizeof(p));
+    const int hw = q.H * q.W;
+    const int d = C / heads;
+    Act out = new_act(q.nimg, q.H, q.W, C);
+    p.heads = heads; p.d = d; p.scale = 1.0f / std::sqrt((float)d);
+    p.out = out.ptr;
+    if (mode == 0) {
+      p.q = q.ptr; p.k = q.ptr + C; p.v = q.ptr + 2 * C;
+      p.nbatch = q.nimg; p.Lq = hw; p.Lk = hw;
+      p.inner = 1; p.q_outer = (long long)hw * q.ld; p.q_inner_stride = 0; p.q_seq = q.ld;
+      p.kv_inner = 1; p.kv_outer = p.q_outer; p.kv_inner_stride = 0; p.kv_seq = q.ld; p.kv_div = 1;
+      p.o_outer = (long long)hw * out.ld; p.o_inner_stride = 0; p.o_seq = out.ld;
+    } else if (mode == 1) {
+      p.q = q.ptr; p.k = kv->ptr; p.v = kv->ptr + C;
+      p.nbatch = q.nimg; p.Lq = hw; p.Lk = ctx_len;
+      p.inner = 1; p.q_outer = (long long)hw * q.ld; p.q_inner_stride = 0; p.q_seq = q.ld;
+      p.kv_inner = 1; p.kv_outer = (long long)ctx_len * kv->ld; p.kv_inner_stride = 0; p.kv_seq = kv->ld; p.kv_div = F;
+      p.o_outer = (long long)hw * out.ld; p.o_inner_stride = 0; p.o_seq = out.ld;
+    } else {
+      p.q = q.ptr; p.k = q.ptr + C; p.v = q.ptr + 2 * C;
+      p.nbatch = (q.nimg / F) * hw; p.Lq = F; p.Lk = F;
+      p.inner = hw; p.q_outer = (long long)F * hw * q.ld; p.q_inner_stride = q.ld; p.q_seq = (long long)hw * q.ld;
+      p.kv_inner = hw; p.kv_outer = p.q_outer; p.kv_inner_stride = q.ld; p.kv_seq = p.q_seq; p.kv_div = 1;
+      p.o_outer = (long long)F * hw * out.ld; p.o_inner_stride = out.ld; p.o_seq = (long long)hw * out.ld;
+    }
+    emit([p](hipStream_t s) { LAUNCH_OK(nr_launch_attention(&p, s)); });
+    return out;
+  }
+
+  // ------------------------------------------------------------------ module builders
+  struct TembSlot { std::string prefix; int off, C; };
+  std::vector<TembSlot> temb_slots;   // filled by a pre-pass over the topology
+  float* temb_all = nullptr;          // [B2][temb_total]
+  const float* temb_for(const std::string& prefix, int C) {
+    for (auto& s : temb_slots) if (s.prefix == prefix) {
+      if (s.C != C) throw NrError(NR_ERR_STATE, "temb slot size mismatch for " + prefix);
+      return temb_all + s.off;
+    }
+    throw NrError(NR_ERR_STATE, "no temb slot for " + prefix);
+  }
+
+  // ResnetBlock3D.forward (resnet.py:182-212); x1 = skip tensor for the up-block concat
+  Act resnet(const Act& x0, const Act* x1, const std::string& pre, int Cout) {
+    const int Cin = x0.C + (x1 ? x1->C : 0);
+    const int hw = x0.H * x0.W;
+    Act h = groupnorm(x0, x1, pre + ".norm1", cfg.norm_eps, 1);
+    GemmOpt o1;
+    o1.bias = w_f32(pre + ".conv1.bias", Cout);
+    o1.rowvec = temb_for(pre, Cout); o1.rowvec_div = F * hw; o1.rowvec_ld = temb_total;
+    Act h1 = conv(h, nullptr, w_conv3(pre + ".conv1.weight", Cout, Cin), Cout, 3, 1, 0, o1);
+    h = Act();
+    Act h2 = groupnorm(h1, nullptr, pre + ".norm2", cfg.norm_eps, 1);
+    h1 = Act();
+    Act sc;
+    const bool shortcut = has(pre + ".conv_shortcut.weight");
+    if (shortcut) {
+      GemmOpt os; os.bias = w_f32(pre + ".conv_shortcut.bias", Cout);
+      sc = conv(x0, x1, w_linear(pre + ".conv_shortcut.weight", Cout, Cin), Cout, 1, 1, 0, os);
+    } else {
+      if (x1 || Cin != Cout) throw NrError(NR_ERR_MISSING_WEIGHT, "missing state-dict entry: " + pre + ".conv_shortcut.weight");
+      sc = x0;
+    }
+    GemmOpt o2;
+    o2.bias = w_f32(pre + ".conv2.bias", Cout);
+    o2.res = &sc;
+    Act out = conv(h2, nullptr, w_conv3(pre + ".conv2.weight", Cout, Cout), Cout, 3, 1, 0, o2);
+    tap(pre, out);
+    return out;
+  }
+
+  // FeedForward(GEGLU) + residual, in place on t (motion_module_new.py:441-471,497-518)
+  void feed_forward(Act& t, const Act& normed, const std::string& pre) {
+    const int C = t.C, inner = 4 * C;
+    GemmOpt o1; o1.bias = b_geglu(pre + ".net.0.proj.bias", inner); o1.geglu = 1;
+    Act hmid = linear(normed, w_geglu(pre + ".net.0.proj.weight", inner, C), 2 * inner, o1);
+    GemmOpt o2; o2.bias = w_f32(pre + ".net.2.bias", C); o2.res = &t; o2.out = &t;
+    linear(hmid, w_linear(pre + ".net.2.weight", C, inner), C, o2);
+  }
+
+  // Transformer3DModel.forward (attention.py:95-142) with one BasicTransformerBlock (:256-300)
+  Act spatial_transformer(const Act& x, const Act& ctx_bf, const std::string& pre) {
+    const int C = x.C, heads = cfg.num_heads;
+    Act hn = groupnorm(x, nullptr, pre + ".norm", 1e-6f, 0);
+    GemmOpt oi; oi.bias = w_f32(pre + ".proj_in.bias", C);
+    Act t = linear(hn, w_linear(pre + ".proj_in.weight", C, C), C, oi);
+    hn = Act();
+    const std::string b = pre + ".transformer_blocks.0";
+    {  // self-attention
+      Act n1 = layernorm(t, b + ".norm1", nullptr, 1);
+      GemmOpt oq;
+      Act qkv = linear(n1, w_linear_cat({b + ".attn1.to_q.weight", b + ".attn1.to_k.weight", b + ".attn1.to_v.weight"}, C, C), 3 * C, oq);
+      n1 = Act();
+      Act a = attention(0, qkv, nullptr, C, heads);
+      qkv = Act();
+      GemmOpt oo; oo.bias = w_f32(b + ".attn1.to_out.0.bias", C); oo.res = &t; oo.out = &t;
+      linear(a, w_linear(b + ".attn1.to_out.0.weight", C, C), C, oo);
+    }
+    {  // cross-attention on the text context (attention.py:100: context repeated per frame)
+      Act n2 = layernorm(t, b + ".norm2", nullptr, 1);
+      GemmOpt oq;
+      Act q = linear(n2, w_linear(b + ".attn2.to_q.weight", C, C), C, oq);
+      n2 = Act();
+      GemmOpt ok;
+      Act kv = linear(ctx_bf, w_linear_cat({b + ".attn2.to_k.weight", b + ".attn2.to_v.weight"}, C, cfg.cross_attention_dim), 2 * C, ok);
+      Act a = attention(1, q, &kv, C, heads);
+      q = Act(); kv = Act();
+      GemmOpt oo; oo.bias = w_f32(b + ".attn2.to_out.0.bias", C); oo.res = &t; oo.out = &t;
+      linear(a, w_linear(b + ".attn2.to_out.0.weight", C, C), C, oo);
+    }
+    {
+      Act n3 = layernorm(t, b + ".norm3", nullptr, 1);
+      feed_forward(t, n3, b + ".ff");
+    }
+    GemmOpt op; op.bias = w_f32(pre + ".proj_out.bias", C); op.res = &x;
+    Act out = linear(t, w_linear(pre + ".proj_out.weight", C, C), C, op);
+    tap(pre, out);
+    return out;
+  }
+
+  // VanillaTemporalModule -> TemporalTransformer3DModel.forward (motion_module.py:134-158)
+  Act temporal_module(const Act& x, const std::string& pre0) {
+    const std::string pre = pre0 + ".temporal_transformer";
+    const int C = x.C, heads = cfg.motion_num_heads;
+    if (F > cfg.motion_pe_max_len)
+      throw NrError(NR_ERR_ARG, "video_length " + std::to_string(F) + " exceeds temporal_position_encoding_max_len " +
+                                    std::to_string(cfg.motion_pe_max_len));
+    Act hn = groupnorm(x, nullptr, pre + ".norm", 1e-6f, 0);
+    GemmOpt oi; oi.bias = w_f32(pre + ".proj_in.bias", C);
+    Act t = linear(hn, w_linear(pre + ".proj_in.weight", C, C), C, oi);
+    hn = Act();
+    const std::string b = pre + ".transformer_blocks.0";
+    const float* pe = pe_table(C, cfg.motion_pe_max_len);
+    for (int k = 0; k < cfg.motion_num_attention_blocks; ++k) {
+      const std::string ab = b + ".attention_blocks." + std::to_string(k);
+      Act n = layernorm(t, b + ".norms." + std::to_string(k), pe, F);   // LayerNorm, then + pe[frame] (motion_module.py:212,277)
+      GemmOpt oq;
+      Act qkv = linear(n, w_linear_cat({ab + ".to_q.weight", ab + ".to_k.weight", ab + ".to_v.weight"}, C, C), 3 * C, oq);
+      n = Act();
+      Act a = attention(2, qkv, nullptr, C, heads);
+      qkv = Act();
+      GemmOpt oo; oo.bias = w_f32(ab + ".to_out.0.bias", C); oo.res = &t; oo.out = &t;
+      linear(a, w_linear(ab + ".to_out.0.weight", C, C), C, oo);
+    }
+    {
+      Act n = layernorm(t, b + ".ff_norm", nullptr, 1);
+      feed_forward(t, n, b + ".ff");
+    }
+    GemmOpt op; op.bias = w_f32(pre + ".proj_out.bias", C); op.res = &x;
+    Act out = linear(t, w_linear(pre + ".proj_out.weight", C, C), C, op);
+    tap(pre0, out);
+    return out;
+  }
+
+  // ------------------------------------------------------------------ topology
+  // enumerate resnets (prefix, Cout) in definition order: used for the batched time-embedding projection
+  void enumerate_resnets(std::vector<TembSlot>& out) const {
+    int off = 0;
+    auto add = [&](const std::string& p, int C) { out.push_back(TembSlot{p, off, C}); off += C; };
+    const int L = cfg.num_levels;
+    for (int i = 0; i < L; ++i)
+      for (int j = 0; j < cfg.layers_per_block; ++j)
+        add("down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), cfg.block_out_channels[i]);
+    add("mid_block.resnets.0", cfg.block_out_channels[L - 1]);
+    add("mid_block.resnets.1", cfg.block_out_channels[L - 1]);
+    if (cfg.kind == NR_KIND_UNET3D)
+      for (int i = 0; i < L; ++i)
+        for (int j = 0; j < cfg.layers_per_block + 1; ++j)
+          add("up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), cfg.block_out_channels[L - 1 - i]);
+  }
+
+  void build() {
+    const int L = cfg.num_levels;
+    const int C0 = cfg.block_out_channels[0];
+    const int temb_dim = 4 * C0;
+    const int nimg = B2 * F;
+    ops.clear(); taps.clear(); arena.reset();
+    temb_slots.clear();
+    enumerate_resnets(temb_slots);
+    temb_total = 0;
+    for (auto& s : temb_slots) temb_total += s.C;
+
+    // ---- time embedding (unet.py:371-392): sinusoid -> Linear -> SiLU -> Linear ; then every
+    // resnet's Linear(SiLU(emb)) (resnet.py:191) in ONE batched launch ----
+    t_dev = new_scratch<float>(16);
+    float* sincos = new_scratch<float>((size_t)B2 * C0);
+    float* emb1 = new_scratch<float>((size_t)B2 * temb_dim);
+    float* emb = new_scratch<float>((size_t)B2 * temb_dim);
+    temb_all = new_scratch<float>((size_t)B2 * temb_total);
+    {
+      const bf16* w1 = w_linear("time_embedding.linear_1.weight", temb_dim, C0);
+      const float* b1 = w_f32("time_embedding.linear_1.bias", temb_dim);
+      const bf16* w2 = w_linear("time_embedding.linear_2.weight", temb_dim, temb_dim);
+      const float* b2 = w_f32("time_embedding.linear_2.bias", temb_dim);
+      // concatenated time_emb_proj weights
+      std::vector<std::string> wk, bk;
+      for (auto& s : temb_slots) { wk.push_back(s.prefix + ".time_emb_proj.weight"); bk.push_back(s.prefix + ".time_emb_proj.bias"); }
+      std::string wname = "tembw:" + std::to_string(cfg.kind), bname = "tembb:" + std::to_string(cfg.kind);
+      for (auto& s : temb_slots) {
+        check_shape(s.prefix + ".time_emb_proj.weight", need(s.prefix + ".time_emb_proj.weight"), {s.C, temb_dim});
+        check_shape(s.prefix + ".time_emb_proj.bias", need(s.prefix + ".time_emb_proj.bias"), {s.C});
+      }
+      const bf16* wp = (const bf16*)cached(wname, [&]() {
+        std::vector<uint16_t> h((size_t)temb_total * temb_dim);
+        size_t o = 0;
+        for (auto& k : wk) { const HostTensor& t = need(k); for (float f : t.data) h[o++] = f2bf_host(f); }
+        return upload(wname, h.data(), h.size() * 2);
+      });
+      const float* bp = (const float*)cached(bname, [&]() {
+        std::vector<float> h; h.reserve(temb_total);
+        for (auto& k : bk) { const HostTensor& t = need(k); h.insert(h.end(), t.data.begin(), t.data.end()); }
+        return upload(bname, h.data(), h.size() * 4);
+      });
+      float* td = t_dev; float* ta = temb_all;
+      const int b2n = B2, tt = temb_total;
+      emit([=](hipStream_t s) {
+        LAUNCH_OK(nr_launch_timestep_sincos(td, b2n, C0, sincos, s));
+        LAUNCH_OK(nr_launch_linear_small(sincos, b2n, C0, w1, b1, temb_dim, 0, 1, emb1, s));   // Linear + SiLU
+        LAUNCH_OK(nr_launch_linear_small(emb1, b2n, temb_dim, w2, b2, temb_dim, 0, 0, emb, s)); // emb
+        LAUNCH_OK(nr_launch_linear_small(emb, b2n, temb_dim, wp, bp, tt, 1, 0, ta, s));         // Linear(SiLU(emb)) for all resnets
+      });
+    }
+
+    // ---- text context fp32 -> bf16 [B2*ctx_len][cross_dim] ----
+    Act ctx_bf = new_act(1, 1, B2 * ctx_len, cfg.cross_attention_dim);
+    {
+      bf16* cp = ctx_bf.ptr; const long long n = (long long)B2 * ctx_len * cfg.cross_attention_dim;
+      emit([this, cp, n](hipStream_t s) { LAUNCH_OK(nr_launch_f32_to_bf16(io.ctx, cp, n, s)); });
+    }
+
+    // ---- conv_in ----
+    Act x = new_act(nimg, H, W, C0);
+    if (cfg.kind == NR_KIND_UNET3D) {
+      const float* wT = w_conv_in("conv_in.weight", C0, cfg.in_channels);
+      const float* bi = w_f32("conv_in.bias", C0);
+      bf16* xp = x.ptr; const int ic = cfg.in_channels, b2n = B2, Fn = F, Hn = H, Wn = W;
+      emit([=, this](hipStream_t s) {
+        LAUNCH_OK(nr_launch_conv_in_small(io.sample, nullptr, ic, 0, b2n, nimg, Fn, Hn, Wn, wT, bi, nullptr, C0, xp, s));
+      });
+    } else {
+      // sparse_controlnet.py:467-521: sample := 0 -> conv_in(0) = bias; + cond_embedding(cat[cond, mask])
+      const int cc = cfg.conditioning_channels;
+      const float* wTe = w_conv_in("controlnet_cond_embedding.weight", C0, cc + 1);
+      const float* be = w_f32("controlnet_cond_embedding.bias", C0);
+      const float* bi = w_f32("conv_in.bias", C0);
+      bf16* xp = x.ptr; const int Fn = F, Hn = H, Wn = W;
+      if (cfg.set_noisy_sample_input_to_zero) {
+        emit([=, this](hipStream_t s) {
+          LAUNCH_OK(nr_launch_conv_in_small(io.cond, io.mask, cc, 1, io.cond_batch, nimg, Fn, Hn, Wn, wTe, be, bi, C0, xp, s));
+        });
+      } else {
+        const float* wT = w_conv_in("conv_in.weight", C0, cfg.in_channels);
+        Act x2 = new_act(nimg, H, W, C0);
+        bf16* x2p = x2.ptr; const int ic = cfg.in_channels, b2n = B2;
+        const long long n = (long long)nimg * H * W * C0;
+        emit([=, this](hipStream_t s) {
+          LAUNCH_OK(nr_launch_conv_in_small(io.sample, nullptr, ic, 0, b2n, nimg, Fn, Hn, Wn, wT, bi, nullptr, C0, xp, s));
+          LAUNCH_OK(nr_launch_conv_in_small(io.cond, io.mask, cc, 1, io.cond_batch, nimg, Fn, Hn, Wn, wTe, be, nullptr, C0, x2p, s));
+          LAUNCH_OK(nr_launch_add_bf16(xp, x2p, xp, n, s));
+        });
+      }
+    }
+    tap("conv_in", x);
+
+    // ---- down blocks ----
+    std::vector<Act> skips;
+    skips.push_back(x);
+    for (int i = 0; i < L; ++i) {
+      const int Cout = cfg.block_out_channels[i];
+      const std::string bp = "down_blocks." + std::to_string(i);
+      for (int j = 0; j < cfg.layers_per_block; ++j) {
+        x = resnet(x, nullptr, bp + ".resnets." + std::to_string(j), Cout);
+        if (cfg.down_block_has_attn[i]) x = spatial_transformer(x, ctx_bf, bp + ".attentions." + std::to_string(j));
+        if (cfg.use_motion_module) x = temporal_module(x, bp + ".motion_modules." + std::to_string(j));
+        skips.push_back(x);
+      }
+      if (i != L - 1) {
+        GemmOpt o; o.bias = w_f32(bp + ".downsamplers.0.conv.bias", Cout);
+        x = conv(x, nullptr, w_conv3(bp + ".downsamplers.0.conv.weight", Cout, Cout), Cout, 3, 2, 0, o);
+        tap(bp + ".downsamplers.0", x);
+        skips.push_back(x);
+      }
+    }
+    n_res = (int)skips.size();
+    res_shapes.clear();
+    for (auto& s : skips) res_shapes.push_back(ResShape{s.C, s.H, s.W});
+
+    // ---- mid block (unet_blocks.py:271-278) ----
+    Act mid_in = x;
+    {
+      const int Cm = cfg.block_out_channels[L - 1];
+      x = resnet(x, nullptr, "mid_block.resnets.0", Cm);
+      x = spatial_transformer(x, ctx_bf, "mid_block.attentions.0");
+      if (cfg.use_motion_module && cfg.motion_module_mid_block) x = temporal_module(x, "mid_block.motion_modules.0");
+      x = resnet(x, nullptr, "mid_block.resnets.1", Cm);
+    }
+    res_shapes.push_back(ResShape{x.C, x.H, x.W});
+    mid_in = Act();
+
+    if (cfg.kind == NR_KIND_SPARSECTRL) {
+      // ---- zero-conv heads (sparse_controlnet.py:551-566): 1x1 conv, * conditioning_scale ----
+      for (int i = 0; i <= n_res; ++i) {
+        const bool is_mid = i == n_res;
+        const Act& src = is_mid ? x : skips[i];
+        const std::string key = is_mid ? std::string("controlnet_mid_block") : "controlnet_down_blocks." + std::to_string(i);
+        NrGemmParams p;
+        std::memset(&p, 0, sizeof(p));
+        p.a0 = src.ptr; p.c0 = src.C; p.lda0 = src.ld; p.H = src.H; p.W = src.W; p.OH = src.H; p.OW = src.W;
+        p.ksize = 1; p.stride = 1; p.w = w_linear(key + ".weight", src.C, src.C);
+        p.M = (int)src.rows(); p.N = src.C; p.K = src.C; p.bias = w_f32(key + ".bias", src.C);
+        p.ldo = src.C; p.out_scale = 1.f;
+        emit([this, p, i, is_mid](hipStream_t s) {
+          NrGemmParams q = p;
+          q.out = (bf16*)(is_mid ? io.out_mid : io.out_down[i]);
+          q.out_scale = io.scale;
+          LAUNCH_OK(nr_launch_igemm(&q, s));
+        });
+      }
+      return;
+    }
+
+    // ---- ControlNet residual adds (unet.py:422-428,436-439) ----
+    {
+      std::vector<Act> added(skips.size());
+      for (int i = 0; i < n_res; ++i) {
+        // all skips but the last have already been consumed by their successor layer -> add in place;
+        // the last one is also the mid-block input, which must stay un-added: it was consumed above, so in place is safe too.
+        const Act s = skips[i];
+        const long long n = (long long)s.rows() * s.C;
+        bf16* sp = s.ptr;
+        emit([this, sp, n, i](hipStream_t st) {
+          if (io.has_res) LAUNCH_OK(nr_launch_add_bf16(sp, (const bf16*)io.down_res[i], sp, n, st));
+        });
+      }
+      const long long n = (long long)x.rows() * x.C;
+      bf16* xp = x.ptr;
+      emit([this, xp, n](hipStream_t st) {
+        if (io.has_res) LAUNCH_OK(nr_launch_add_bf16(xp, (const bf16*)io.mid_res, xp, n, st));
+      });
+    }
+
+    // ---- up blocks (unet_blocks.py:621-667,735-760) ----
+    for (int i = 0; i < L; ++i) {
+      const int Cout = cfg.block_out_channels[L - 1 - i];
+      const std::string bp = "up_blocks." + std::to_string(i);
+      for (int j = 0; j < cfg.layers_per_block + 1; ++j) {
+        Act skip = skips.back();
+        skips.pop_back();
+        x = resnet(x, &skip, bp + ".resnets." + std::to_string(j), Cout);
+        skip = Act();
+        if (cfg.up_block_has_attn[i]) x = spatial_transformer(x, ctx_bf, bp + ".attentions." + std::to_string(j));
+        if (cfg.use_motion_module) x = temporal_module(x, bp + ".motion_modules." + std::to_string(j));
+      }
+      if (i != L - 1) {
+        GemmOpt o; o.bias = w_f32(bp + ".upsamplers.0.conv.bias", Cout);
+        x = conv(x, nullptr, w_conv3(bp + ".upsamplers.0.conv.weight", Cout, Cout), Cout, 3, 1, 1, o);
+        tap(bp + ".upsamplers.0", x);
+      }
+    }
+
+    // ---- out (unet.py:468-470) ----
+    Act hn = groupnorm(x, nullptr, "conv_norm_out", cfg.norm_eps, 1);
+    {
+      const HostTensor& wt = need("conv_out.weight");
+      check_shape("conv_out.weight", wt, {cfg.out_channels, C0, 3, 3});
+      const bf16* wo = w_conv3("conv_out.weight", cfg.out_channels, C0);
+      const float* bo = w_f32("conv_out.bias", cfg.out_channels);
+      const bf16* hp = hn.ptr; const int Fn = F, Hn = H, Wn = W, oc = cfg.out_channels;
+      emit([=, this](hipStream_t s) { LAUNCH_OK(nr_launch_conv_out_small(hp, C0, nimg, Fn, Hn, Wn, wo, bo, oc, io.out, s)); });
+    }
+  }
+
+  void plan(int batch, int frames, int h, int w, int ctxl) {
+    if (batch <= 0 || batch > 16 || frames <= 0 || h <= 0 || w <= 0 || ctxl <= 0) throw NrError(NR_ERR_ARG, "plan: bad shape");
+    const int down = 1 << (cfg.num_levels - 1);
+    if (h % down != 0 || w % down != 0)
+      throw NrError(NR_ERR_ARG, "plan: latent h,w must be multiples of " + std::to_string(down));
+    HIP_OK(hipDeviceSynchronize());
+    if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
+    B2 = batch; F = frames; H = h; W = w; ctx_len = ctxl;
+    planned = false;
+    // pass 1: sizes only
+    dry = true;
+    char* old = arena_base; arena_base = nullptr;
+    build();
+    const size_t need_bytes = arena.high + 256;
+    dry = false;
+    arena_base = old;
+    if (need_bytes > arena_bytes) {
+      if (arena_base) { HIP_OK(hipFree(arena_base)); arena_base = nullptr; }
+      HIP_OK(hipMalloc((void**)&arena_base, need_bytes));
+      arena_bytes = need_bytes;
+    }
+    // pass 2: real pointers, weights uploaded
+    build();
+    HIP_OK(hipDeviceSynchronize());
+    planned = true;
+  }
+
+  void run(hipStream_t s, const float* timesteps) {
+    TimestepVals tv;
+    for (int i = 0; i < 16; ++i) tv.v[i] = i < B2 ? timesteps[i] : 0.f;
+    hipLaunchKernelGGL(set_timesteps_kernel, dim3(1), dim3(64), 0, s, t_dev, tv, B2);
+    if (!use_graph) {
+      for (auto& op : ops) op(s);
+      return;
+    }
+    if (!gexec || !(captured == io) || captured_stream != s) {
+      if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
+      hipGraph_t g = nullptr;
+      HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      try {
+        for (auto& op : ops) op(s);
+      } catch (...) {
+        (void)hipStreamEndCapture(s, &g);
+        if (g) (void)hipGraphDestroy(g);
+        throw;
+      }
+      HIP_OK(hipStreamEndCapture(s, &g));
+      hipError_t e = hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      if (e != hipSuccess) { gexec = nullptr; throw NrError(NR_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+      captured = io; captured_stream = s;
+    }
+    HIP_OK(hipGraphLaunch(gexec, s));
+  }
+};
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+#define NR_TRY try {
+#define NR_CATCH                                                         \
+  }                                                                      \
+  catch (const NrError& e) { set_err(e.what()); return e.code; }         \
+  catch (const std::exception& e) { set_err(e.what()); return NR_ERR_STATE; } \
+  return NR_OK;
+
+extern "C" const char* nr_last_error(void) { return g_err.c_str(); }
+
+extern "C" nr_status nr_net_create(const nr_net_config* cfg, nr_net** out) {
+  NR_TRY
+  if (!cfg || !out) throw NrError(NR_ERR_ARG, "null argument");
+  if (cfg->num_levels < 2 || cfg->num_levels > NR_MAX_LEVELS) throw NrError(NR_ERR_ARG, "num_levels must be 2..4");
+  if (cfg->kind != NR_KIND_UNET3D && cfg->kind != NR_KIND_SPARSECTRL) throw NrError(NR_ERR_ARG, "bad kind");
+  for (int i = 0; i < cfg->num_levels; ++i) {
+    const int C = cfg->block_out_channels[i];
+    if (C % 64 != 0) throw NrError(NR_ERR_UNSUPPORTED, "block_out_channels must be multiples of 64");
+    if (C % cfg->norm_num_groups != 0) throw NrError(NR_ERR_ARG, "channels not divisible by norm_num_groups");
+    if (C % cfg->num_heads != 0 || (C / cfg->num_heads) % 8 != 0 || C / cfg->num_heads > 160)
+      throw NrError(NR_ERR_UNSUPPORTED, "head dim must be a multiple of 8 and <= 160");
+  }
+  if (cfg->cross_attention_dim % 64 != 0) throw NrError(NR_ERR_UNSUPPORTED, "cross_attention_dim must be a multiple of 64");
+  if (cfg->norm_num_groups > 64) throw NrError(NR_ERR_UNSUPPORTED, "norm_num_groups > 64");
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) throw NrError(NR_ERR_HIP, "no HIP device available: libneurons_amd requires an MI355X (gfx950) GPU");
+  nr_net* h = new nr_net();
+  h->cfg = *cfg;
+  *out = h;
+  NR_CATCH
+}
+
+extern "C" void nr_net_destroy(nr_net* h) { delete h; }
+
+extern "C" nr_status nr_net_load_tensor(nr_net* h, const char* key, const float* host_data, const int64_t* shape, int32_t ndim) {
+  NR_TRY
+  if (!h || !key || !host_data || ndim < 0 || ndim > 8) throw NrError(NR_ERR_ARG, "bad argument");
+  HostTensor t;
+  int64_t n = 1;
+  for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= shape[i]; }
+  t.data.assign(host_data, host_data + n);
+  h->host[key] = std::move(t);
+  // a reload invalidates converted copies derived from this key
+  for (auto it = h->dev.begin(); it != h->dev.end();) {
+    if (it->first.find(key) != std::string::npos || it->first.rfind("temb", 0) == 0) {
+      (void)hipDeviceSynchronize();
+      (void)hipFree(it->second);
+      it = h->dev.erase(it);
+      h->planned = false;
+    } else ++it;
+  }
+  NR_CATCH
+}
+
+extern "C" nr_status nr_net_plan(nr_net* h, int32_t batch, int32_t frames, int32_t lat_h, int32_t lat_w, int32_t ctx_len) {
+  NR_TRY
+  if (!h) throw NrError(NR_ERR_ARG, "null handle");
+  h->plan(batch, frames, lat_h, lat_w, ctx_len);
+  NR_CATCH
+}
+
+extern "C" nr_status nr_net_set_graph(nr_net* h, int32_t enable) {
+  NR_TRY
+  if (!h) throw NrError(NR_ERR_ARG, "null handle");
+  h->use_graph = enable != 0;
+  NR_CATCH
+}
+
+extern "C" nr_status nr_net_set_debug(nr_net* h, int32_t keep) {
+  NR_TRY
+  if (!h) throw NrError(NR_ERR_ARG, "null handle");
+  h->keep_all = keep != 0;
+  h->planned = false;
+  NR_CATCH
+}
+
+extern "C" int64_t nr_net_workspace_bytes(const nr_net* h) { return h ? (int64_t)h->arena_bytes : 0; }
+extern "C" int64_t nr_net_weight_bytes(const nr_net* h) { return h ? (int64_t)h->weight_bytes : 0; }
+extern "C" int32_t nr_net_num_residuals(const nr_net* h) { return h ? h->n_res : 0; }
+extern "C" nr_status nr_net_residual_shape(const nr_net* h, int32_t i, int32_t* C, int32_t* hh, int32_t* ww) {
+  NR_TRY
+  if (!h || !h->planned) throw NrError(NR_ERR_STATE, "not planned");
+  if (i < 0 || i >= (int)h->res_shapes.size()) throw NrError(NR_ERR_ARG, "residual index out of range");
+  *C = h->res_shapes[i].C; *hh = h->res_shapes[i].h; *ww = h->res_shapes[i].w;
+  NR_CATCH
+}
+
+extern "C" nr_status nr_unet3d_forward(nr_net* h, nr_stream stream, const float* sample_dev, const float* timesteps,
+                                       const float* ctx_dev, int32_t ctx_len, const void* const* down_res_dev,
+                                       const void* mid_res_dev, float* out_dev) {
+  NR_TRY
+  if (!h || h->cfg.kind != NR_KIND_UNET3D) throw NrError(NR_ERR_ARG, "handle is not a UNet3D");
+  if (!h->planned) throw NrError(NR_ERR_STATE, "nr_net_plan() has not been called (or weights changed since)");
+  if (!sample_dev || !timesteps || !ctx_dev || !out_dev) throw NrError(NR_ERR_ARG, "null tensor argument");
+  if (ctx_len != h->ctx_len) throw NrError(NR_ERR_ARG, "ctx_len differs from the planned value");
+  if ((down_res_dev == nullptr) != (mid_res_dev == nullptr)) throw NrError(NR_ERR_ARG, "down/mid residuals must be given together");
+  IO io;
+  std::memset(&io, 0, sizeof(io));
+  io.sample = sample_dev; io.ctx = ctx_dev; io.out = out_dev; io.scale = 1.f; io.cond_batch = 1;
+  if (down_res_dev) {
+    io.has_res = 1;
+    for (int i = 0; i < h->n_res; ++i) {
+      if (!down_res_dev[i]) throw NrError(NR_ERR_ARG, "null residual pointer");
+      io.down_res[i] = down_res_dev[i];
+    }
+    io.mid_res = mid_res_dev;
+  }
+  h->io = io;
+  h->run((hipStream_t)stream, timesteps);
+  NR_CATCH
+}
+
+extern "C" nr_status nr_sparsectrl_forward(nr_net* h, nr_stream stream, const float* sample_dev, const float* timesteps,
+                                           const float* ctx_dev, int32_t ctx_len, const float* cond_dev,
+                                           const float* mask_dev, int32_t cond_batch, float scale,
+                                           void* const* out_down_dev, void* out_mid_dev) {
+  NR_TRY
+  if (!h || h->cfg.kind != NR_KIND_SPARSECTRL) throw NrError(NR_ERR_ARG, "handle is not a SparseCtrl");
+  if (!h->planned) throw NrError(NR_ERR_STATE, "nr_net_plan() has not been called (or weights changed since)");
+  if (!timesteps || !ctx_dev || !cond_dev || !mask_dev || !out_down_dev || !out_mid_dev) throw NrError(NR_ERR_ARG, "null tensor argument");
+  if (!h->cfg.set_noisy_sample_input_to_zero && !sample_dev) throw NrError(NR_ERR_ARG, "sample required");
+  if (ctx_len != h->ctx_len) throw NrError(NR_ERR_ARG, "ctx_len differs from the planned value");
+  if (cond_batch <= 0 || h->B2 % cond_batch != 0) throw NrError(NR_ERR_ARG, "cond_batch must divide the planned batch");
+  IO io;
+  std::memset(&io, 0, sizeof(io));
+  io.sample = sample_dev; io.ctx = ctx_dev; io.cond = cond_dev; io.mask = mask_dev; io.cond_batch = cond_batch; io.scale = scale;
+  for (int i = 0; i < h->n_res; ++i) {
+    if (!out_down_dev[i]) throw NrError(NR_ERR_ARG, "null output pointer");
+    io.out_down[i] = out_down_dev[i];
+  }
+  io.out_mid = out_mid_dev;
+  h->io = io;
+  h->run((hipStream_t)stream, timesteps);
+  NR_CATCH
+}
+
+extern "C" nr_status nr_cfg_ddim_step(nr_stream stream, const float* eps_dev, const float* x_dev, float* x_out_dev,
+                                      int64_t n, float guidance_scale, int32_t do_cfg, double a_t, double a_prev) {
+  NR_TRY
+  if (!eps_dev || !x_dev || !x_out_dev || n <= 0) throw NrError(NR_ERR_ARG, "bad argument");
+  LAUNCH_OK(nr_launch_cfg_ddim_step(eps_dev, x_dev, x_out_dev, n, guidance_scale, do_cfg, (float)std::sqrt(a_t),
+                                    (float)std::sqrt(1.0 - a_t), (float)std::sqrt(a_prev), (float)std::sqrt(1.0 - a_prev),
+                                    (hipStream_t)stream));
+  NR_CATCH
+}
+
+extern "C" int32_t nr_net_num_taps(const nr_net* h) { return h ? (int32_t)h->taps.size() : 0; }
+extern "C" const char* nr_net_tap_name(const nr_net* h, int32_t i) {
+  if (!h || i < 0 || i >= (int)h->taps.size()) return "";
+  return h->taps[i].name.c_str();
+}
+extern "C" nr_status nr_net_read_tap(nr_net* h, int32_t i, float* host_out, int64_t capacity, int32_t* rows, int32_t* C) {
+  NR_TRY
+  if (!h || i < 0 || i >= (int)h->taps.size()) throw NrError(NR_ERR_ARG, "tap index out of range");
+  const Tap& t = h->taps[i];
+  *rows = (int32_t)t.rows; *C = t.C;
+  if (capacity < t.rows * t.C) throw NrError(NR_ERR_ARG, "tap buffer too small");
+  HIP_OK(hipDeviceSynchronize());
+  std::vector<uint16_t> tmp((size_t)t.rows * t.ld);
+  HIP_OK(hipMemcpy(tmp.data(), t.ptr, tmp.size() * 2, hipMemcpyDeviceToHost));
+  for (int64_t r = 0; r < t.rows; ++r)
+    for (int c = 0; c < t.C; ++c) {
+      const uint32_t u = (uint32_t)tmp[(size_t)r * t.ld + c] << 16;
+      float f; std::memcpy(&f, &u, 4);
+      host_out[(size_t)r * t.C + c] = f;
+    }
+  NR_CATCH
+}
+
+// ---- single-op entry points ---------------------------------------------------------------------
+extern "C" nr_status nr_op_gemm(nr_stream stream, const void* a, int32_t lda, const void* w, const float* bias,
+                                const void* res, int32_t ldr, void* out, int32_t ldo, int32_t M, int32_t N, int32_t K,
+                                int32_t geglu) {
+  NR_TRY
+  NrGemmParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.a0 = (const bf16*)a; p.c0 = K; p.lda0 = lda; p.H = p.W = p.OH = p.OW = 1; p.ksize = 1; p.stride = 1;
+  p.w = (const bf16*)w; p.M = M; p.N = N; p.K = K; p.bias = bias; p.res = (const bf16*)res; p.ldr = ldr;
+  p.out = (bf16*)out; p.ldo = ldo; p.out_scale = 1.f; p.geglu = geglu; p.rowvec_div = 1;
+  LAUNCH_OK(nr_launch_igemm(&p, (hipStream_t)stream));
+  NR_CATCH
+}
+
+extern "C" nr_status nr_op_conv3x3(nr_stream stream, const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t nimg,
+                                   int32_t H, int32_t W, int32_t stride, int32_t ups, const void* w, const float* bias,
+                                   const float* rowvec, int32_t rowvec_div, const void* res, void* out, int32_t Cout) {
+  NR_TRY
+  NrGemmParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.a0 = (const bf16*)x0; p.c0 = c0; p.lda0 = c0; p.a1 = (const bf16*)x1; p.c1 = x1 ? c1 : 0; p.lda1 = c1;
+  p.H = H; p.W = W;
+  int OH = H, OW = W;
+  if (ups) { OH *= 2; OW *= 2; }
+  if (stride == 2) { OH = (OH - 1) / 2 + 1; OW = (OW - 1) / 2 + 1; }
+  p.OH = OH; p.OW = OW; p.ksize = 3; p.stride = stride; p.ups = ups;
+  p.w = (const bf16*)w; p.M = nimg * OH * OW; p.N = Cout; p.K = 9 * (p.c0 + p.c1);
+  p.bias = bias; p.rowvec = rowvec; p.rowvec_div = rowvec_div > 0 ? rowvec_div : 1; p.rowvec_ld = Cout;
+  p.res = (const bf16*)res; p.ldr = Cout; p.out = (bf16*)out; p.ldo = Cout; p.out_scale = 1.f;
+  LAUNCH_OK(nr_launch_igemm(&p, (hipStream_t)stream));
+  NR_CATCH
+}
+
+extern "C" nr_status nr_op_groupnorm(nr_stream stream, const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t nimg,
+                                     int32_t hw, int32_t groups, const float* gamma, const float* beta, float eps,
+                                     int32_t silu, float* partial_ws, void* out) {
+  NR_TRY
+  NrGnParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.x0 = (const bf16*)x0; p.c0 = c0; p.ld0 = c0; p.x1 = (const bf16*)x1; p.c1 = x1 ? c1 : 0; p.ld1 = c1;
+  p.nimg = nimg; p.hw = hw; p.groups = groups; p.partial = partial_ws; p.gamma = gamma; p.beta = beta; p.eps = eps;
+  p.silu = silu; p.out = (bf16*)out; p.ldo = p.c0 + p.c1;
+  LAUNCH_OK(nr_launch_groupnorm(&p, (hipStream_t)stream));
+  NR_CATCH
+}
+
+extern "C" nr_status nr_op_layernorm(nr_stream stream, const void* x, void* out, int32_t M, int32_t C, const float* gamma,
+                                     const float* beta, float eps, const float* pe, int32_t pe_hw, int32_t pe_F) {
+  NR_TRY
+  LAUNCH_OK(nr_launch_layernorm((const bf16*)x, C, (bf16*)out, C, M, C, gamma, beta, eps, pe, pe_hw > 0 ? pe_hw : 1,
+                                pe_F > 0 ? pe_F : 1, (hipStream_t)stream));
+  NR_CATCH
+}
+
+extern "C" nr_status nr_op_attention(nr_stream stream, int32_t mode, const void* qp, const void* kvp, void* outp,
+                                     int32_t nimg, int32_t L, int32_t Lk, int32_t C, int32_t heads, int32_t frames,
+                                     int32_t kv_div) {
+  NR_TRY
+  NrAttnParams p;
+  std::memset(&p, 0, sizeof(p));
+  const bf16* q = (const bf16*)qp; const bf16* kv = (const bf16*)kvp;
+  p.heads = heads; p.d = C / heads; p.scale = 1.0f / std::sqrt((float)p.d); p.out = (bf16*)outp;
+  if (mode == 0) {
+    const int ld = 3 * C;
+    p.q = q; p.k = q + C; p.v = q + 2 * C; p.nbatch = nimg; p.Lq = L; p.Lk = L; p.inner = 1; p.kv_inner = 1; p.kv_div = 1;
+    p.q_outer = (long long)L * ld; p.q_seq = ld; p.kv_outer = p.q_outer; p.kv_seq = ld;
+    p.o_outer = (long long)L * C; p.o_seq = C;
+  } else if (mode == 1) {
+    p.q = q; p.k = kv; p.v = kv + C; p.nbatch = nimg; p.Lq = L; p.Lk = Lk; p.inner = 1; p.kv_inner = 1; p.kv_div = kv_div;
+    p.q_outer = (long long)L * C; p.q_seq = C; p.kv_outer = (long long)Lk * 2 * C; p.kv_seq = 2 * C;
+    p.o_outer = (long long)L * C; p.o_seq = C;
+  } else if (mode == 2) {
+    const int ld = 3 * C, hw = L, F = frames;
+    p.q = q; p.k = q + C; p.v = q + 2 * C; p.nbatch = (nimg / F) * hw; p.Lq = F; p.Lk = F; p.inner = hw; p.kv_inner = hw; p.kv_div = 1;
+    p.q_outer = (long long)F * hw * ld; p.q_inner_stride = ld; p.q_seq = (long long)hw * ld;
+    p.kv_outer = p.q_outer; p.kv_inner_stride = ld; p.kv_seq = p.q_seq;
+    p.o_outer = (long long)F * hw * C; p.o_inner_stride = C; p.o_seq = (long long)hw * C;
+  } else throw NrError(NR_ERR_ARG, "bad attention mode");
+  LAUNCH_OK(nr_launch_attention(&p, (hipStream_t)stream));
+  NR_CATCH
+}

@@ -1,0 +1,223 @@
+// GroupNorm(32 groups, per frame-image) [+SiLU] and LayerNorm [+temporal positional encoding] on
+// channels-last bf16 activations.  HBM-bound kernels: 16-byte vector loads, fp32 statistics.
+//
+// Reference semantics:
+//   InflatedGroupNorm / nn.GroupNorm on "(b f) c h w"   animatediff/models/resnet.py:21-29,
+//       attention.py:61,105, motion_module.py:109,142, unet.py:245,468  (biased variance, eps inside sqrt)
+//   nn.LayerNorm(dim) eps=1e-5                            attention.py:189,206,212; motion_module.py:201,207
+//   PositionalEncoding add after the temporal LayerNorm   motion_module.py:241-243,274-278
+//
+// GroupNorm is two launches: gn_stats (per image x pixel-chunk partial sums, deterministic: no
+// float atomics) and gn_apply (re-reduces the partials, folds gamma/beta/mean/rstd into a per-channel
+// scale+shift held in LDS, streams the pixels).  Both accept a channel-concat of two sources so the
+// up-block skip concat (unet_blocks.py:634,740) is never materialised for the norm.
+#include "common.h"
+
+
+namespace {
+
+// grid (nchunk, nimg), block 256.  dynamic LDS: 2*PL*C floats, PL = pixel lanes (see below)
+__global__ __launch_bounds__(256) void gn_stats_kernel(NrGnParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int C = p.c0 + p.c1;
+  const int CP = C >> 3;                         // 16-byte chunks per pixel
+  const int PL = CP <= 256 ? 256 / CP : 1;       // pixel lanes: thread = (pixel lane, channel chunk)
+  float* chs = lds;                              // [PL][C] per-channel sums
+  float* chq = lds + (size_t)PL * C;             // [PL][C] per-channel sums of squares
+  const int img = blockIdx.y, chunk = blockIdx.x;
+  const int pbeg = chunk * p.pix_per_blk;
+  const int pend = min(p.hw, pbeg + p.pix_per_blk);
+  const int tid = threadIdx.x;
+  const int pl = CP <= 256 ? tid / CP : 0;
+  if (pl < PL) {
+    for (int cc = (CP <= 256 ? tid - pl * CP : tid); cc < CP; cc += 256) {
+      const int c = cc << 3;
+      const bf16* src; int ld;
+      if (c < p.c0) { src = p.x0 + c; ld = p.ld0; } else { src = p.x1 + (c - p.c0); ld = p.ld1; }
+      float s[8], q[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+      for (int px = pbeg + pl; px < pend; px += PL) {
+        const bf16x8 v = *(const bf16x8*)(src + ((size_t)img * p.hw + px) * ld);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s[e] += f; q[e] += f * f; }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { chs[pl * C + c + e] = s[e]; chq[pl * C + c + e] = q[e]; }
+    }
+  }
+  __syncthreads();
+  // group reduce (fixed order => deterministic): 8 threads per group
+  const int cg = C / p.groups;
+  const int g = tid >> 3, sub = tid & 7;
+  if (g < p.groups) {
+    float s = 0.f, q = 0.f;
+    for (int i = sub; i < cg * PL; i += 8) {
+      const int l = i / cg, ci = i - l * cg;
+      s += chs[l * C + g * cg + ci]; q += chq[l * C + g * cg + ci];
+    }
+    s += __shfl_xor(s, 1, 64); q += __shfl_xor(q, 1, 64);
+    s += __shfl_xor(s, 2, 64); q += __shfl_xor(q, 2, 64);
+    s += __shfl_xor(s, 4, 64); q += __shfl_xor(q, 4, 64);
+    if (sub == 0) {
+      float* o = p.partial + (((size_t)img * p.nchunk + chunk) * p.groups + g) * 2;
+      o[0] = s; o[1] = q;
+    }
+  }
+}
+
+// grid (nchunk, nimg), block 256.  dynamic LDS: 2*C floats
+__global__ __launch_bounds__(256) void gn_apply_kernel(NrGnParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int C = p.c0 + p.c1;
+  const int CP = C >> 3;
+  float* sc = lds;       // [C] scale
+  float* sh = lds + C;   // [C] shift
+  __shared__ float gmean[64], grstd[64];
+  const int img = blockIdx.y, chunk = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int cg = C / p.groups;
+  if (tid < p.groups) {
+    float s = 0.f, q = 0.f;
+    for (int k = 0; k < p.nchunk; ++k) {
+      const float* o = p.partial + (((size_t)img * p.nchunk + k) * p.groups + tid) * 2;
+      s += o[0]; q += o[1];
+    }
+    const float inv = 1.0f / ((float)cg * (float)p.hw);
+    const float mean = s * inv;
+    float var = q * inv - mean * mean;
+    var = fmaxf(var, 0.f);
+    gmean[tid] = mean;
+    grstd[tid] = rsqrtf(var + p.eps);
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const int g = c / cg;
+    const float a = p.gamma[c] * grstd[g];
+    sc[c] = a;
+    sh[c] = p.beta[c] - gmean[g] * a;
+  }
+  __syncthreads();
+  const int pbeg = chunk * p.pix_per_blk;
+  const int pend = min(p.hw, pbeg + p.pix_per_blk);
+  const int total = (pend - pbeg) * CP;
+  for (int idx = tid; idx < total; idx += 256) {
+    const int px = pbeg + idx / CP;
+    const int c = (idx % CP) << 3;
+    const bf16* src; int ld;
+    if (c < p.c0) { src = p.x0 + c; ld = p.ld0; } else { src = p.x1 + (c - p.c0); ld = p.ld1; }
+    const size_t row = (size_t)img * p.hw + px;
+    const bf16x8 v = *(const bf16x8*)(src + row * ld);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f = (float)v[e] * sc[c + e] + sh[c + e];
+      if (p.silu) f = silu_f(f);
+      o[e] = (bf16)f;
+    }
+    *(bf16x8*)(p.out + row * p.ldo + c) = o;
+  }
+}
+
+// LayerNorm over the last dim C (C % 8 == 0, C <= 64*8*MAXV); one wave per row; two-pass in registers.
+// pe: optional [pe_len][C] fp32 table added after the affine; frame index = (row / pe_hw) % pe_F.
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__ x, int ldx, bf16* __restrict__ out,
+                                                        int ldo, int M, int C, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        const float* __restrict__ pe, int pe_hw, int pe_F) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int CP = C >> 3;
+  float v[MAXV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int cc = lane + 64 * i;
+    if (cc < CP) {
+      const bf16x8 t = *(const bf16x8*)(x + (size_t)row * ldx + cc * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[i][e] = (float)t[e]; s += v[i][e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+  s = wave_sum(s);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int cc = lane + 64 * i;
+    if (cc < CP) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    }
+  }
+  q = wave_sum(q);
+  const float rstd = rsqrtf(q / (float)C + eps);
+  const float* perow = pe ? pe + (size_t)((row / pe_hw) % pe_F) * C : nullptr;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int cc = lane + 64 * i;
+    if (cc < CP) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = cc * 8 + e;
+        float f = (v[i][e] - mean) * rstd * gamma[c] + beta[c];
+        if (perow) f += perow[c];
+        o[e] = (bf16)f;
+      }
+      *(bf16x8*)(out + (size_t)row * ldo + cc * 8) = o;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int nr_gn_workspace_floats(int nimg, int hw, int groups, int* pix_per_blk_out, int* nchunk_out) {
+  // aim for >= ~16 chunks per image but at least 8 pixels per block
+  int ppb = (hw + 15) / 16;
+  if (ppb < 8) ppb = 8;
+  if (ppb > hw) ppb = hw;
+  const int nchunk = (hw + ppb - 1) / ppb;
+  if (pix_per_blk_out) *pix_per_blk_out = ppb;
+  if (nchunk_out) *nchunk_out = nchunk;
+  return nimg * nchunk * groups * 2;
+}
+
+extern "C" int nr_launch_groupnorm(NrGnParams* pp, hipStream_t stream) {
+  NrGnParams p = *pp;
+  const int C = p.c0 + p.c1;
+  if (C % 8 != 0 || C % p.groups != 0 || p.groups > 64) return 1;
+  if (p.x1 && p.c0 % 8 != 0) return 2;
+  nr_gn_workspace_floats(p.nimg, p.hw, p.groups, &p.pix_per_blk, &p.nchunk);
+  const int CP = C / 8;
+  const int PL = CP <= 256 ? 256 / CP : 1;
+  const size_t shm_stats = (size_t)2 * PL * C * sizeof(float);
+  const size_t shm_apply = (size_t)2 * C * sizeof(float);
+  if (shm_stats > 60000 || shm_apply > 60000) return 3;
+  dim3 grid(p.nchunk, p.nimg);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), shm_stats, stream, p);
+  hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), shm_apply, stream, p);
+  return 0;
+}
+
+extern "C" int nr_launch_layernorm(const bf16* x, int ldx, bf16* out, int ldo, int M, int C, const float* gamma,
+                                   const float* beta, float eps, const float* pe, int pe_hw, int pe_F,
+                                   hipStream_t stream) {
+  if (C % 8 != 0) return 1;
+  const int CP = C / 8;
+  dim3 grid((M + 3) / 4);
+  if (CP <= 64)
+    hipLaunchKernelGGL((layernorm_kernel<1>), grid, dim3(256), 0, stream, x, ldx, out, ldo, M, C, gamma, beta, eps, pe, pe_hw, pe_F);
+  else if (CP <= 128)
+    hipLaunchKernelGGL((layernorm_kernel<2>), grid, dim3(256), 0, stream, x, ldx, out, ldo, M, C, gamma, beta, eps, pe, pe_hw, pe_F);
+  else if (CP <= 256)
+    hipLaunchKernelGGL((layernorm_kernel<4>), grid, dim3(256), 0, stream, x, ldx, out, ldo, M, C, gamma, beta, eps, pe, pe_hw, pe_F);
+  else
+    return 2;
+  return 0;
+}

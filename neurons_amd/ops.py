@@ -1,0 +1,133 @@
+"""Single-kernel entry points of libneurons_amd.so on torch tensors (device memory + streams only).
+
+Used by tests/ to check each HIP kernel against the oracle; the product path is the whole-network
+engine (neurons_amd/unet3d.py, sparsectrl.py), which calls the same kernels from C++.
+All activations are channels-last bf16 ``[nimg, H, W, C]`` / token-major ``[M, C]``.
+"""
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk_bf16(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous(), (t.dtype, t.shape)
+
+
+def _chk_f32(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), (t.dtype, t.shape)
+
+
+def gemm(a, w, bias=None, res=None, geglu=False):
+    """out[M, N(or N/2)] = a[M, K] @ w[N, K]^T (+bias) (+res) ; geglu expects the value/gate-interleaved weight."""
+    _chk_bf16(a, w, res)
+    _chk_f32(bias)
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty(M, N // 2 if geglu else N, dtype=torch.bfloat16, device=a.device)
+    lib = _lib.load()
+    _lib.check(lib.nr_op_gemm(_stream(), _ptr(a), K, _ptr(w), _ptr(bias), _ptr(res), out.shape[1], _ptr(out),
+                              out.shape[1], M, N, K, 1 if geglu else 0))
+    return out
+
+
+def geglu_permute(w, b):
+    """Reorder a GEGLU projection (rows [value(inner) | gate(inner)]) into 16-value/16-gate interleave."""
+    inner = w.shape[0] // 2
+    n = torch.arange(2 * inner)
+    q, j = n // 32, n % 32
+    src = torch.where(j < 16, q * 16 + j, inner + q * 16 + (j - 16))
+    return w[src].contiguous(), (None if b is None else b[src].contiguous())
+
+
+def conv3x3(x0, w, bias=None, x1=None, stride=1, ups=False, rowvec=None, rowvec_div=1, res=None):
+    """x0/x1: [nimg, H, W, C] bf16; w: [Cout, 3, 3, Cin] bf16 (tap-major); returns [nimg, OH, OW, Cout]."""
+    _chk_bf16(x0, x1, w, res)
+    _chk_f32(bias, rowvec)
+    nimg, H, W, c0 = x0.shape
+    c1 = 0 if x1 is None else x1.shape[3]
+    Cout = w.shape[0]
+    OH, OW = (2 * H, 2 * W) if ups else (H, W)
+    if stride == 2:
+        OH, OW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
+    out = torch.empty(nimg, OH, OW, Cout, dtype=torch.bfloat16, device=x0.device)
+    lib = _lib.load()
+    _lib.check(lib.nr_op_conv3x3(_stream(), _ptr(x0), c0, _ptr(x1), c1, nimg, H, W, stride, 1 if ups else 0, _ptr(w),
+                                 _ptr(bias), _ptr(rowvec), rowvec_div, _ptr(res), _ptr(out), Cout))
+    return out
+
+
+def groupnorm(x0, gamma, beta, groups=32, eps=1e-5, silu=False, x1=None):
+    _chk_bf16(x0, x1)
+    _chk_f32(gamma, beta)
+    nimg, H, W, c0 = x0.shape
+    c1 = 0 if x1 is None else x1.shape[3]
+    out = torch.empty(nimg, H, W, c0 + c1, dtype=torch.bfloat16, device=x0.device)
+    ws = torch.empty(nimg * (H * W) * groups * 2 + 64, dtype=torch.float32, device=x0.device)
+    lib = _lib.load()
+    _lib.check(lib.nr_op_groupnorm(_stream(), _ptr(x0), c0, _ptr(x1), c1, nimg, H * W, groups, _ptr(gamma), _ptr(beta),
+                                   eps, 1 if silu else 0, _ptr(ws), _ptr(out)))
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, pe=None, pe_hw=1, pe_F=1):
+    _chk_bf16(x)
+    _chk_f32(gamma, beta, pe)
+    M, Cc = x.shape
+    out = torch.empty_like(x)
+    lib = _lib.load()
+    _lib.check(lib.nr_op_layernorm(_stream(), _ptr(x), _ptr(out), M, Cc, _ptr(gamma), _ptr(beta), eps, _ptr(pe), pe_hw, pe_F))
+    return out
+
+
+def attention_self(qkv, heads):
+    """qkv: [nimg, L, 3C] fused; returns [nimg, L, C]."""
+    _chk_bf16(qkv)
+    nimg, L, C3 = qkv.shape
+    Cc = C3 // 3
+    out = torch.empty(nimg, L, Cc, dtype=torch.bfloat16, device=qkv.device)
+    lib = _lib.load()
+    _lib.check(lib.nr_op_attention(_stream(), 0, _ptr(qkv), None, _ptr(out), nimg, L, L, Cc, heads, 1, 1))
+    return out
+
+
+def attention_cross(q, kv, heads, kv_div):
+    """q: [nimg, L, C]; kv: [nb, Lk, 2C] fused; image n attends to kv[n // kv_div]."""
+    _chk_bf16(q, kv)
+    nimg, L, Cc = q.shape
+    Lk = kv.shape[1]
+    out = torch.empty_like(q)
+    lib = _lib.load()
+    _lib.check(lib.nr_op_attention(_stream(), 1, _ptr(q), _ptr(kv), _ptr(out), nimg, L, Lk, Cc, heads, 1, kv_div))
+    return out
+
+
+def attention_temporal(qkv, heads, frames):
+    """qkv: [(b f), hw, 3C] fused; attention runs over f for every (b, pixel); returns [(b f), hw, C]."""
+    _chk_bf16(qkv)
+    nimg, hw, C3 = qkv.shape
+    Cc = C3 // 3
+    out = torch.empty(nimg, hw, Cc, dtype=torch.bfloat16, device=qkv.device)
+    lib = _lib.load()
+    _lib.check(lib.nr_op_attention(_stream(), 2, _ptr(qkv), None, _ptr(out), nimg, hw, frames, Cc, heads, frames, 1))
+    return out
+
+
+def cfg_ddim_step(eps, x, guidance_scale, alpha_prod_t, alpha_prod_t_prev, do_cfg=True):
+    _chk_f32(eps, x)
+    out = torch.empty_like(x)
+    lib = _lib.load()
+    _lib.check(lib.nr_cfg_ddim_step(_stream(), _ptr(eps), _ptr(x), _ptr(out), x.numel(), float(guidance_scale),
+                                    1 if do_cfg else 0, float(alpha_prod_t), float(alpha_prod_t_prev)))
+    return out

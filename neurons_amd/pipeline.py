@@ -1,0 +1,285 @@
+"""NeuroclipsPipeline — the denoising loop of ``animatediff/pipelines/pipeline_neuroclips.py`` (:43, ``__call__``
+:321-501) with the two networks and the CFG+DDIM update running in libneurons_amd.so.
+
+Kept identical to the reference (so ``scripts/neuroclips_video*.py`` can call it unchanged):
+  * call signature and defaults (:322-346), ``check_inputs`` errors (:274-287), ``prepare_latents`` (:289-318)
+  * CFG order: uncond first (``cat([uncond, text])`` :238, ``chunk(2)`` :479)
+  * RNG order: an unused ``keylatents`` randn draw happens before ``noise = randn_like(latents)`` (:395-405,418)
+  * the ``low_strength`` quirk: latents are noised to ``timesteps[0]`` and ALL timesteps are run;
+    ``low_strength >= 1`` gives an empty ``latent_timestep`` exactly as in the reference (:410-413)
+  * SparseCtrl cond/mask construction (:447-458) — built once, they are step-invariant
+Additive extensions (defaults keep reference behaviour): ``text_embeddings=`` (skip the CLIP encoder),
+``noise=`` (explicit noise instead of the in-call draw), ``output_type="latent"`` (skip the VAE).
+VAE and CLIP stay PyTorch modules supplied by the caller (north-star: out of the HIP scope).
+"""
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+@dataclass
+class AnimationPipelineOutput:
+    videos: Union[torch.Tensor, np.ndarray]
+
+
+class _NullBar:
+    def __init__(self, total=None):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def update(self, n=1):
+        pass
+
+
+class NeuroclipsPipeline:
+    _optional_components = []
+
+    def __init__(self, vae, text_encoder, tokenizer, unet, scheduler, controlnet=None):
+        # the reference patches steps_offset != 1 / clip_sample == True configs with a deprecation warning
+        # (pipeline_neuroclips.py:64-89); the NEURONS scheduler config already has the patched values
+        if getattr(scheduler.config, "steps_offset", 1) != 1:
+            scheduler.config.steps_offset = 1
+        if getattr(scheduler.config, "clip_sample", False) is True:
+            scheduler.config.clip_sample = False
+        self.register_modules(vae=vae, text_encoder=text_encoder, tokenizer=tokenizer, unet=unet, scheduler=scheduler,
+                              controlnet=controlnet)
+        if vae is not None and hasattr(vae, "config"):
+            self.vae_scale_factor = 2 ** (len(vae.config.block_out_channels) - 1)
+        else:
+            self.vae_scale_factor = 8
+        self._progress_bar_config = {}
+        self._device = torch.device("cpu")
+
+    # ---- DiffusionPipeline surface used by the scripts (SURVEY §8c "Python harness rows") ----
+    def register_modules(self, **kwargs):
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    def to(self, device):
+        self._device = torch.device(device)
+        for name in ("vae", "text_encoder", "unet", "controlnet"):
+            m = getattr(self, name, None)
+            if m is not None and hasattr(m, "to"):
+                m.to(self._device)
+        return self
+
+    @property
+    def device(self):
+        return self._device
+
+    @property
+    def _execution_device(self):
+        return self._device
+
+    def set_progress_bar_config(self, **kwargs):
+        self._progress_bar_config = kwargs
+
+    def progress_bar(self, total=None):
+        return _NullBar(total)
+
+    def enable_vae_slicing(self):
+        if hasattr(self.vae, "enable_slicing"):
+            self.vae.enable_slicing()
+
+    def disable_vae_slicing(self):
+        if hasattr(self.vae, "disable_slicing"):
+            self.vae.disable_slicing()
+
+    # ---- prompt encoding (pipeline_neuroclips.py:153-240); CLIP stays PyTorch ----
+    def _encode_prompt(self, prompt, device, num_videos_per_prompt, do_classifier_free_guidance, negative_prompt):
+        if self.tokenizer is None or self.text_encoder is None:
+            raise ValueError("tokenizer/text_encoder are required to encode prompts; pass text_embeddings= instead")
+        batch_size = len(prompt) if isinstance(prompt, list) else 1
+        text_inputs = self.tokenizer(prompt, padding="max_length", max_length=self.tokenizer.model_max_length,
+                                     truncation=True, return_tensors="pt")
+        text_input_ids = text_inputs.input_ids
+        use_mask = hasattr(self.text_encoder.config, "use_attention_mask") and self.text_encoder.config.use_attention_mask
+        attention_mask = text_inputs.attention_mask.to(device) if use_mask else None
+        text_embeddings = self.text_encoder(text_input_ids.to(device), attention_mask=attention_mask)[0]
+        bs_embed, seq_len, _ = text_embeddings.shape
+        text_embeddings = text_embeddings.repeat(1, num_videos_per_prompt, 1).view(bs_embed * num_videos_per_prompt, seq_len, -1)
+        if do_classifier_free_guidance:
+            if negative_prompt is None:
+                uncond_tokens = [""] * batch_size
+            elif type(prompt) is not type(negative_prompt):
+                raise TypeError(f"`negative_prompt` should be the same type to `prompt`, but got {type(negative_prompt)} !="
+                                f" {type(prompt)}.")
+            elif isinstance(negative_prompt, str):
+                uncond_tokens = [negative_prompt]
+            elif batch_size != len(negative_prompt):
+                raise ValueError(f"`negative_prompt`: {negative_prompt} has batch size {len(negative_prompt)}, but `prompt`:"
+                                 f" {prompt} has batch size {batch_size}. Please make sure that passed `negative_prompt` matches"
+                                 " the batch size of `prompt`.")
+            else:
+                uncond_tokens = negative_prompt
+            max_length = text_input_ids.shape[-1]
+            uncond_input = self.tokenizer(uncond_tokens, padding="max_length", max_length=max_length, truncation=True,
+                                          return_tensors="pt")
+            attention_mask = uncond_input.attention_mask.to(device) if use_mask else None
+            uncond_embeddings = self.text_encoder(uncond_input.input_ids.to(device), attention_mask=attention_mask)[0]
+            seq_len = uncond_embeddings.shape[1]
+            uncond_embeddings = uncond_embeddings.repeat(1, num_videos_per_prompt, 1).view(batch_size * num_videos_per_prompt, seq_len, -1)
+            text_embeddings = torch.cat([uncond_embeddings, text_embeddings])
+        return text_embeddings
+
+    # ---- VAE decode, frame by frame (pipeline_neuroclips.py:242-255); VAE stays PyTorch ----
+    def decode_latents(self, latents):
+        video_length = latents.shape[2]
+        latents = 1 / 0.18215 * latents
+        b, c, f, h, w = latents.shape
+        latents = latents.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
+        video = []
+        for frame_idx in range(latents.shape[0]):
+            video.append(self.vae.decode(latents[frame_idx:frame_idx + 1]).sample)
+        video = torch.cat(video)
+        video = video.reshape(b, video_length, *video.shape[1:]).permute(0, 2, 1, 3, 4)
+        video = (video / 2 + 0.5).clamp(0, 1)
+        return video.cpu().float().numpy()
+
+    def check_inputs(self, prompt, height, width, callback_steps):
+        if not isinstance(prompt, str) and not isinstance(prompt, list):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if (callback_steps is None) or (callback_steps is not None and (not isinstance(callback_steps, int) or callback_steps <= 0)):
+            raise ValueError(f"`callback_steps` has to be a positive integer but is {callback_steps} of type"
+                             f" {type(callback_steps)}.")
+
+    def prepare_latents(self, batch_size, num_channels_latents, video_length, height, width, dtype, device, generator,
+                        latents=None):
+        shape = (batch_size, num_channels_latents, video_length, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
+                             f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        if latents is None:
+            if isinstance(generator, list):
+                latents = [torch.randn(shape, generator=generator[i], device=device, dtype=dtype) for i in range(batch_size)]
+                latents = torch.cat(latents, dim=0).to(device)
+            else:
+                latents = torch.randn(shape, generator=generator, device=device, dtype=dtype).to(device)
+        else:
+            if latents.shape != shape:
+                raise ValueError(f"Unexpected latents shape, got {latents.shape}, expected {shape}")
+            latents = latents.to(device)
+        latents = latents * self.scheduler.init_noise_sigma
+        return latents
+
+    @torch.no_grad()
+    def __call__(self, prompt: Union[str, List[str]], video_length: Optional[int], height: Optional[int] = None,
+                 width: Optional[int] = None, num_inference_steps: int = 50, guidance_scale: float = 7.5,
+                 negative_prompt: Optional[Union[str, List[str]]] = None, num_videos_per_prompt: Optional[int] = 1,
+                 eta: float = 0.0, generator=None, latents: Optional[torch.Tensor] = None,
+                 keylatents: Optional[torch.Tensor] = None, output_type: Optional[str] = "tensor", return_dict: bool = True,
+                 callback: Optional[Callable[[int, int, torch.Tensor], None]] = None, callback_steps: Optional[int] = 1,
+                 controlnet_images: torch.Tensor = None, controlnet_image_index: list = [0],
+                 controlnet_conditioning_scale: Union[float, List[float]] = 1.0, low_strength=0.0,
+                 text_embeddings: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None, **kwargs):
+        height = height or self.unet.config.sample_size * self.vae_scale_factor
+        width = width or self.unet.config.sample_size * self.vae_scale_factor
+        self.check_inputs(prompt, height, width, callback_steps)
+        if eta != 0.0:
+            raise NotImplementedError("eta != 0 is not on the NEURONS path")
+
+        batch_size = 1
+        if latents is not None:
+            batch_size = latents.shape[0]
+        if isinstance(prompt, list):
+            batch_size = len(prompt)
+        device = self._execution_device
+        if device.type != "cuda":
+            raise RuntimeError("NeuroclipsPipeline runs on MI355X only: call .to('cuda') first (no CPU fallback)")
+        do_classifier_free_guidance = guidance_scale > 1.0
+
+        if text_embeddings is None:
+            prompt = prompt if isinstance(prompt, list) else [prompt] * batch_size
+            if negative_prompt is not None:
+                negative_prompt = negative_prompt if isinstance(negative_prompt, list) else [negative_prompt] * batch_size
+            text_embeddings = self._encode_prompt(prompt, device, num_videos_per_prompt, do_classifier_free_guidance, negative_prompt)
+        text_embeddings = text_embeddings.to(device)
+        want = batch_size * num_videos_per_prompt * (2 if do_classifier_free_guidance else 1)
+        if text_embeddings.shape[0] != want:
+            raise ValueError(f"text_embeddings batch {text_embeddings.shape[0]} != {want}")
+
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        timesteps = self.scheduler.timesteps
+        timesteps_host = self.scheduler.timesteps_host
+
+        num_channels_latents = self.unet.in_channels
+        latents = self.prepare_latents(batch_size * num_videos_per_prompt, num_channels_latents, video_length, height, width,
+                                       text_embeddings.dtype, device, generator, latents)
+        # drawn and never used by the reference — kept for RNG-order parity (:395-405)
+        keylatents = self.prepare_latents(batch_size * num_videos_per_prompt, num_channels_latents, video_length, height,
+                                          width, text_embeddings.dtype, device, generator, keylatents)
+        del keylatents
+        latents_dtype = latents.dtype
+
+        init_timestep = min(int(num_inference_steps * low_strength), num_inference_steps)
+        t_start = max(num_inference_steps - init_timestep, 0)
+        steps = self.scheduler.timesteps[:t_start]
+        latent_timestep = steps[:1].repeat(batch_size)
+        if noise is None:
+            noise = torch.randn_like(latents)
+        else:
+            noise = noise.to(device=device, dtype=latents.dtype)
+        latents = self.scheduler.add_noise(latents, noise, latent_timestep)
+        latents = latents.to(torch.float32).contiguous()      # DDIM state stays fp32 for the whole loop
+
+        use_ctrl = (getattr(self, "controlnet", None) is not None) and (controlnet_images is not None)
+        if use_ctrl:
+            assert controlnet_images.dim() == 5
+            controlnet_images = controlnet_images.to(latents.device)
+            cond_shape = list(controlnet_images.shape)
+            cond_shape[2] = video_length
+            controlnet_cond = torch.zeros(cond_shape, device=latents.device)
+            mask_shape = list(cond_shape)
+            mask_shape[1] = 1
+            controlnet_conditioning_mask = torch.zeros(mask_shape, device=latents.device)
+            assert controlnet_images.shape[2] >= len(controlnet_image_index)
+            controlnet_cond[:, :, controlnet_image_index] = controlnet_images[:, :, :len(controlnet_image_index)]
+            controlnet_conditioning_mask[:, :, controlnet_image_index] = 1
+
+        lib = _lib.load()
+        n_lat = latents.numel()
+        with self.progress_bar(total=num_inference_steps) as progress_bar:
+            for i, t in enumerate(timesteps_host):
+                latent_model_input = torch.cat([latents] * 2) if do_classifier_free_guidance else latents
+                latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)
+                down_res = mid_res = None
+                if use_ctrl:
+                    down_res, mid_res = self.controlnet(
+                        latent_model_input, t, encoder_hidden_states=text_embeddings, controlnet_cond=controlnet_cond,
+                        conditioning_mask=controlnet_conditioning_mask, conditioning_scale=controlnet_conditioning_scale,
+                        guess_mode=False, return_dict=False)
+                noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=text_embeddings,
+                                       down_block_additional_residuals=down_res,
+                                       mid_block_additional_residual=mid_res).sample
+                # CFG combine + DDIM step fused in one HIP kernel (reference: :478-483)
+                a_t, a_prev = self.scheduler.alpha_pair(t)
+                new_latents = torch.empty_like(latents)
+                _lib.check(lib.nr_cfg_ddim_step(torch.cuda.current_stream().cuda_stream, noise_pred.data_ptr(),
+                                                latents.data_ptr(), new_latents.data_ptr(), n_lat, float(guidance_scale),
+                                                1 if do_classifier_free_guidance else 0, a_t, a_prev))
+                latents = new_latents
+                progress_bar.update()
+                if callback is not None and i % callback_steps == 0:
+                    callback(i, t, latents)
+
+        latents = latents.to(latents_dtype)
+        if output_type == "latent":
+            video = latents
+        else:
+            video = self.decode_latents(latents)
+            if output_type == "tensor":
+                video = torch.from_numpy(video)
+        if not return_dict:
+            return video
+        return AnimationPipelineOutput(videos=video)

@@ -1,0 +1,445 @@
+"""NativeUNet3D — drop-in for ``animatediff.models.unet.UNet3DConditionModel`` on the inference path.
+
+Same constructor keywords that matter (unet.py:42-90), same ``forward`` signature and ``.sample`` output
+(unet.py:320-333,472-475), ``load_state_dict`` with the reference key names, ``.in_channels``,
+``.config.sample_size`` (read at pipeline_neuroclips.py:349-350,382).  Every FLOP of the forward runs in
+libneurons_amd.so (C ABI ``nr_unet3d_forward``); there is no torch fallback.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from types import SimpleNamespace
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+@dataclass
+class UNet3DConfig:
+    sample_size: Optional[int] = 64
+    in_channels: int = 4
+    out_channels: int = 4
+    down_block_types: Tuple[str, ...] = ("CrossAttnDownBlock3D", "CrossAttnDownBlock3D", "CrossAttnDownBlock3D", "DownBlock3D")
+    up_block_types: Tuple[str, ...] = ("UpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D")
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
+    layers_per_block: int = 2
+    norm_num_groups: int = 32
+    norm_eps: float = 1e-5
+    cross_attention_dim: int = 768          # SD-1.5 unet/config.json (the class default 1280 is never used by NEURONS)
+    attention_head_dim: int = 8             # = number of heads (diffusers naming quirk, sparse_controlnet.py:143-149)
+    use_inflated_groupnorm: bool = True     # inference-v3.yaml:2 (per-frame GroupNorm)
+    use_motion_module: bool = True
+    motion_module_resolutions: Tuple[int, ...] = (1, 2, 4, 8)
+    motion_module_mid_block: bool = False
+    motion_module_type: str = "Vanilla"
+    motion_module_kwargs: dict = field(default_factory=lambda: dict(
+        num_attention_heads=8, num_transformer_block=1, attention_block_types=("Temporal_Self", "Temporal_Self"),
+        temporal_position_encoding=True, temporal_position_encoding_max_len=24, temporal_attention_dim_div=1,
+        zero_initialize=True))
+    # SparseCtrl only
+    conditioning_channels: int = 4
+    set_noisy_sample_input_to_zero: bool = True
+    use_simplified_condition_embedding: bool = True
+    concate_conditioning_mask: bool = True
+
+
+@dataclass
+class UNet3DConditionOutput:
+    sample: torch.Tensor
+
+
+def _check_supported(cfg: UNet3DConfig, kind: int):
+    n = len(cfg.block_out_channels)
+    if len(cfg.down_block_types) != n:
+        raise ValueError("Must provide the same number of `block_out_channels` as `down_block_types`.")
+    for t in cfg.down_block_types:
+        if t not in ("CrossAttnDownBlock3D", "DownBlock3D"):
+            raise ValueError(f"{t} does not exist.")
+    if kind == _lib.NR_KIND_UNET3D:
+        for t in cfg.up_block_types:
+            if t not in ("CrossAttnUpBlock3D", "UpBlock3D"):
+                raise ValueError(f"{t} does not exist.")
+    if not cfg.use_inflated_groupnorm:
+        raise NotImplementedError("only use_inflated_groupnorm=True (per-frame GroupNorm, the NEURONS v3 config) is built")
+    mm = cfg.motion_module_kwargs
+    if cfg.use_motion_module:
+        if cfg.motion_module_type != "Vanilla":
+            raise ValueError("unknown motion_module_type")
+        if tuple(cfg.motion_module_resolutions) != tuple(2 ** i for i in range(n)):
+            raise NotImplementedError("motion modules at every resolution only (inference-v3.yaml:4)")
+        if mm.get("num_transformer_block", 1) != 1 or mm.get("temporal_attention_dim_div", 1) != 1:
+            raise NotImplementedError("num_transformer_block=1, temporal_attention_dim_div=1 only")
+        if any(b != "Temporal_Self" for b in mm.get("attention_block_types", ())):
+            raise NotImplementedError("Temporal_Self attention blocks only")
+        if not mm.get("temporal_position_encoding", False):
+            raise NotImplementedError("temporal_position_encoding=True only")
+    if kind == _lib.NR_KIND_SPARSECTRL and not (cfg.use_simplified_condition_embedding and cfg.concate_conditioning_mask):
+        raise NotImplementedError("SparseCtrl latent-condition variant only (latent_condition.yaml:2-4)")
+
+
+def make_c_config(cfg: UNet3DConfig, kind: int) -> _lib.NrNetConfig:
+    _check_supported(cfg, kind)
+    c = _lib.NrNetConfig()
+    c.kind = kind
+    c.in_channels = cfg.in_channels
+    c.out_channels = cfg.out_channels
+    n = len(cfg.block_out_channels)
+    c.num_levels = n
+    for i in range(n):
+        c.block_out_channels[i] = cfg.block_out_channels[i]
+        c.down_block_has_attn[i] = 1 if cfg.down_block_types[i] == "CrossAttnDownBlock3D" else 0
+        if kind == _lib.NR_KIND_UNET3D:
+            c.up_block_has_attn[i] = 1 if cfg.up_block_types[i] == "CrossAttnUpBlock3D" else 0
+    c.layers_per_block = cfg.layers_per_block
+    c.num_heads = cfg.attention_head_dim
+    c.cross_attention_dim = cfg.cross_attention_dim
+    c.norm_num_groups = cfg.norm_num_groups
+    c.norm_eps = cfg.norm_eps
+    c.use_motion_module = 1 if cfg.use_motion_module else 0
+    mm = cfg.motion_module_kwargs
+    c.motion_num_heads = mm.get("num_attention_heads", 8)
+    c.motion_num_attention_blocks = len(mm.get("attention_block_types", ("Temporal_Self", "Temporal_Self")))
+    c.motion_pe_max_len = mm.get("temporal_position_encoding_max_len", 24)
+    c.motion_module_mid_block = 1 if cfg.motion_module_mid_block else 0
+    c.conditioning_channels = cfg.conditioning_channels
+    c.set_noisy_sample_input_to_zero = 1 if cfg.set_noisy_sample_input_to_zero else 0
+    return c
+
+
+# ---------------------------------------------------------------------------------------------------
+# state-dict schema: reference parameter names -> shapes (what nn.Module.state_dict() of the reference
+# classes contains; ``pos_encoder.pe`` is a non-persistent buffer, motion_module.py:239, and is regenerated)
+# ---------------------------------------------------------------------------------------------------
+def _resnet_keys(p, cin, cout, temb):
+    k = {f"{p}.norm1.weight": (cin,), f"{p}.norm1.bias": (cin,), f"{p}.conv1.weight": (cout, cin, 3, 3), f"{p}.conv1.bias": (cout,),
+         f"{p}.time_emb_proj.weight": (cout, temb), f"{p}.time_emb_proj.bias": (cout,),
+         f"{p}.norm2.weight": (cout,), f"{p}.norm2.bias": (cout,), f"{p}.conv2.weight": (cout, cout, 3, 3), f"{p}.conv2.bias": (cout,)}
+    if cin != cout:
+        k[f"{p}.conv_shortcut.weight"] = (cout, cin, 1, 1)
+        k[f"{p}.conv_shortcut.bias"] = (cout,)
+    return k
+
+
+def _ff_keys(p, c):
+    return {f"{p}.net.0.proj.weight": (8 * c, c), f"{p}.net.0.proj.bias": (8 * c,), f"{p}.net.2.weight": (c, 4 * c), f"{p}.net.2.bias": (c,)}
+
+
+def _attn_keys(p, c, kdim):
+    return {f"{p}.to_q.weight": (c, c), f"{p}.to_k.weight": (c, kdim), f"{p}.to_v.weight": (c, kdim),
+            f"{p}.to_out.0.weight": (c, c), f"{p}.to_out.0.bias": (c,)}
+
+
+def _transformer_keys(p, c, ctx):
+    k = {f"{p}.norm.weight": (c,), f"{p}.norm.bias": (c,), f"{p}.proj_in.weight": (c, c, 1, 1), f"{p}.proj_in.bias": (c,),
+         f"{p}.proj_out.weight": (c, c, 1, 1), f"{p}.proj_out.bias": (c,)}
+    b = f"{p}.transformer_blocks.0"
+    for n in ("norm1", "norm2", "norm3"):
+        k[f"{b}.{n}.weight"] = (c,)
+        k[f"{b}.{n}.bias"] = (c,)
+    k.update(_attn_keys(f"{b}.attn1", c, c))
+    k.update(_attn_keys(f"{b}.attn2", c, ctx))
+    k.update(_ff_keys(f"{b}.ff", c))
+    return k
+
+
+def _motion_keys(p, c, nblocks):
+    p = f"{p}.temporal_transformer"
+    k = {f"{p}.norm.weight": (c,), f"{p}.norm.bias": (c,), f"{p}.proj_in.weight": (c, c), f"{p}.proj_in.bias": (c,),
+         f"{p}.proj_out.weight": (c, c), f"{p}.proj_out.bias": (c,)}
+    b = f"{p}.transformer_blocks.0"
+    for i in range(nblocks):
+        k.update(_attn_keys(f"{b}.attention_blocks.{i}", c, c))
+        k[f"{b}.norms.{i}.weight"] = (c,)
+        k[f"{b}.norms.{i}.bias"] = (c,)
+    k.update(_ff_keys(f"{b}.ff", c))
+    k[f"{b}.ff_norm.weight"] = (c,)
+    k[f"{b}.ff_norm.bias"] = (c,)
+    return k
+
+
+def state_dict_schema(cfg: UNet3DConfig, kind: int = _lib.NR_KIND_UNET3D) -> dict:
+    boc = list(cfg.block_out_channels)
+    L = len(boc)
+    temb = 4 * boc[0]
+    ctx = cfg.cross_attention_dim
+    nmm = len(cfg.motion_module_kwargs.get("attention_block_types", ())) if cfg.use_motion_module else 0
+    k = {"conv_in.weight": (boc[0], cfg.in_channels, 3, 3), "conv_in.bias": (boc[0],),
+         "time_embedding.linear_1.weight": (temb, boc[0]), "time_embedding.linear_1.bias": (temb,),
+         "time_embedding.linear_2.weight": (temb, temb), "time_embedding.linear_2.bias": (temb,)}
+    out_c = boc[0]
+    for i in range(L):
+        in_c, out_c = out_c, boc[i]
+        for j in range(cfg.layers_per_block):
+            k.update(_resnet_keys(f"down_blocks.{i}.resnets.{j}", in_c if j == 0 else out_c, out_c, temb))
+            if cfg.down_block_types[i] == "CrossAttnDownBlock3D":
+                k.update(_transformer_keys(f"down_blocks.{i}.attentions.{j}", out_c, ctx))
+            if nmm:
+                k.update(_motion_keys(f"down_blocks.{i}.motion_modules.{j}", out_c, nmm))
+        if i != L - 1:
+            k[f"down_blocks.{i}.downsamplers.0.conv.weight"] = (out_c, out_c, 3, 3)
+            k[f"down_blocks.{i}.downsamplers.0.conv.bias"] = (out_c,)
+    cm = boc[-1]
+    k.update(_resnet_keys("mid_block.resnets.0", cm, cm, temb))
+    k.update(_transformer_keys("mid_block.attentions.0", cm, ctx))
+    if nmm and cfg.motion_module_mid_block:
+        k.update(_motion_keys("mid_block.motion_modules.0", cm, nmm))
+    k.update(_resnet_keys("mid_block.resnets.1", cm, cm, temb))
+    if kind == _lib.NR_KIND_SPARSECTRL:
+        k["controlnet_cond_embedding.weight"] = (boc[0], cfg.conditioning_channels + 1, 3, 3)
+        k["controlnet_cond_embedding.bias"] = (boc[0],)
+        chans = [boc[0]]
+        for i in range(L):
+            chans += [boc[i]] * cfg.layers_per_block
+            if i != L - 1:
+                chans.append(boc[i])
+        for i, c in enumerate(chans):
+            k[f"controlnet_down_blocks.{i}.weight"] = (c, c, 1, 1)
+            k[f"controlnet_down_blocks.{i}.bias"] = (c,)
+        k["controlnet_mid_block.weight"] = (cm, cm, 1, 1)
+        k["controlnet_mid_block.bias"] = (cm,)
+        return k
+    rev = boc[::-1]
+    out_c = rev[0]
+    for i in range(L):
+        prev_out, out_c = out_c, rev[i]
+        in_c = rev[min(i + 1, L - 1)]
+        for j in range(cfg.layers_per_block + 1):
+            skip_c = in_c if j == cfg.layers_per_block else out_c
+            res_in = prev_out if j == 0 else out_c
+            k.update(_resnet_keys(f"up_blocks.{i}.resnets.{j}", res_in + skip_c, out_c, temb))
+            if cfg.up_block_types[i] == "CrossAttnUpBlock3D":
+                k.update(_transformer_keys(f"up_blocks.{i}.attentions.{j}", out_c, ctx))
+            if nmm:
+                k.update(_motion_keys(f"up_blocks.{i}.motion_modules.{j}", out_c, nmm))
+        if i != L - 1:
+            k[f"up_blocks.{i}.upsamplers.0.conv.weight"] = (out_c, out_c, 3, 3)
+            k[f"up_blocks.{i}.upsamplers.0.conv.bias"] = (out_c,)
+    k["conv_norm_out.weight"] = (boc[0],)
+    k["conv_norm_out.bias"] = (boc[0],)
+    k["conv_out.weight"] = (cfg.out_channels, boc[0], 3, 3)
+    k["conv_out.bias"] = (cfg.out_channels,)
+    return k
+
+
+def random_state_dict(cfg: UNet3DConfig, kind: int = _lib.NR_KIND_UNET3D, seed: int = 0, zero_init_heads: bool = False) -> dict:
+    """Seeded synthetic weights with a forward-stable scale (no checkpoints are available offline).
+
+    Linear/conv weights ~ N(0, 1/fan_in); norm gains ~ 1 + 0.1 N(0,1); biases ~ 0.02 N(0,1).  The layers
+    the reference zero-initialises (motion ``proj_out`` motion_module.py:74-75, ControlNet zero-convs
+    sparse_controlnet.py:244-246,281-295) are random too unless ``zero_init_heads`` — otherwise the temporal
+    and control paths would be numerically invisible."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, shape in state_dict_schema(cfg, kind).items():
+        if name.endswith(".bias"):
+            t = 0.02 * torch.randn(shape, generator=g)
+            if ".norm" in name or "norms." in name or "conv_norm_out" in name or "ff_norm" in name:
+                t = 0.1 * torch.randn(shape, generator=g)
+        elif len(shape) == 1:
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            t = torch.randn(shape, generator=g) / (fan_in ** 0.5)
+            zero = ("motion_modules" in name and ".proj_out." in name) or name.startswith("controlnet_down_blocks") or \
+                name.startswith("controlnet_mid_block") or name.startswith("controlnet_cond_embedding")
+            if zero and zero_init_heads:
+                t = torch.zeros(shape)
+        sd[name] = t
+    return sd
+
+
+class _NativeNet:
+    """Shared handle management for the two networks."""
+    _kind = _lib.NR_KIND_UNET3D
+
+    def __init__(self, config: Optional[UNet3DConfig] = None, **kwargs):
+        if config is None:
+            config = UNet3DConfig(**kwargs)
+        elif kwargs:
+            raise TypeError("pass either a UNet3DConfig or keyword arguments")
+        self.config = config
+        self.in_channels = config.in_channels
+        self.sample_size = config.sample_size
+        self.dtype = torch.float32          # dtype at the API boundary; compute is bf16/fp32-accumulate in HIP
+        self.device = torch.device("cpu")
+        self._cconf = make_c_config(config, self._kind)
+        self._schema = state_dict_schema(config, self._kind)
+        self._h = None
+        self._plan_key = None
+        self._loaded = set()
+        self._pending = {}
+        self._graph = True
+
+    # -- module-like surface ---------------------------------------------------------------------------
+    def to(self, device=None, dtype=None):
+        if device is not None:
+            self.device = torch.device(device)
+            if self.device.type != "cuda":
+                raise RuntimeError("neurons_amd networks run on MI355X only (device must be 'cuda'); there is no CPU fallback")
+        return self
+
+    def cuda(self, device=None):
+        return self.to(torch.device("cuda", torch.cuda.current_device() if device is None else device))
+
+    def eval(self):
+        return self
+
+    def requires_grad_(self, flag=False):
+        return self
+
+    def enable_graph(self, flag=True):
+        self._graph = bool(flag)
+        if self._h is not None:
+            _lib.check(_lib.load().nr_net_set_graph(self._h, 1 if flag else 0))
+        return self
+
+    def state_dict_keys(self):
+        return list(self._schema.keys())
+
+    def _handle(self):
+        if self._h is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("neurons_amd: no HIP device visible; the networks run in libneurons_amd.so on MI355X only")
+            lib = _lib.load()
+            h = C.c_void_p()
+            _lib.check(lib.nr_net_create(C.byref(self._cconf), C.byref(h)))
+            self._h = h
+            _lib.check(lib.nr_net_set_graph(self._h, 1 if self._graph else 0))
+        return self._h
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Accepts the reference key names.  Returns (missing_keys, unexpected_keys) like torch."""
+        missing = [k for k in self._schema if k not in state_dict and k not in self._loaded]
+        unexpected = [k for k in state_dict if k not in self._schema and not k.endswith("pos_encoder.pe")]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for {type(self).__name__}:\n\tMissing key(s): {missing[:8]}"
+                               f"{'...' if len(missing) > 8 else ''}\n\tUnexpected key(s): {unexpected[:8]}")
+        for k, v in state_dict.items():
+            if k not in self._schema:
+                continue
+            if tuple(v.shape) != tuple(self._schema[k]):
+                raise RuntimeError(f"size mismatch for {k}: copying a param with shape {tuple(v.shape)}, "
+                                   f"the shape in current model is {tuple(self._schema[k])}.")
+            self._pending[k] = v
+            self._loaded.add(k)
+        self._plan_key = None
+        return missing, unexpected
+
+    def _flush_weights(self):
+        if not self._pending:
+            return
+        lib = _lib.load()
+        h = self._handle()
+        for k, v in self._pending.items():
+            a = np.ascontiguousarray(v.detach().to("cpu", torch.float32).numpy())
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            _lib.check(lib.nr_net_load_tensor(h, k.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
+        self._pending = {}
+
+    def _ensure_plan(self, batch, frames, h, w, ctx_len):
+        self._flush_weights()
+        key = (batch, frames, h, w, ctx_len)
+        if key != self._plan_key:
+            _lib.check(_lib.load().nr_net_plan(self._handle(), batch, frames, h, w, ctx_len))
+            self._plan_key = key
+            self._on_plan()
+
+    def _on_plan(self):
+        pass
+
+    def workspace_bytes(self):
+        return int(_lib.load().nr_net_workspace_bytes(self._handle()))
+
+    def weight_bytes(self):
+        return int(_lib.load().nr_net_weight_bytes(self._handle()))
+
+    @staticmethod
+    def _timesteps_host(timestep, batch):
+        if torch.is_tensor(timestep):
+            t = timestep.detach().to("cpu", torch.float32).reshape(-1)   # sync only if the caller passed a device tensor
+            vals = [float(x) for x in t]
+        else:
+            vals = [float(timestep)]
+        if len(vals) == 1:
+            vals = vals * batch
+        if len(vals) != batch:
+            raise ValueError(f"timestep has {len(vals)} entries for batch {batch}")
+        return (C.c_float * batch)(*vals)
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                _lib.load().nr_net_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def _as_nhwc_bf16(r, frames):
+    """ControlNet residual (b, C, f, h, w) -> channels-last bf16 buffer; zero-copy for NativeSparseCtrl outputs."""
+    if r.dim() == 4:            # (b, C, h, w) broadcast over frames  (unet.py:426-427)
+        r = r.unsqueeze(2).expand(-1, -1, frames, -1, -1)
+    v = r.permute(0, 2, 3, 4, 1)
+    if v.dtype == torch.bfloat16 and v.is_contiguous():
+        return v
+    return v.to(torch.bfloat16).contiguous()
+
+
+class NativeUNet3D(_NativeNet):
+    _kind = _lib.NR_KIND_UNET3D
+
+    def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, attention_mask=None,
+                down_block_additional_residuals: Optional[Sequence[torch.Tensor]] = None,
+                mid_block_additional_residual: Optional[torch.Tensor] = None, return_dict: bool = True):
+        if class_labels is not None or attention_mask is not None:
+            raise NotImplementedError("class_labels / attention_mask are not used on the NEURONS path")
+        if sample.dim() != 5:
+            raise ValueError(f"Expected sample to have ndim=5 (b c f h w), got {sample.dim()}")
+        if not sample.is_cuda:
+            raise RuntimeError("NativeUNet3D.forward: CUDA (ROCm) tensors required; there is no CPU fallback")
+        b, c, f, h, w = sample.shape
+        if c != self.config.in_channels:
+            raise ValueError(f"sample has {c} channels, expected {self.config.in_channels}")
+        ctx = encoder_hidden_states
+        if ctx.shape[0] != b or ctx.shape[2] != self.config.cross_attention_dim:
+            raise ValueError(f"encoder_hidden_states shape {tuple(ctx.shape)} does not match batch {b} / cross_attention_dim")
+        self._ensure_plan(b, f, h, w, ctx.shape[1])
+        lib = _lib.load()
+        # fixed I/O staging buffers: stable pointers let the engine replay one captured hipGraph
+        self._io_sample.copy_(sample)
+        self._io_ctx.copy_(ctx)
+        sample_c, ctx_c, out = self._io_sample, self._io_ctx, self._io_out
+        ts = self._timesteps_host(timestep, b)
+        keep = []
+        down_ptrs = None
+        mid_ptr = None
+        if (down_block_additional_residuals is None) != (mid_block_additional_residual is None):
+            raise ValueError("down_block_additional_residuals and mid_block_additional_residual must be given together")
+        if down_block_additional_residuals is not None:
+            n = int(lib.nr_net_num_residuals(self._h))
+            if len(down_block_additional_residuals) != n:
+                raise ValueError(f"expected {n} down-block residuals, got {len(down_block_additional_residuals)}")
+            keep = [_as_nhwc_bf16(r, f) for r in down_block_additional_residuals]
+            mid = _as_nhwc_bf16(mid_block_additional_residual, f)
+            keep.append(mid)
+            down_ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in keep[:n]])
+            mid_ptr = mid.data_ptr()
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.nr_unet3d_forward(self._h, stream, sample_c.data_ptr(), ts, ctx_c.data_ptr(), ctx.shape[1],
+                                         down_ptrs, mid_ptr, out.data_ptr()))
+        out = out.clone()
+        if not return_dict:
+            return (out,)
+        return UNet3DConditionOutput(sample=out)
+
+    __call__ = forward
+
+    def _on_plan(self):
+        b, f, h, w, L = self._plan_key
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        self._io_sample = torch.empty(b, self.config.in_channels, f, h, w, dtype=torch.float32, device=dev)
+        self._io_ctx = torch.empty(b, L, self.config.cross_attention_dim, dtype=torch.float32, device=dev)
+        self._io_out = torch.empty(b, self.config.out_channels, f, h, w, dtype=torch.float32, device=dev)

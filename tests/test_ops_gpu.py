@@ -1,0 +1,191 @@
+"""Per-kernel parity: each HIP kernel (through the C ABI nr_op_* entry points) against a plain fp32 torch
+statement of the same reference op, on the same bf16-rounded inputs.  Tolerance: outputs are bf16
+(8-bit mantissa) with fp32 accumulation -> max |err| <= 2e-2 * max|ref|, mean |err| <= 4e-3 * mean|ref|."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _cmp(name, out, ref, max_tol=2e-2, mean_tol=4e-3):
+    out = out.float()
+    ref = ref.float()
+    assert out.shape == ref.shape, (name, out.shape, ref.shape)
+    assert torch.isfinite(out).all(), f"{name}: non-finite output"
+    err = (out - ref).abs()
+    mx, mean = err.max().item(), err.mean().item()
+    rmx, rmean = ref.abs().max().item(), ref.abs().mean().item()
+    print(f"[{name}] max_err={mx:.4e} (ref max {rmx:.3e})  mean_err={mean:.4e} (ref mean {rmean:.3e})")
+    assert mx <= max_tol * rmx + 1e-6, f"{name}: max err {mx} vs ref max {rmx}"
+    assert mean <= mean_tol * rmean + 1e-7, f"{name}: mean err {mean} vs ref mean {rmean}"
+
+
+def _bf(*shape, scale=1.0, dev="cuda"):
+    return (torch.randn(*shape, device=dev) * scale).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 1280, 1280), (32768, 320, 320), (154, 640, 768), (2048, 1280, 5120),
+                                   (100, 64, 64), (8192, 960, 320)])
+def test_gemm_bias_res(cuda, M, N, K):
+    from neurons_amd import ops
+    torch.manual_seed(0)
+    a, w = _bf(M, K), _bf(N, K, scale=K ** -0.5)
+    bias = torch.randn(N, device=cuda)
+    res = _bf(M, N)
+    out = ops.gemm(a, w, bias, res)
+    ref = a.float() @ w.float().t() + bias + res.float()
+    _cmp(f"gemm {M}x{N}x{K}", out, ref)
+    out2 = ops.gemm(a, w)
+    _cmp(f"gemm-plain {M}x{N}x{K}", out2, a.float() @ w.float().t())
+
+
+@pytest.mark.parametrize("M,C", [(2048, 320), (300, 64), (512, 1280)])
+def test_gemm_geglu(cuda, M, C):
+    from neurons_amd import ops
+    torch.manual_seed(1)
+    a = _bf(M, C)
+    w = _bf(8 * C, C, scale=C ** -0.5)
+    b = torch.randn(8 * C, device=cuda) * 0.1
+    wp, bp = ops.geglu_permute(w, b)
+    out = ops.gemm(a, wp, bp, geglu=True)
+    h = a.float() @ w.float().t() + b
+    val, gate = h.chunk(2, dim=-1)
+    _cmp(f"geglu {M}x{C}", out, val * F.gelu(gate))
+
+
+def _conv_ref(x_nhwc, w_tap, bias, stride=1, ups=False):
+    x = x_nhwc.float().permute(0, 3, 1, 2)
+    if ups:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    w = w_tap.float().permute(0, 3, 1, 2)  # [Cout,3,3,Cin] -> [Cout,Cin,3,3]
+    y = F.conv2d(x, w, bias, stride=stride, padding=1)
+    return y.permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("nimg,H,W,Cin,Cout,stride,ups", [
+    (4, 32, 32, 320, 320, 1, False), (4, 16, 16, 640, 640, 2, False), (4, 8, 8, 1280, 1280, 1, True),
+    (2, 4, 4, 1280, 1280, 1, False), (3, 6, 10, 64, 128, 1, False), (3, 6, 10, 64, 64, 2, False)])
+def test_conv3x3(cuda, nimg, H, W, Cin, Cout, stride, ups):
+    from neurons_amd import ops
+    torch.manual_seed(2)
+    x = _bf(nimg, H, W, Cin)
+    w = _bf(Cout, 3, 3, Cin, scale=(9 * Cin) ** -0.5)
+    bias = torch.randn(Cout, device=cuda)
+    out = ops.conv3x3(x, w, bias, stride=stride, ups=ups)
+    _cmp(f"conv3x3 {nimg}x{H}x{W} {Cin}->{Cout} s{stride} u{int(ups)}", out, _conv_ref(x, w, bias, stride, ups))
+
+
+def test_conv3x3_concat_temb_res(cuda):
+    from neurons_amd import ops
+    torch.manual_seed(3)
+    nimg, H, W, c0, c1, Cout, Fr = 8, 8, 8, 128, 64, 128, 4
+    x0, x1 = _bf(nimg, H, W, c0), _bf(nimg, H, W, c1)
+    w = _bf(Cout, 3, 3, c0 + c1, scale=(9 * (c0 + c1)) ** -0.5)
+    bias = torch.randn(Cout, device=cuda)
+    temb = torch.randn(nimg // Fr, Cout, device=cuda)
+    res = _bf(nimg, H, W, Cout)
+    out = ops.conv3x3(x0, w, bias, x1=x1, rowvec=temb, rowvec_div=Fr * H * W, res=res)
+    ref = _conv_ref(torch.cat([x0, x1], dim=-1), w, bias)
+    ref = ref + temb.repeat_interleave(Fr, dim=0)[:, None, None, :] + res.float()
+    _cmp("conv3x3 concat+temb+res", out, ref)
+
+
+@pytest.mark.parametrize("nimg,H,W,c0,c1,silu,eps", [
+    (4, 32, 32, 320, 0, True, 1e-5), (4, 8, 8, 1280, 640, True, 1e-5), (2, 4, 4, 1280, 1280, False, 1e-6),
+    (3, 6, 10, 64, 0, False, 1e-6), (2, 16, 16, 640, 320, True, 1e-5), (3, 2, 2, 128, 64, True, 1e-5)])
+def test_groupnorm(cuda, nimg, H, W, c0, c1, silu, eps):
+    from neurons_amd import ops
+    torch.manual_seed(4)
+    x0 = (_bf(nimg, H, W, c0).float() * 2 + 0.5).to(torch.bfloat16)
+    x1 = _bf(nimg, H, W, c1) if c1 else None
+    C = c0 + c1
+    g, b = torch.randn(C, device=cuda), torch.randn(C, device=cuda)
+    out = ops.groupnorm(x0, g, b, groups=32, eps=eps, silu=silu, x1=x1)
+    xc = x0 if x1 is None else torch.cat([x0, x1], dim=-1)
+    ref = F.group_norm(xc.float().permute(0, 3, 1, 2), 32, g, b, eps)
+    if silu:
+        ref = F.silu(ref)
+    _cmp(f"groupnorm {nimg}x{H}x{W}x{c0}+{c1} silu{int(silu)}", out, ref.permute(0, 2, 3, 1))
+
+
+@pytest.mark.parametrize("M,C,with_pe", [(4096, 320, False), (1000, 640, True), (77, 1280, False), (64, 64, True)])
+def test_layernorm(cuda, M, C, with_pe):
+    from neurons_amd import ops
+    torch.manual_seed(5)
+    x = (_bf(M, C).float() * 3 + 1).to(torch.bfloat16)
+    g, b = torch.randn(C, device=cuda), torch.randn(C, device=cuda)
+    pe = torch.randn(8, C, device=cuda) if with_pe else None
+    hw = 5
+    out = ops.layernorm(x, g, b, pe=pe, pe_hw=hw, pe_F=8)
+    ref = F.layer_norm(x.float(), (C,), g, b, 1e-5)
+    if with_pe:
+        fidx = (torch.arange(M, device=cuda) // hw) % 8
+        ref = ref + pe[fidx]
+    _cmp(f"layernorm {M}x{C} pe{int(with_pe)}", out, ref)
+
+
+def _attn_ref(q, k, v, heads):
+    # q [B, Lq, C], k/v [B, Lk, C] fp32 -> motion_module_new.py:258-287
+    B, Lq, C = q.shape
+    d = C // heads
+    def split(t):
+        return t.reshape(B, -1, heads, d).permute(0, 2, 1, 3)
+    s = torch.matmul(split(q), split(k).transpose(-1, -2)) * (d ** -0.5)
+    p = s.softmax(dim=-1)
+    o = torch.matmul(p, split(v))
+    return o.permute(0, 2, 1, 3).reshape(B, Lq, C)
+
+
+@pytest.mark.parametrize("nimg,L,C", [(4, 1024, 320), (4, 256, 640), (8, 64, 1280), (8, 16, 1280), (3, 40, 64), (2, 100, 128)])
+def test_attention_self(cuda, nimg, L, C):
+    from neurons_amd import ops
+    torch.manual_seed(6)
+    qkv = _bf(nimg, L, 3 * C)
+    out = ops.attention_self(qkv, 8)
+    q, k, v = qkv.float().chunk(3, dim=-1)
+    _cmp(f"attn-self {nimg}x{L}x{C}", out, _attn_ref(q, k, v, 8), max_tol=3e-2, mean_tol=8e-3)
+
+
+@pytest.mark.parametrize("B,Fr,L,C,Lk", [(2, 4, 256, 320, 77), (2, 2, 64, 1280, 77), (1, 3, 24, 64, 5)])
+def test_attention_cross(cuda, B, Fr, L, C, Lk):
+    from neurons_amd import ops
+    torch.manual_seed(7)
+    q = _bf(B * Fr, L, C)
+    kv = _bf(B, Lk, 2 * C)
+    out = ops.attention_cross(q, kv, 8, Fr)
+    k, v = kv.float().chunk(2, dim=-1)
+    k = k.repeat_interleave(Fr, dim=0)
+    v = v.repeat_interleave(Fr, dim=0)
+    _cmp(f"attn-cross {B}x{Fr}x{L}x{C}", out, _attn_ref(q.float(), k, v, 8), max_tol=3e-2, mean_tol=8e-3)
+
+
+@pytest.mark.parametrize("B,Fr,hw,C", [(2, 16, 64, 320), (2, 8, 16, 640), (1, 16, 4, 1280), (2, 24, 9, 64), (1, 32, 8, 128)])
+def test_attention_temporal(cuda, B, Fr, hw, C):
+    from neurons_amd import ops
+    torch.manual_seed(8)
+    qkv = _bf(B * Fr, hw, 3 * C)
+    out = ops.attention_temporal(qkv, 8, Fr)
+    # "(b f) d c -> (b d) f c"  (motion_module.py:275)
+    t = qkv.float().reshape(B, Fr, hw, 3 * C).permute(0, 2, 1, 3).reshape(B * hw, Fr, 3 * C)
+    q, k, v = t.chunk(3, dim=-1)
+    ref = _attn_ref(q, k, v, 8).reshape(B, hw, Fr, C).permute(0, 2, 1, 3).reshape(B * Fr, hw, C)
+    _cmp(f"attn-temporal {B}x{Fr}x{hw}x{C}", out, ref, max_tol=3e-2, mean_tol=8e-3)
+
+
+def test_cfg_ddim_step(cuda):
+    from neurons_amd import ops
+    torch.manual_seed(9)
+    x = torch.randn(2, 4, 8, 16, 16, device=cuda)
+    eps = torch.randn(4, 4, 8, 16, 16, device=cuda)
+    a_t, a_p, s = 0.31, 0.47, 8.5
+    out = ops.cfg_ddim_step(eps, x, s, a_t, a_p)
+    eu, et = eps.chunk(2)
+    e = eu + s * (et - eu)
+    x0 = (x - (1 - a_t) ** 0.5 * e) / a_t ** 0.5
+    ref = a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * e
+    err = (out - ref).abs().max().item()
+    print(f"[cfg_ddim] max_err={err:.3e}")
+    assert err < 1e-4
