@@ -230,18 +230,18 @@ def random_state_dict(cfg: UNet3DConfig, kind: int = _lib.NR_KIND_UNET3D, seed: 
     the reference zero-initialises (motion ``proj_out`` motion_module.py:74-75, ControlNet zero-convs
     sparse_controlnet.py:244-246,281-295) are random too unless ``zero_init_heads`` — otherwise the temporal
     and control paths would be numerically invisible."""
-    g = torch.Generator().manual_seed(seed)
+    from .synth import randn
     sd = {}
     for name, shape in state_dict_schema(cfg, kind).items():
+        z = randn(name, shape, seed)
         if name.endswith(".bias"):
-            t = 0.02 * torch.randn(shape, generator=g)
-            if ".norm" in name or "norms." in name or "conv_norm_out" in name or "ff_norm" in name:
-                t = 0.1 * torch.randn(shape, generator=g)
+            is_norm = ".norm" in name or "norms." in name or "conv_norm_out" in name or "ff_norm" in name
+            t = (0.1 if is_norm else 0.02) * z
         elif len(shape) == 1:
-            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+            t = 1.0 + 0.1 * z
         else:
             fan_in = int(np.prod(shape[1:]))
-            t = torch.randn(shape, generator=g) / (fan_in ** 0.5)
+            t = z / (fan_in ** 0.5)
             zero = ("motion_modules" in name and ".proj_out." in name) or name.startswith("controlnet_down_blocks") or \
                 name.startswith("controlnet_mid_block") or name.startswith("controlnet_cond_embedding")
             if zero and zero_init_heads:

@@ -1,0 +1,370 @@
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own classes.
+
+Runs only in the build container (needs /root/reference; the GPU box never sees it).  Nothing from the
+reference is copied: its modules are imported from where they lie, fed deterministic synthetic weights and
+inputs (neurons_amd.synth: a recipe, not data), and only inputs/outputs are stored.
+
+Scaffolding: the reference imports un-vendored ``diffusers==0.11.1`` and ``torchvision``.  We
+register throw-away in-memory stand-ins for the NON-arithmetic pieces (ConfigMixin, ModelMixin, BaseOutput,
+logging, is_xformers_available).  The arithmetic pieces are wired to the reference's own text:
+  diffusers.models.attention.{CrossAttention, FeedForward}  <- animatediff/models/motion_module_new.py:119,429
+  diffusers.models.embeddings.Timesteps                      <- generative_models/sgm/modules/diffusionmodules/util.py:207
+  diffusers.models.embeddings.TimestepEmbedding              =  Linear -> SiLU -> Linear (as sgm openaimodel.py:590-594)
+The DDIM scheduler has no in-repo source; the loop fixture uses oracle.animatediff_oracle's restatement for the
+scheduler and the reference classes for the networks (parity for the scheduler stays "unpinned").
+
+Usage:  python oracle/gen_golden.py            (writes tests/golden/*.npz, a few hundred KB each)
+"""
+import functools
+import importlib.util
+import inspect
+import logging
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+
+# --------------------------------------------------------------------------------------------------
+# scaffolding
+# --------------------------------------------------------------------------------------------------
+class _FrozenDict(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+def _register_to_config(init):
+    @functools.wraps(init)
+    def inner(self, *args, **kwargs):
+        sig = inspect.signature(init)
+        bound = sig.bind(self, *args, **kwargs)
+        bound.apply_defaults()
+        cfg = {k: v for k, v in bound.arguments.items() if k != "self"}
+        object.__setattr__(self, "_internal_dict", _FrozenDict(cfg))
+        init(self, *args, **kwargs)
+    return inner
+
+
+class _ConfigMixin:
+    @property
+    def config(self):
+        return self._internal_dict
+
+
+class _ModelMixin(nn.Module):
+    @property
+    def dtype(self):
+        return next(self.parameters()).dtype
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+
+class _BaseOutput:
+    pass
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def install_scaffolding():
+    if "diffusers" in sys.modules and getattr(sys.modules["diffusers"], "_nr_stub", False):
+        return
+    log = types.SimpleNamespace(get_logger=lambda name=None: logging.getLogger(name or "ref"))
+    d = _mod("diffusers", _nr_stub=True, __version__="0.11.1-stub")
+    d.__path__ = []
+    _mod("diffusers.configuration_utils", ConfigMixin=_ConfigMixin, register_to_config=_register_to_config, FrozenDict=_FrozenDict)
+    _mod("diffusers.modeling_utils", ModelMixin=_ModelMixin)
+    u = _mod("diffusers.utils", BaseOutput=_BaseOutput, logging=log)
+    u.__path__ = []
+    _mod("diffusers.utils.import_utils", is_xformers_available=lambda: False)
+    m = _mod("diffusers.models")
+    m.__path__ = []
+    _mod("diffusers.models.unet_2d_condition", UNet2DConditionModel=type("UNet2DConditionModel", (), {}))
+    tv = _mod("torchvision")
+    tv.__path__ = []
+
+    # arithmetic: the reference's own vendored copy of diffusers' attention/FF
+    spec = importlib.util.spec_from_file_location("ref_motion_module_new", f"{REF}/animatediff/models/motion_module_new.py")
+    mmn = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mmn)
+
+    class AdaLayerNorm(nn.Module):  # never instantiated (num_embeds_ada_norm=None on the NEURONS path)
+        def __init__(self, *a, **k):
+            raise NotImplementedError
+
+    _mod("diffusers.models.attention", CrossAttention=mmn.CrossAttention, FeedForward=mmn.FeedForward, AdaLayerNorm=AdaLayerNorm)
+
+    # arithmetic: sinusoid from the reference's sgm util
+    spec = importlib.util.spec_from_file_location("ref_sgm_util", f"{REF}/generative_models/sgm/modules/diffusionmodules/util.py")
+    sgm_util = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sgm_util)
+
+    class Timesteps(nn.Module):
+        def __init__(self, num_channels, flip_sin_to_cos, downscale_freq_shift):
+            super().__init__()
+            assert flip_sin_to_cos and downscale_freq_shift == 0, "SD-1.5 config (unet.py:48-49)"
+            self.num_channels = num_channels
+
+        def forward(self, timesteps):
+            return sgm_util.timestep_embedding(timesteps, self.num_channels)
+
+    class TimestepEmbedding(nn.Module):
+        def __init__(self, in_channels, time_embed_dim, act_fn="silu"):
+            super().__init__()
+            self.linear_1 = nn.Linear(in_channels, time_embed_dim)
+            self.act = nn.SiLU()
+            self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
+
+        def forward(self, sample):
+            return self.linear_2(self.act(self.linear_1(sample)))
+
+    _mod("diffusers.models.embeddings", Timesteps=Timesteps, TimestepEmbedding=TimestepEmbedding)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+
+
+def reference_classes():
+    install_scaffolding()
+    from animatediff.models.unet import UNet3DConditionModel
+    from animatediff.models.sparse_controlnet import SparseControlNetModel
+    from animatediff.models import attention as ref_attention, motion_module as ref_mm, resnet as ref_resnet
+    return UNet3DConditionModel, SparseControlNetModel, ref_attention, ref_mm, ref_resnet
+
+
+# --------------------------------------------------------------------------------------------------
+# shared tiny configuration (also imported by tests/)
+# --------------------------------------------------------------------------------------------------
+def tiny_unet_config():
+    from neurons_amd.unet3d import UNet3DConfig
+    return UNet3DConfig(sample_size=8, block_out_channels=(64, 64, 128, 128), cross_attention_dim=64)
+
+
+def tiny_ctrl_config():
+    from neurons_amd.sparsectrl import controlnet_config_from_unet
+    return controlnet_config_from_unet(tiny_unet_config(), dict(
+        set_noisy_sample_input_to_zero=True, use_simplified_condition_embedding=True, conditioning_channels=4,
+        use_motion_module=True, motion_module_resolutions=[1, 2, 4, 8], motion_module_mid_block=False,
+        motion_module_type="Vanilla",
+        motion_module_kwargs=dict(num_attention_heads=8, num_transformer_block=1, attention_block_types=["Temporal_Self"],
+                                  temporal_position_encoding=True, temporal_position_encoding_max_len=32,
+                                  temporal_attention_dim_div=1)))
+
+
+def build_reference_unet(cfg, sd):
+    UNet3D, _, _, _, _ = reference_classes()
+    mm = dict(cfg.motion_module_kwargs)
+    mm["attention_block_types"] = list(mm["attention_block_types"])
+    net = UNet3D(sample_size=cfg.sample_size, in_channels=cfg.in_channels, out_channels=cfg.out_channels,
+                 down_block_types=tuple(cfg.down_block_types), up_block_types=tuple(cfg.up_block_types),
+                 block_out_channels=tuple(cfg.block_out_channels), layers_per_block=cfg.layers_per_block,
+                 norm_num_groups=cfg.norm_num_groups, norm_eps=cfg.norm_eps, cross_attention_dim=cfg.cross_attention_dim,
+                 attention_head_dim=cfg.attention_head_dim, use_inflated_groupnorm=True, use_motion_module=True,
+                 motion_module_resolutions=tuple(cfg.motion_module_resolutions), motion_module_mid_block=False,
+                 motion_module_type="Vanilla", motion_module_kwargs=mm,
+                 unet_use_cross_frame_attention=False, unet_use_temporal_attention=False)
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.endswith("pos_encoder.pe") for k in missing), missing
+    ref_keys = {k for k in net.state_dict().keys()}
+    assert ref_keys == set(sd.keys()), "schema differs from the reference's state_dict keys"
+    return net.eval()
+
+
+def build_reference_ctrl(cfg, sd):
+    _, Ctrl, _, _, _ = reference_classes()
+    mm = dict(cfg.motion_module_kwargs)
+    mm["attention_block_types"] = list(mm["attention_block_types"])
+    net = Ctrl(in_channels=cfg.in_channels, conditioning_channels=cfg.conditioning_channels,
+               down_block_types=tuple(cfg.down_block_types), block_out_channels=tuple(cfg.block_out_channels),
+               layers_per_block=cfg.layers_per_block, norm_num_groups=cfg.norm_num_groups, norm_eps=cfg.norm_eps,
+               cross_attention_dim=cfg.cross_attention_dim, attention_head_dim=cfg.attention_head_dim,
+               use_motion_module=True, motion_module_resolutions=(1, 2, 4, 8), motion_module_mid_block=False,
+               motion_module_type="Vanilla", motion_module_kwargs=mm, concate_conditioning_mask=True,
+               use_simplified_condition_embedding=True, set_noisy_sample_input_to_zero=True)
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.endswith("pos_encoder.pe") for k in missing), missing
+    assert set(net.state_dict().keys()) == set(sd.keys()), "schema differs from the reference's state_dict keys"
+    return net.eval()
+
+
+def _sub(t, n=4096):
+    """deterministic subsample of a big tensor: (flat indices, values)"""
+    flat = t.detach().reshape(-1)
+    if flat.numel() <= n:
+        idx = np.arange(flat.numel())
+    else:
+        idx = (np.arange(n, dtype=np.int64) * 2654435761 % flat.numel())
+    return idx.astype(np.int64), flat[torch.from_numpy(idx)].numpy().astype(np.float32)
+
+
+@torch.no_grad()
+def gen_networks(out_dir):
+    from neurons_amd import _lib
+    from neurons_amd.synth import randn
+    from neurons_amd.unet3d import random_state_dict
+    ucfg, ccfg = tiny_unet_config(), tiny_ctrl_config()
+    usd = random_state_dict(ucfg, _lib.NR_KIND_UNET3D, seed=11)
+    csd = random_state_dict(ccfg, _lib.NR_KIND_SPARSECTRL, seed=12)
+    unet = build_reference_unet(ucfg, usd)
+    ctrl = build_reference_ctrl(ccfg, csd)
+    B, F, H, W = 1, 8, 8, 8
+    sample = randn("sample", (2 * B, 4, F, H, W), 21)
+    ctx = randn("ctx", (2 * B, 77, ucfg.cross_attention_dim), 22)
+    cond = torch.zeros(B, 4, F, H, W)
+    cond[:, :, 0] = randn("cond", (B, 4, H, W), 23) * 0.18215
+    mask = torch.zeros(B, 1, F, H, W)
+    mask[:, :, 0] = 1
+    t = 681
+
+    # hook a few intermediate modules of the reference U-Net
+    taps = {}
+    names = ["down_blocks.0.resnets.0", "down_blocks.0.attentions.0", "down_blocks.0.motion_modules.0",
+             "down_blocks.1.downsamplers.0", "mid_block.resnets.1", "up_blocks.1.upsamplers.0", "up_blocks.3.motion_modules.2"]
+    mods = dict(unet.named_modules())
+    hooks = []
+    for n in names:
+        def mk(n):
+            def hook(m, i, o):
+                taps[n] = o.sample if hasattr(o, "sample") else o
+            return hook
+        hooks.append(mods[n].register_forward_hook(mk(n)))
+    eps_plain = unet(sample, t, encoder_hidden_states=ctx).sample
+    for h in hooks:
+        h.remove()
+    down, mid = ctrl(sample, t, encoder_hidden_states=ctx, controlnet_cond=cond, conditioning_mask=mask,
+                     conditioning_scale=1.0, guess_mode=False, return_dict=False)
+    eps_ctrl = unet(sample, t, encoder_hidden_states=ctx, down_block_additional_residuals=down,
+                    mid_block_additional_residual=mid).sample
+    out = dict(sample=sample.numpy(), ctx=ctx.numpy(), cond=cond.numpy(), mask=mask.numpy(), t=np.int64(t),
+               eps_plain=eps_plain.numpy(), eps_ctrl=eps_ctrl.numpy(), mid_res=mid.numpy())
+    for i, d in enumerate(down):
+        out[f"down_res_{i}"] = d.numpy()
+    for n, v in taps.items():
+        idx, val = _sub(v)
+        out[f"tap_idx:{n}"] = idx
+        out[f"tap_val:{n}"] = val
+        out[f"tap_shape:{n}"] = np.array(v.shape)
+    np.savez_compressed(os.path.join(out_dir, "tiny_networks.npz"), **out)
+    print("tiny_networks:", {k: getattr(v, "shape", None) for k, v in out.items() if not k.startswith("tap_")})
+    return unet, ctrl, usd, csd, ucfg, ccfg
+
+
+@torch.no_grad()
+def gen_loop(out_dir, unet, ctrl):
+    """BASELINE config 1: single 8-frame 64x64 clip (8x8 latent), 10 DDIM steps, guidance 8.5, random conditioning."""
+    from neurons_amd.synth import randn
+    from oracle import animatediff_oracle as O
+    B, F, H, W, N, s = 1, 8, 8, 8, 10, 8.5
+    latents = randn("c1.latents", (B, 4, F, H, W), 31)
+    noise = randn("c1.noise", (B, 4, F, H, W), 32)
+    ctx = randn("c1.ctx", (2 * B, 77, 64), 33)
+    cimg = randn("c1.cimg", (B, 4, 1, H, W), 34) * 0.18215
+    ac = O.ddim_alphas_cumprod()
+    ts = O.ddim_timesteps(N)
+    x = O.add_noise(latents, noise, ts[0], ac)
+    cond = torch.zeros(B, 4, F, H, W)
+    cond[:, :, [0]] = cimg[:, :, :1]
+    mask = torch.zeros(B, 1, F, H, W)
+    mask[:, :, [0]] = 1
+    eps_log = {}
+    for i, t in enumerate(ts):
+        xin = torch.cat([x] * 2)
+        down, mid = ctrl(xin, t, encoder_hidden_states=ctx, controlnet_cond=cond, conditioning_mask=mask,
+                         conditioning_scale=1.0, guess_mode=False, return_dict=False)
+        eps = unet(xin, t, encoder_hidden_states=ctx, down_block_additional_residuals=down,
+                   mid_block_additional_residual=mid).sample
+        if i in (0, 1, N - 1):
+            eps_log[i] = eps.numpy()
+        eu, et = eps.chunk(2)
+        e = eu + s * (et - eu)
+        x = O.ddim_step(e, t, x, ac, N)
+    out = dict(latents=latents.numpy(), noise=noise.numpy(), ctx=ctx.numpy(), cimg=cimg.numpy(), steps=np.int64(N),
+               guidance=np.float64(s), timesteps=np.array(ts), final=x.numpy())
+    for i, e in eps_log.items():
+        out[f"eps_step_{i}"] = e
+    np.savez_compressed(os.path.join(out_dir, "c1_loop.npz"), **out)
+    print("c1_loop: final latents", x.shape, "abs mean", x.abs().mean().item())
+
+
+@torch.no_grad()
+def gen_leaf_ops(out_dir):
+    """Full-width leaf modules of the reference (head dims 40/80/160, Cin 2560 @ 4x4, temporal attention with PE)."""
+    from neurons_amd.synth import randn
+    _, _, ref_attention, ref_mm, ref_resnet = reference_classes()
+    CrossAttention = sys.modules["diffusers.models.attention"].CrossAttention
+    FeedForward = sys.modules["diffusers.models.attention"].FeedForward
+    out = {}
+
+    def fill(mod, tag, seed):
+        sd = {}
+        for k, v in mod.state_dict().items():
+            if k.endswith("pos_encoder.pe"):
+                continue
+            z = randn(f"{tag}.{k}", tuple(v.shape), seed)
+            if v.dim() == 1:
+                z = (1.0 + 0.1 * z) if k.endswith("weight") else 0.05 * z
+            else:
+                z = z / (int(np.prod(v.shape[1:])) ** 0.5)
+            sd[k] = z
+        mod.load_state_dict(sd, strict=False)
+        return mod.eval()
+
+    for C in (320, 640, 1280):
+        a = fill(CrossAttention(query_dim=C, heads=8, dim_head=C // 8), f"attn{C}", 41)
+        x = randn(f"attn{C}.x", (2, 48, C), 42)
+        out[f"selfattn{C}.y"] = a(x).numpy()
+        ac = fill(CrossAttention(query_dim=C, cross_attention_dim=768, heads=8, dim_head=C // 8), f"xattn{C}", 43)
+        ctx = randn(f"xattn{C}.ctx", (2, 77, 768), 44)
+        out[f"crossattn{C}.y"] = ac(x, encoder_hidden_states=ctx).numpy()
+    ff = fill(FeedForward(320, activation_fn="geglu"), "ff320", 45)
+    out["ff320.y"] = ff(randn("ff320.x", (2, 48, 320), 46)).numpy()
+    va = fill(ref_mm.VersatileAttention(attention_mode="Temporal", cross_attention_dim=None, query_dim=320, heads=8, dim_head=40,
+                                        temporal_position_encoding=True, temporal_position_encoding_max_len=24), "va320", 47)
+    out["va320.y"] = va(randn("va320.x", (2 * 16, 6, 320), 48), video_length=16).numpy()
+    rb = fill(ref_resnet.ResnetBlock3D(in_channels=2560, out_channels=1280, temb_channels=1280, eps=1e-5, groups=32,
+                                       use_inflated_groupnorm=True), "rb2560", 49)
+    y = rb(randn("rb2560.x", (1, 2560, 2, 4, 4), 50), randn("rb2560.temb", (1, 1280), 51))
+    out["rb2560.y"] = y.numpy()
+    tm = fill(ref_mm.VanillaTemporalModule(in_channels=320, num_attention_heads=8, num_transformer_block=1,
+                                           attention_block_types=("Temporal_Self", "Temporal_Self"),
+                                           temporal_position_encoding=True, temporal_position_encoding_max_len=24,
+                                           zero_initialize=False), "tm320", 52)
+    out["tm320.y"] = tm(randn("tm320.x", (1, 320, 16, 3, 3), 53), None, None).numpy()
+    t3 = fill(ref_attention.Transformer3DModel(8, 40, in_channels=320, num_layers=1, cross_attention_dim=768, norm_num_groups=32,
+                                               unet_use_cross_frame_attention=False, unet_use_temporal_attention=False), "t3d320", 54)
+    out["t3d320.y"] = t3(randn("t3d320.x", (1, 320, 2, 4, 4), 55), encoder_hidden_states=randn("t3d320.ctx", (1, 77, 768), 56)).sample.numpy()
+    up = fill(ref_resnet.Upsample3D(64, use_conv=True, out_channels=64), "up64", 57)
+    out["up64.y"] = up(randn("up64.x", (1, 64, 2, 3, 5), 58)).numpy()
+    dn = fill(ref_resnet.Downsample3D(64, use_conv=True, out_channels=64, padding=1, name="op"), "dn64", 59)
+    out["dn64.y"] = dn(randn("dn64.x", (1, 64, 2, 6, 10), 60)).numpy()
+    np.savez_compressed(os.path.join(out_dir, "leaf_ops.npz"), **out)
+    print("leaf_ops:", {k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+    unet, ctrl, *_ = gen_networks(out_dir)
+    gen_loop(out_dir, unet, ctrl)
+    gen_leaf_ops(out_dir)
+    for f in sorted(os.listdir(out_dir)):
+        print(f, os.path.getsize(os.path.join(out_dir, f)) // 1024, "KiB")
