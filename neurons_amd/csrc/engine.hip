@@ -192,12 +192,18 @@ struct nr_net {
   bool use_graph = false;
   hipGraphExec_t gexec = nullptr;
   IO captured;
-  hipStream_t captured_stream = nullptr;
+  // graph replay happens on an engine-owned non-blocking stream (capture is illegal on the legacy default
+  // stream PyTorch hands over); it is fenced to the caller's stream with two events per forward
+  hipStream_t own_stream = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
 
   ~nr_net() {
     for (auto& kv : dev) if (kv.second) (void)hipFree(kv.second);
     if (arena_base) (void)hipFree(arena_base);
     if (gexec) (void)hipGraphExecDestroy(gexec);
+    if (ev_in) (void)hipEventDestroy(ev_in);
+    if (ev_out) (void)hipEventDestroy(ev_out);
+    if (own_stream) (void)hipStreamDestroy(own_stream);
   }
 
   // ------------------------------------------------------------------ weights
@@ -819,15 +825,24 @@ struct nr_net {
     planned = true;
   }
 
-  void run(hipStream_t s, const float* timesteps) {
+  void run(hipStream_t caller, const float* timesteps) {
     TimestepVals tv;
     for (int i = 0; i < 16; ++i) tv.v[i] = i < B2 ? timesteps[i] : 0.f;
-    hipLaunchKernelGGL(set_timesteps_kernel, dim3(1), dim3(64), 0, s, t_dev, tv, B2);
     if (!use_graph) {
-      for (auto& op : ops) op(s);
+      hipLaunchKernelGGL(set_timesteps_kernel, dim3(1), dim3(64), 0, caller, t_dev, tv, B2);
+      for (auto& op : ops) op(caller);
       return;
     }
-    if (!gexec || !(captured == io) || captured_stream != s) {
+    if (!own_stream) {
+      HIP_OK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+      HIP_OK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+      HIP_OK(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
+    }
+    hipStream_t s = own_stream;
+    HIP_OK(hipEventRecord(ev_in, caller));
+    HIP_OK(hipStreamWaitEvent(s, ev_in, 0));
+    hipLaunchKernelGGL(set_timesteps_kernel, dim3(1), dim3(64), 0, s, t_dev, tv, B2);
+    if (!gexec || !(captured == io)) {
       if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
       hipGraph_t g = nullptr;
       HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -842,9 +857,11 @@ struct nr_net {
       hipError_t e = hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0);
       (void)hipGraphDestroy(g);
       if (e != hipSuccess) { gexec = nullptr; throw NrError(NR_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
-      captured = io; captured_stream = s;
+      captured = io;
     }
     HIP_OK(hipGraphLaunch(gexec, s));
+    HIP_OK(hipEventRecord(ev_out, s));
+    HIP_OK(hipStreamWaitEvent(caller, ev_out, 0));
   }
 };
 
