@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the NEURONS video-denoising hot path on MI355X.
+
+Metric (BASELINE.json): denoising frames/sec on 16-frame 256x256 clips, 50 DDIM steps.
+One "step" of this script = ONE CLIP through the whole hot path: 50 x {SparseCtrl forward, temporal U-Net
+forward on the CFG-doubled batch, CFG combine + DDIM update} on a (1,4,16,32,32) latent — BASELINE config 2.
+Inputs (latents, noise, text context, keyframe latent) are synthetic and resident in HBM before the timed
+region; weights are seeded random tensors of the reference architecture (1 277 M + 497 M parameters).
+
+    python bench.py --gpus N --steps K --warmup W
+For N > 1 the driver launches one rank per GPU with torch.distributed.run; clips shard across ranks with no
+data-path collective (weak scaling); rank 0 broadcasts the shared weights once over RCCL before timing.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     dominant kernel class = the MFMA implicit-GEMM (conv/Linear): algorithmic FLOPs / summed launch
+               time, measured with one HIP event pair per launch on the launch stream (nr_net_profile_last).
+  cpu_baseline the oracle (fp32 torch restatement of the reference graph, eager, math attention) timed on the host
+               cores for a bounded sample and scaled to the clip.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3, help="timed clips per GPU")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed clips per GPU")
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--latent", type=int, default=32, help="latent side (pixels/8)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    return ap.parse_args()
+
+
+def gpu_random_state_dict(schema, seed, device):
+    """Seeded weights generated on the GPU (fast for 1.8 G parameters); same scaling rules as
+    neurons_amd.unet3d.random_state_dict."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd = {}
+    for name, shape in schema.items():
+        z = torch.randn(shape, generator=g, device=device, dtype=torch.float32)
+        if name.endswith(".bias"):
+            is_norm = ".norm" in name or "norms." in name or "conv_norm_out" in name or "ff_norm" in name
+            z = (0.1 if is_norm else 0.02) * z
+        elif len(shape) == 1:
+            z = 1.0 + 0.1 * z
+        else:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            z = z / (fan_in ** 0.5)
+        sd[name] = z
+    return sd
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=dev)
+
+    from neurons_amd import _lib, DDIMScheduler, NativeSparseCtrl, NativeUNet3D, NeuroclipsPipeline
+    from neurons_amd.sparsectrl import controlnet_config_from_unet
+    from neurons_amd.unet3d import UNet3DConfig, state_dict_schema
+
+    ucfg = UNet3DConfig()
+    ccfg = controlnet_config_from_unet(ucfg, dict(
+        set_noisy_sample_input_to_zero=True, use_simplified_condition_embedding=True, conditioning_channels=4,
+        motion_module_kwargs=dict(attention_block_types=["Temporal_Self"], temporal_position_encoding_max_len=32)))
+    unet = NativeUNet3D(ucfg).to(dev)
+    ctrl = NativeSparseCtrl(ccfg).to(dev)
+    if args.no_graph:
+        unet.enable_graph(False)
+        ctrl.enable_graph(False)
+
+    # ---- weights: rank 0 generates, everyone receives them over RCCL/xGMI (one broadcast per network) ----
+    t0 = time.time()
+    host_sd = {}
+    for net, cfg, kind, seed in ((unet, ucfg, _lib.NR_KIND_UNET3D, 1), (ctrl, ccfg, _lib.NR_KIND_SPARSECTRL, 2)):
+        schema = state_dict_schema(cfg, kind)
+        total = sum(int(torch.Size(s).numel()) for s in schema.values())
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        if rank == 0:
+            sd = gpu_random_state_dict(schema, seed, dev)
+            off = 0
+            for k, s in schema.items():
+                n = sd[k].numel()
+                flat[off:off + n] = sd[k].reshape(-1)
+                off += n
+            del sd
+        if dist is not None:
+            dist.broadcast(flat, src=0)
+        flat_cpu = flat.cpu()
+        del flat
+        sd, off = {}, 0
+        for k, s in schema.items():
+            n = int(torch.Size(s).numel())
+            sd[k] = flat_cpu[off:off + n].view(s)
+            off += n
+        net.load_state_dict(sd)
+        host_sd[kind] = sd
+    torch.cuda.empty_cache()
+
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
+    pipe = NeuroclipsPipeline(vae=None, text_encoder=None, tokenizer=None, unet=unet, scheduler=sched, controlnet=ctrl).to(dev)
+
+    F, L = args.frames, args.latent
+    n_clips = args.warmup + args.steps
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    clips = []
+    for _ in range(n_clips):   # synthetic inputs, resident in HBM before timing
+        clips.append(dict(
+            latents=torch.randn(1, 4, F, L, L, generator=g, device=dev),
+            noise=torch.randn(1, 4, F, L, L, generator=g, device=dev),
+            ctx=torch.randn(2, 77, ucfg.cross_attention_dim, generator=g, device=dev),
+            cimg=torch.randn(1, 4, 1, L, L, generator=g, device=dev) * 0.18215))
+
+    def run_clip(c):
+        return pipe("", video_length=F, height=L * 8, width=L * 8, num_inference_steps=args.ddim_steps, guidance_scale=8.5,
+                    latents=c["latents"], noise=c["noise"], text_embeddings=c["ctx"], controlnet_images=c["cimg"],
+                    controlnet_image_index=[0], low_strength=0.3, output_type="latent").videos
+
+    for i in range(args.warmup):
+        run_clip(clips[i])
+    torch.cuda.synchronize()
+    setup_s = time.time() - t0
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(args.warmup, n_clips):
+        out = run_clip(clips[i])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t1
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    finite = bool(torch.isfinite(out).all().item())
+
+    result = None
+    if rank == 0:
+        total_frames = world * args.steps * F
+        value = total_frames / elapsed
+        # ---- roofline of the dominant kernel class (MFMA implicit GEMM), HIP events per launch ----
+        pu, pc = unet.profile_last(), ctrl.profile_last()
+        ig_ms = pu["igemm"]["ms"] + pc["igemm"]["ms"]
+        ig_fl = pu["igemm"]["flops"] + pc["igemm"]["flops"]
+        ig_n = pu["igemm"]["launches"] + pc["igemm"]["launches"]
+        achieved = ig_fl / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
+        breakdown = {k: round(pu[k]["ms"] + pc[k]["ms"], 3) for k in pu}
+        step_flops = sum(pu[k]["flops"] + pc[k]["flops"] for k in pu)
+        step_bytes = sum(pu[k]["bytes"] + pc[k]["bytes"] for k in pu)
+        result = {
+            "metric": "denoising frames/sec, 16f x 256^2 clip, 50 DDIM steps",
+            "value": round(value, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 2: 1 clip/GPU, (1,4,{F},{L},{L}) latent, {args.ddim_steps} DDIM steps, CFG 8.5 "
+                                   f"(batch 2), SparseCtrl + temporal U-Net per step, random-init weights",
+                       "clips_per_gpu": args.steps, "frame_steps_per_s": round(value * args.ddim_steps, 2),
+                       "ms_per_ddim_step": round(1e3 * elapsed / args.steps / args.ddim_steps, 3),
+                       "hip_graph": not args.no_graph, "output_finite": finite, "setup_s": round(setup_s, 1)},
+            "roofline": {"bound": "mfma", "kernel": "igemm_bf16_kernel (3x3/1x1 conv + Linear)", "achieved": round(achieved, 2),
+                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                         "traffic": None, "launches_per_ddim_step": ig_n, "ms_per_ddim_step": round(ig_ms, 3),
+                         "algorithmic_tflop_per_ddim_step": round(ig_fl / 1e12, 3),
+                         "per_class_ms_per_ddim_step": breakdown,
+                         "whole_step_algorithmic": {"tflop": round(step_flops / 1e12, 3), "gbytes": round(step_bytes / 1e9, 2)}},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(host_sd, ucfg, ccfg, args)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+def cpu_baseline(host_sd, ucfg, ccfg, args):
+    """Oracle (reference module graph, fp32, eager) on the host cores: ONE denoising step (SparseCtrl + U-Net, CFG
+    batch 2) at a reduced frame count, scaled linearly in frames and DDIM steps to the clip (per-frame work is
+    frame-count independent except the tiny temporal-attention core)."""
+    from neurons_amd import _lib
+    from oracle import animatediff_oracle as O
+    threads = torch.get_num_threads()
+    Fs, L = 2, args.latent
+    uc, cc = O.OracleConfig.from_native(ucfg), O.OracleConfig.from_native(ccfg)
+    usd, csd = host_sd[_lib.NR_KIND_UNET3D], host_sd[_lib.NR_KIND_SPARSECTRL]
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, Fs, L, L, generator=g)
+    ctx = torch.randn(2, 77, ucfg.cross_attention_dim, generator=g)
+    cond = torch.zeros(1, 4, Fs, L, L)
+    mask = torch.zeros(1, 1, Fs, L, L)
+    mask[:, :, 0] = 1
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        down, mid = O.sparse_controlnet_forward(csd, cc, x, 500, ctx, cond, mask, 1.0)
+        O.unet3d_forward(usd, uc, x, 500, ctx, down, mid)
+        dt = time.perf_counter() - t0
+    clip_s = dt * (args.frames / Fs) * args.ddim_steps
+    return {"value": round(args.frames / clip_s, 6), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"1 DDIM step (SparseCtrl+U-Net fwd, CFG batch 2) at {Fs} frames {L}x{L} latent took {dt:.2f} s on "
+                      f"{threads} threads ({os.cpu_count()} logical CPUs); scaled x{args.frames // Fs} frames x{args.ddim_steps} steps"}
+
+
+if __name__ == "__main__":
+    main()

@@ -88,6 +88,10 @@ nr_status nr_net_load_tensor(nr_net* h, const char* key, const float* host_data,
  * again with another shape. */
 nr_status nr_net_plan(nr_net* h, int32_t batch, int32_t frames, int32_t lat_h, int32_t lat_w, int32_t ctx_len);
 
+/* Frees the host fp32 copies of the state dict (7 GB for the two full-size networks); the converted
+ * device weights stay.  Re-planning with another shape keeps working; loading new tensors re-converts. */
+nr_status nr_net_release_host_weights(nr_net* h);
+
 /* 1: run forward as a captured hipGraph (re-captured when an I/O pointer changes); 0: eager launches */
 nr_status nr_net_set_graph(nr_net* h, int32_t enable);
 
@@ -126,6 +130,23 @@ nr_status nr_sparsectrl_forward(nr_net* h, nr_stream stream, const float* sample
  *   eps_dev fp32 [2B or B][...], x_dev fp32 [B][...] -> x_out_dev (may alias x_dev); n = elements of x     */
 nr_status nr_cfg_ddim_step(nr_stream stream, const float* eps_dev, const float* x_dev, float* x_out_dev, int64_t n,
                            float guidance_scale, int32_t do_cfg, double alpha_prod_t, double alpha_prod_t_prev);
+
+/* ---- measurement ----------------------------------------------------------------------------- */
+#define NR_PROF_IGEMM 0     /* MFMA implicit-GEMM conv / Linear kernel            */
+#define NR_PROF_GROUPNORM 1
+#define NR_PROF_LAYERNORM 2
+#define NR_PROF_ATTENTION 3
+#define NR_PROF_OTHER 4     /* boundary convs, time embedding, adds, converts     */
+#define NR_PROF_KINDS 5
+typedef struct nr_profile {
+  double ms[NR_PROF_KINDS];       /* summed launch durations, HIP events on the launch stream */
+  double flops[NR_PROF_KINDS];    /* algorithmic FLOPs (2*M*N*K; 4*B*H*Lq*Lk*d for attention)   */
+  double bytes[NR_PROF_KINDS];    /* algorithmic bytes (inputs + weights + outputs, bf16)       */
+  int32_t launches[NR_PROF_KINDS];
+} nr_profile;
+/* Re-runs the launch plan of the most recent forward eagerly on `stream`, one HIP event pair per
+ * launch, and reports per-kernel-class totals (bench.py's roofline object). */
+nr_status nr_net_profile_last(nr_net* h, nr_stream stream, nr_profile* out);
 
 /* ---- debug / test hooks (activation taps by reference module name) --------------------------- */
 nr_status nr_net_set_debug(nr_net* h, int32_t keep_all_activations);

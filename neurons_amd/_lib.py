@@ -39,6 +39,15 @@ class NrNetConfig(C.Structure):
     ]
 
 
+NR_PROF_KINDS = 5
+NR_PROF_NAMES = ("igemm", "groupnorm", "layernorm", "attention", "other")
+
+
+class NrProfile(C.Structure):
+    _fields_ = [("ms", C.c_double * NR_PROF_KINDS), ("flops", C.c_double * NR_PROF_KINDS),
+                ("bytes", C.c_double * NR_PROF_KINDS), ("launches", C.c_int32 * NR_PROF_KINDS)]
+
+
 # every symbol include/neurons_amd.h declares: name -> (restype, argtypes)
 _VP = C.c_void_p
 _FP = C.POINTER(C.c_float)
@@ -50,6 +59,7 @@ SYMBOLS = {
     "nr_last_error": (C.c_char_p, []),
     "nr_net_load_tensor": (_I32, [_VP, C.c_char_p, _VP, C.POINTER(_I64), _I32]),
     "nr_net_plan": (_I32, [_VP, _I32, _I32, _I32, _I32, _I32]),
+    "nr_net_release_host_weights": (_I32, [_VP]),
     "nr_net_set_graph": (_I32, [_VP, _I32]),
     "nr_net_workspace_bytes": (_I64, [_VP]),
     "nr_net_weight_bytes": (_I64, [_VP]),
@@ -58,6 +68,7 @@ SYMBOLS = {
     "nr_unet3d_forward": (_I32, [_VP, _VP, _VP, _FP, _VP, _I32, C.POINTER(_VP), _VP, _VP]),
     "nr_sparsectrl_forward": (_I32, [_VP, _VP, _VP, _FP, _VP, _I32, _VP, _VP, _I32, C.c_float, C.POINTER(_VP), _VP]),
     "nr_cfg_ddim_step": (_I32, [_VP, _VP, _VP, _VP, _I64, C.c_float, _I32, C.c_double, C.c_double]),
+    "nr_net_profile_last": (_I32, [_VP, _VP, C.POINTER(NrProfile)]),
     "nr_net_set_debug": (_I32, [_VP, _I32]),
     "nr_net_num_taps": (_I32, [_VP]),
     "nr_net_tap_name": (C.c_char_p, [_VP, _I32]),

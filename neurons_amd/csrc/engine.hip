@@ -177,6 +177,8 @@ struct nr_net {
   char* arena_base = nullptr;
   size_t arena_bytes = 0;
   std::vector<std::function<void(hipStream_t)>> ops;
+  struct OpMeta { int kind; double flops, bytes; };
+  std::vector<OpMeta> op_meta;   // parallel to ops: kernel class + algorithmic work (for roofline reporting)
   std::vector<Tap> taps;
   bool keep_all = false;
   IO io;
@@ -213,6 +215,13 @@ struct nr_net {
     return it->second;
   }
   bool has(const std::string& key) const { return host.count(key) != 0; }
+  // host copies may have been released after the first plan (nr_net_release_host_weights)
+  const HostTensor& data_of(const std::string& key) const {
+    const HostTensor& t = need(key);
+    if ((int64_t)t.data.size() != t.numel())
+      throw NrError(NR_ERR_STATE, "host copy of " + key + " was released; load the state dict again before re-converting");
+    return t;
+  }
 
   void* upload(const std::string& name, const void* data, size_t bytes) {
     void* d = nullptr;
@@ -243,8 +252,9 @@ struct nr_net {
     const HostTensor& t = need(key);
     check_shape(key, t, {N, K});
     return (const bf16*)cached("lin:" + key, [&]() {
+      const HostTensor& td = data_of(key);
       std::vector<uint16_t> h((size_t)N * K);
-      for (size_t i = 0; i < h.size(); ++i) h[i] = f2bf_host(t.data[i]);
+      for (size_t i = 0; i < h.size(); ++i) h[i] = f2bf_host(td.data[i]);
       return upload("lin:" + key, h.data(), h.size() * 2);
     });
   }
@@ -255,7 +265,7 @@ struct nr_net {
     return (const bf16*)cached(name, [&]() {
       std::vector<uint16_t> h((size_t)keys.size() * Neach * K);
       size_t o = 0;
-      for (auto& k : keys) { const HostTensor& t = need(k); for (size_t i = 0; i < t.data.size(); ++i) h[o++] = f2bf_host(t.data[i]); }
+      for (auto& k : keys) { const HostTensor& t = data_of(k); for (size_t i = 0; i < t.data.size(); ++i) h[o++] = f2bf_host(t.data[i]); }
       return upload(name, h.data(), h.size() * 2);
     });
   }
@@ -264,6 +274,7 @@ struct nr_net {
     const HostTensor& t = need(key);
     check_shape(key, t, {2 * inner, K});
     return (const bf16*)cached("geglu:" + key, [&]() {
+      (void)data_of(key);
       std::vector<uint16_t> h((size_t)2 * inner * K);
       for (int n = 0; n < 2 * inner; ++n) {
         const int q = n / 32, j = n % 32;
@@ -277,6 +288,7 @@ struct nr_net {
     const HostTensor& t = need(key);
     check_shape(key, t, {2 * inner});
     return (const float*)cached("geglub:" + key, [&]() {
+      (void)data_of(key);
       std::vector<float> h((size_t)2 * inner);
       for (int n = 0; n < 2 * inner; ++n) {
         const int q = n / 32, j = n % 32;
@@ -290,6 +302,7 @@ struct nr_net {
     const HostTensor& t = need(key);
     check_shape(key, t, {Cout, Cin, 3, 3});
     return (const bf16*)cached("conv3:" + key, [&]() {
+      (void)data_of(key);
       std::vector<uint16_t> h((size_t)Cout * 9 * Cin);
       for (int o = 0; o < Cout; ++o)
         for (int c = 0; c < Cin; ++c)
@@ -303,6 +316,7 @@ struct nr_net {
     const HostTensor& t = need(key);
     check_shape(key, t, {Cout, Cin, 3, 3});
     return (const float*)cached("convin:" + key, [&]() {
+      (void)data_of(key);
       std::vector<float> h((size_t)Cin * 9 * Cout);
       for (int o = 0; o < Cout; ++o)
         for (int k = 0; k < Cin * 9; ++k) h[(size_t)k * Cout + o] = t.data[(size_t)o * Cin * 9 + k];
@@ -312,7 +326,7 @@ struct nr_net {
   const float* w_f32(const std::string& key, int64_t n) {
     const HostTensor& t = need(key);
     check_shape(key, t, {n});
-    return (const float*)cached("f32:" + key, [&]() { return upload("f32:" + key, t.data.data(), t.data.size() * 4); });
+    return (const float*)cached("f32:" + key, [&]() { (void)data_of(key); return upload("f32:" + key, t.data.data(), t.data.size() * 4); });
   }
   // sinusoidal temporal PE table [max_len][C]  (motion_module.py:225-239), regenerated (non-persistent buffer)
   const float* pe_table(int C, int max_len) {
@@ -352,7 +366,11 @@ struct nr_net {
     b->arena = &arena; b->bytes = bytes; b->off = arena.alloc(bytes); b->keep = keep_all;
     return b;
   }
-  void emit(std::function<void(hipStream_t)> fn) { if (!dry) ops.push_back(std::move(fn)); }
+  void emit(std::function<void(hipStream_t)> fn, int kind = NR_PROF_OTHER, double flops = 0, double bytes = 0) {
+    if (dry) return;
+    ops.push_back(std::move(fn));
+    op_meta.push_back(OpMeta{kind, flops, bytes});
+  }
   void tap(const std::string& name, const Act& a) {
     if (!dry && keep_all) taps.push_back(Tap{name, a.ptr, a.rows(), a.C, a.ld});
   }
@@ -391,7 +409,11 @@ struct nr_net {
       p.res = o.res->ptr; p.ldr = o.res->ld;
     }
     p.out = out.ptr; p.ldo = out.ld;
-    emit([p](hipStream_t s) { LAUNCH_OK(nr_launch_igemm(&p, s)); });
+    {
+      const double in_elems = (double)x0.rows() * (p.c0 + p.c1);   // every input element is needed at least once
+      const double bytes = 2.0 * (in_elems + (double)p.N * p.K + (double)p.M * outC + (o.res ? (double)p.M * outC : 0.0));
+      emit([p](hipStream_t s) { LAUNCH_OK(nr_launch_igemm(&p, s)); }, NR_PROF_IGEMM, 2.0 * p.M * (double)p.N * p.K, bytes);
+    }
     return out;
   }
   Act linear(const Act& x, const bf16* w, int N, const GemmOpt& o) { return conv(x, nullptr, w, N, 1, 1, 0, o); }
@@ -410,7 +432,8 @@ struct nr_net {
     p.partial = at<float>(ws->off);
     Act out = new_act(x0.nimg, x0.H, x0.W, C);
     p.out = out.ptr; p.ldo = out.ld;
-    emit([p](hipStream_t s) { NrGnParams q = p; LAUNCH_OK(nr_launch_groupnorm(&q, s)); });
+    emit([p](hipStream_t s) { NrGnParams q = p; LAUNCH_OK(nr_launch_groupnorm(&q, s)); }, NR_PROF_GROUPNORM,
+         8.0 * (double)x0.rows() * C, 2.0 * 2.0 * (double)x0.rows() * C);
     return out;
   }
 
@@ -420,7 +443,8 @@ struct nr_net {
     Act out = new_act(x.nimg, x.H, x.W, x.C);
     const bf16* xp = x.ptr; bf16* op = out.ptr;
     const int ldx = x.ld, ldo = out.ld, M = (int)x.rows(), C = x.C, hw = x.H * x.W;
-    emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_layernorm(xp, ldx, op, ldo, M, C, g, b, 1e-5f, pe, hw, pe_F, s)); });
+    emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_layernorm(xp, ldx, op, ldo, M, C, g, b, 1e-5f, pe, hw, pe_F, s)); },
+         NR_PROF_LAYERNORM, 8.0 * (double)M * C, 2.0 * 2.0 * (double)M * C);
     return out;
   }
 
@@ -452,7 +476,12 @@ struct nr_net {
       p.kv_inner = hw; p.kv_outer = p.q_outer; p.kv_inner_stride = q.ld; p.kv_seq = p.q_seq; p.kv_div = 1;
       p.o_outer = (long long)F * hw * out.ld; p.o_inner_stride = out.ld; p.o_seq = (long long)hw * out.ld;
     }
-    emit([p](hipStream_t s) { LAUNCH_OK(nr_launch_attention(&p, s)); });
+    {
+      const double flops = 4.0 * (double)p.nbatch * p.heads * (double)p.Lq * p.Lk * p.d;
+      const double kvrows = mode == 1 ? (double)(p.nbatch / p.kv_div) * p.Lk : (double)p.nbatch * p.Lk;
+      const double bytes = 2.0 * ((double)p.nbatch * p.Lq * C * 2.0 + kvrows * C * 2.0);   // q + out + k + v
+      emit([p](hipStream_t s) { LAUNCH_OK(nr_launch_attention(&p, s)); }, NR_PROF_ATTENTION, flops, bytes);
+    }
     return out;
   }
 
@@ -602,7 +631,7 @@ struct nr_net {
     const int C0 = cfg.block_out_channels[0];
     const int temb_dim = 4 * C0;
     const int nimg = B2 * F;
-    ops.clear(); taps.clear(); arena.reset();
+    ops.clear(); op_meta.clear(); taps.clear(); arena.reset();
     temb_slots.clear();
     enumerate_resnets(temb_slots);
     temb_total = 0;
@@ -631,12 +660,12 @@ struct nr_net {
       const bf16* wp = (const bf16*)cached(wname, [&]() {
         std::vector<uint16_t> h((size_t)temb_total * temb_dim);
         size_t o = 0;
-        for (auto& k : wk) { const HostTensor& t = need(k); for (float f : t.data) h[o++] = f2bf_host(f); }
+        for (auto& k : wk) { const HostTensor& t = data_of(k); for (float f : t.data) h[o++] = f2bf_host(f); }
         return upload(wname, h.data(), h.size() * 2);
       });
       const float* bp = (const float*)cached(bname, [&]() {
         std::vector<float> h; h.reserve(temb_total);
-        for (auto& k : bk) { const HostTensor& t = need(k); h.insert(h.end(), t.data.begin(), t.data.end()); }
+        for (auto& k : bk) { const HostTensor& t = data_of(k); h.insert(h.end(), t.data.begin(), t.data.end()); }
         return upload(bname, h.data(), h.size() * 4);
       });
       float* td = t_dev; float* ta = temb_all;
@@ -742,7 +771,7 @@ struct nr_net {
           q.out = (bf16*)(is_mid ? io.out_mid : io.out_down[i]);
           q.out_scale = io.scale;
           LAUNCH_OK(nr_launch_igemm(&q, s));
-        });
+        }, NR_PROF_IGEMM, 2.0 * p.M * (double)p.N * p.K, 2.0 * (2.0 * p.M * (double)p.N + (double)p.N * p.K));
       }
       return;
     }
@@ -868,6 +897,27 @@ struct nr_net {
 // ================================================================================================
 // C ABI
 // ================================================================================================
+static void profile_last(nr_net* h, hipStream_t s, nr_profile* out) {
+  std::memset(out, 0, sizeof(*out));
+  const size_t n = h->ops.size();
+  std::vector<hipEvent_t> ev(n + 1);
+  for (auto& e : ev) HIP_OK(hipEventCreate(&e));
+  HIP_OK(hipStreamSynchronize(s));
+  HIP_OK(hipEventRecord(ev[0], s));
+  for (size_t i = 0; i < n; ++i) {
+    h->ops[i](s);
+    HIP_OK(hipEventRecord(ev[i + 1], s));
+  }
+  HIP_OK(hipStreamSynchronize(s));
+  for (size_t i = 0; i < n; ++i) {
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+    const auto& m = h->op_meta[i];
+    out->ms[m.kind] += ms; out->flops[m.kind] += m.flops; out->bytes[m.kind] += m.bytes; out->launches[m.kind] += 1;
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+}
+
 #define NR_TRY try {
 #define NR_CATCH                                                         \
   }                                                                      \
@@ -925,6 +975,14 @@ extern "C" nr_status nr_net_plan(nr_net* h, int32_t batch, int32_t frames, int32
   NR_TRY
   if (!h) throw NrError(NR_ERR_ARG, "null handle");
   h->plan(batch, frames, lat_h, lat_w, ctx_len);
+  NR_CATCH
+}
+
+extern "C" nr_status nr_net_release_host_weights(nr_net* h) {
+  NR_TRY
+  if (!h) throw NrError(NR_ERR_ARG, "null handle");
+  if (!h->planned) throw NrError(NR_ERR_STATE, "plan first: the converted device copies must exist");
+  for (auto& kv : h->host) { std::vector<float>().swap(kv.second.data); }
   NR_CATCH
 }
 
@@ -1010,6 +1068,14 @@ extern "C" nr_status nr_cfg_ddim_step(nr_stream stream, const float* eps_dev, co
   LAUNCH_OK(nr_launch_cfg_ddim_step(eps_dev, x_dev, x_out_dev, n, guidance_scale, do_cfg, (float)std::sqrt(a_t),
                                     (float)std::sqrt(1.0 - a_t), (float)std::sqrt(a_prev), (float)std::sqrt(1.0 - a_prev),
                                     (hipStream_t)stream));
+  NR_CATCH
+}
+
+extern "C" nr_status nr_net_profile_last(nr_net* h, nr_stream stream, nr_profile* out) {
+  NR_TRY
+  if (!h || !out) throw NrError(NR_ERR_ARG, "null argument");
+  if (!h->planned || !h->io.ctx) throw NrError(NR_ERR_STATE, "run a forward first");
+  profile_last(h, (hipStream_t)stream, out);
   NR_CATCH
 }
 

@@ -343,11 +343,19 @@ class _NativeNet:
         key = (batch, frames, h, w, ctx_len)
         if key != self._plan_key:
             _lib.check(_lib.load().nr_net_plan(self._handle(), batch, frames, h, w, ctx_len))
+            _lib.check(_lib.load().nr_net_release_host_weights(self._handle()))
             self._plan_key = key
             self._on_plan()
 
     def _on_plan(self):
         pass
+
+    def profile_last(self):
+        """Per-kernel-class time / algorithmic work of the most recent forward (HIP events per launch)."""
+        prof = _lib.NrProfile()
+        _lib.check(_lib.load().nr_net_profile_last(self._handle(), torch.cuda.current_stream().cuda_stream, C.byref(prof)))
+        return {name: dict(ms=prof.ms[i], flops=prof.flops[i], bytes=prof.bytes[i], launches=prof.launches[i])
+                for i, name in enumerate(_lib.NR_PROF_NAMES)}
 
     def workspace_bytes(self):
         return int(_lib.load().nr_net_workspace_bytes(self._handle()))

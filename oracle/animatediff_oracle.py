@@ -259,7 +259,11 @@ def _down_blocks(sd: SD, cfg: OracleConfig, x, emb, ctx, taps=None):
 def _mid_block(sd: SD, cfg: OracleConfig, x, emb, ctx, taps=None):
     """UNetMidBlock3DCrossAttn.forward — unet_blocks.py:271-278."""
     x = resnet_block3d(sd, "mid_block.resnets.0", x, emb, cfg.norm_num_groups, cfg.norm_eps)
+    if taps is not None:
+        taps["mid_block.resnets.0"] = x
     x = transformer3d(sd, "mid_block.attentions.0", x, ctx, cfg.attention_head_dim, cfg.norm_num_groups)
+    if taps is not None:
+        taps["mid_block.attentions.0"] = x
     if cfg.use_motion_module and cfg.motion_module_mid_block:
         x = temporal_transformer3d(sd, "mid_block.motion_modules.0", x, cfg.motion_num_heads, cfg.norm_num_groups,
                                    cfg.motion_attention_blocks, cfg.motion_pe_max_len)
