@@ -17,6 +17,8 @@
 #include "../../include/neurons_amd.h"
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -177,7 +179,7 @@ struct nr_net {
   char* arena_base = nullptr;
   size_t arena_bytes = 0;
   std::vector<std::function<void(hipStream_t)>> ops;
-  struct OpMeta { int kind; double flops, bytes; };
+  struct OpMeta { int kind; double flops, bytes; std::string desc; };
   std::vector<OpMeta> op_meta;   // parallel to ops: kernel class + algorithmic work (for roofline reporting)
   std::vector<Tap> taps;
   bool keep_all = false;
@@ -366,10 +368,11 @@ struct nr_net {
     b->arena = &arena; b->bytes = bytes; b->off = arena.alloc(bytes); b->keep = keep_all;
     return b;
   }
-  void emit(std::function<void(hipStream_t)> fn, int kind = NR_PROF_OTHER, double flops = 0, double bytes = 0) {
+  void emit(std::function<void(hipStream_t)> fn, int kind = NR_PROF_OTHER, double flops = 0, double bytes = 0,
+            const std::string& desc = std::string()) {
     if (dry) return;
     ops.push_back(std::move(fn));
-    op_meta.push_back(OpMeta{kind, flops, bytes});
+    op_meta.push_back(OpMeta{kind, flops, bytes, desc});
   }
   void tap(const std::string& name, const Act& a) {
     if (!dry && keep_all) taps.push_back(Tap{name, a.ptr, a.rows(), a.C, a.ld});
@@ -412,7 +415,9 @@ struct nr_net {
     {
       const double in_elems = (double)x0.rows() * (p.c0 + p.c1);   // every input element is needed at least once
       const double bytes = 2.0 * (in_elems + (double)p.N * p.K + (double)p.M * outC + (o.res ? (double)p.M * outC : 0.0));
-      emit([p](hipStream_t s) { LAUNCH_OK(nr_launch_igemm(&p, s)); }, NR_PROF_IGEMM, 2.0 * p.M * (double)p.N * p.K, bytes);
+      char d[160];
+      snprintf(d, sizeof(d), "igemm ks=%d s=%d ups=%d M=%d N=%d K=%d geglu=%d res=%d", ksize, stride, ups, p.M, p.N, p.K, p.geglu, o.res ? 1 : 0);
+      emit([p](hipStream_t s) { LAUNCH_OK(nr_launch_igemm(&p, s)); }, NR_PROF_IGEMM, 2.0 * p.M * (double)p.N * p.K, bytes, d);
     }
     return out;
   }
@@ -433,7 +438,8 @@ struct nr_net {
     Act out = new_act(x0.nimg, x0.H, x0.W, C);
     p.out = out.ptr; p.ldo = out.ld;
     emit([p](hipStream_t s) { NrGnParams q = p; LAUNCH_OK(nr_launch_groupnorm(&q, s)); }, NR_PROF_GROUPNORM,
-         8.0 * (double)x0.rows() * C, 2.0 * 2.0 * (double)x0.rows() * C);
+         8.0 * (double)x0.rows() * C, 2.0 * 2.0 * (double)x0.rows() * C,
+         "groupnorm nimg=" + std::to_string(x0.nimg) + " hw=" + std::to_string(x0.H * x0.W) + " C=" + std::to_string(C));
     return out;
   }
 
@@ -444,7 +450,8 @@ struct nr_net {
     const bf16* xp = x.ptr; bf16* op = out.ptr;
     const int ldx = x.ld, ldo = out.ld, M = (int)x.rows(), C = x.C, hw = x.H * x.W;
     emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_layernorm(xp, ldx, op, ldo, M, C, g, b, 1e-5f, pe, hw, pe_F, s)); },
-         NR_PROF_LAYERNORM, 8.0 * (double)M * C, 2.0 * 2.0 * (double)M * C);
+         NR_PROF_LAYERNORM, 8.0 * (double)M * C, 2.0 * 2.0 * (double)M * C,
+         "layernorm M=" + std::to_string(M) + " C=" + std::to_string(C));
     return out;
   }
 
@@ -480,7 +487,9 @@ struct nr_net {
       const double flops = 4.0 * (double)p.nbatch * p.heads * (double)p.Lq * p.Lk * p.d;
       const double kvrows = mode == 1 ? (double)(p.nbatch / p.kv_div) * p.Lk : (double)p.nbatch * p.Lk;
       const double bytes = 2.0 * ((double)p.nbatch * p.Lq * C * 2.0 + kvrows * C * 2.0);   // q + out + k + v
-      emit([p](hipStream_t s) { LAUNCH_OK(nr_launch_attention(&p, s)); }, NR_PROF_ATTENTION, flops, bytes);
+      char d[160];
+      snprintf(d, sizeof(d), "attention mode=%d nbatch=%d heads=%d d=%d Lq=%d Lk=%d", mode, p.nbatch, p.heads, p.d, p.Lq, p.Lk);
+      emit([p](hipStream_t s) { LAUNCH_OK(nr_launch_attention(&p, s)); }, NR_PROF_ATTENTION, flops, bytes, d);
     }
     return out;
   }
@@ -897,7 +906,7 @@ struct nr_net {
 // ================================================================================================
 // C ABI
 // ================================================================================================
-static void profile_last(nr_net* h, hipStream_t s, nr_profile* out) {
+static void profile_last(nr_net* h, hipStream_t s, nr_profile* out, const char* csv_path = nullptr) {
   std::memset(out, 0, sizeof(*out));
   const size_t n = h->ops.size();
   std::vector<hipEvent_t> ev(n + 1);
@@ -909,12 +918,16 @@ static void profile_last(nr_net* h, hipStream_t s, nr_profile* out) {
     HIP_OK(hipEventRecord(ev[i + 1], s));
   }
   HIP_OK(hipStreamSynchronize(s));
+  FILE* f = csv_path ? fopen(csv_path, "w") : nullptr;
+  if (f) fprintf(f, "idx,kind,ms,gflop,mbytes,desc\n");
   for (size_t i = 0; i < n; ++i) {
     float ms = 0.f;
     HIP_OK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
     const auto& m = h->op_meta[i];
     out->ms[m.kind] += ms; out->flops[m.kind] += m.flops; out->bytes[m.kind] += m.bytes; out->launches[m.kind] += 1;
+    if (f) fprintf(f, "%zu,%d,%.4f,%.3f,%.3f,%s\n", i, m.kind, ms, m.flops / 1e9, m.bytes / 1e6, m.desc.c_str());
   }
+  if (f) fclose(f);
   for (auto& e : ev) (void)hipEventDestroy(e);
 }
 
@@ -1075,7 +1088,7 @@ extern "C" nr_status nr_net_profile_last(nr_net* h, nr_stream stream, nr_profile
   NR_TRY
   if (!h || !out) throw NrError(NR_ERR_ARG, "null argument");
   if (!h->planned || !h->io.ctx) throw NrError(NR_ERR_STATE, "run a forward first");
-  profile_last(h, (hipStream_t)stream, out);
+  profile_last(h, (hipStream_t)stream, out, getenv("NR_PROFILE_CSV"));
   NR_CATCH
 }
 
