@@ -28,7 +28,8 @@
 #include <vector>
 
 extern "C" {
-int nr_launch_igemm(const NrGemmParams* pp, hipStream_t stream);
+int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStream_t stream);
+size_t nr_igemm_workspace_bytes(const NrGemmParams* pp);
 int nr_gn_workspace_floats(int nimg, int hw, int groups, int* pix_per_blk_out, int* nchunk_out);
 int nr_launch_groupnorm(NrGnParams* pp, hipStream_t stream);
 int nr_launch_layernorm(const bf16* x, int ldx, bf16* out, int ldo, int M, int C, const float* gamma, const float* beta,
@@ -417,7 +418,12 @@ struct nr_net {
       const double bytes = 2.0 * (in_elems + (double)p.N * p.K + (double)p.M * outC + (o.res ? (double)p.M * outC : 0.0));
       char d[160];
       snprintf(d, sizeof(d), "igemm ks=%d s=%d ups=%d M=%d N=%d K=%d geglu=%d res=%d", ksize, stride, ups, p.M, p.N, p.K, p.geglu, o.res ? 1 : 0);
-      emit([p](hipStream_t s) { LAUNCH_OK(nr_launch_igemm(&p, s)); }, NR_PROF_IGEMM, 2.0 * p.M * (double)p.N * p.K, bytes, d);
+      // split-K slabs (small-M / huge-K layers): scratch with the lifetime of this launch
+      const size_t wsb = nr_igemm_workspace_bytes(&p);
+      float* ws = nullptr;
+      std::shared_ptr<Buf> wsbuf;
+      if (wsb) { wsbuf = new_tmp(wsb); ws = at<float>(wsbuf->off); }
+      emit([p, ws](hipStream_t s) { LAUNCH_OK(nr_launch_igemm(&p, ws, s)); }, NR_PROF_IGEMM, 2.0 * p.M * (double)p.N * p.K, bytes, d);
     }
     return out;
   }
@@ -775,11 +781,15 @@ struct nr_net {
         p.ksize = 1; p.stride = 1; p.w = w_linear(key + ".weight", src.C, src.C);
         p.M = (int)src.rows(); p.N = src.C; p.K = src.C; p.bias = w_f32(key + ".bias", src.C);
         p.ldo = src.C; p.out_scale = 1.f;
-        emit([this, p, i, is_mid](hipStream_t s) {
+        const size_t wsb = nr_igemm_workspace_bytes(&p);
+        float* ws = nullptr;
+        std::shared_ptr<Buf> wsbuf;
+        if (wsb) { wsbuf = new_tmp(wsb); ws = at<float>(wsbuf->off); }
+        emit([this, p, i, is_mid, ws](hipStream_t s) {
           NrGemmParams q = p;
           q.out = (bf16*)(is_mid ? io.out_mid : io.out_down[i]);
           q.out_scale = io.scale;
-          LAUNCH_OK(nr_launch_igemm(&q, s));
+          LAUNCH_OK(nr_launch_igemm(&q, ws, s));
         }, NR_PROF_IGEMM, 2.0 * p.M * (double)p.N * p.K, 2.0 * (2.0 * p.M * (double)p.N + (double)p.N * p.K));
       }
       return;
@@ -1116,6 +1126,19 @@ extern "C" nr_status nr_net_read_tap(nr_net* h, int32_t i, float* host_out, int6
 }
 
 // ---- single-op entry points ---------------------------------------------------------------------
+static float* op_workspace(const NrGemmParams& p) {
+  static float* ws = nullptr;
+  static size_t cap = 0;
+  const size_t need = nr_igemm_workspace_bytes(&p);
+  if (need > cap) {
+    HIP_OK(hipDeviceSynchronize());
+    if (ws) (void)hipFree(ws);
+    HIP_OK(hipMalloc((void**)&ws, need));
+    cap = need;
+  }
+  return need ? ws : nullptr;
+}
+
 extern "C" nr_status nr_op_gemm(nr_stream stream, const void* a, int32_t lda, const void* w, const float* bias,
                                 const void* res, int32_t ldr, void* out, int32_t ldo, int32_t M, int32_t N, int32_t K,
                                 int32_t geglu) {
@@ -1125,7 +1148,7 @@ extern "C" nr_status nr_op_gemm(nr_stream stream, const void* a, int32_t lda, co
   p.a0 = (const bf16*)a; p.c0 = K; p.lda0 = lda; p.H = p.W = p.OH = p.OW = 1; p.ksize = 1; p.stride = 1;
   p.w = (const bf16*)w; p.M = M; p.N = N; p.K = K; p.bias = bias; p.res = (const bf16*)res; p.ldr = ldr;
   p.out = (bf16*)out; p.ldo = ldo; p.out_scale = 1.f; p.geglu = geglu; p.rowvec_div = 1;
-  LAUNCH_OK(nr_launch_igemm(&p, (hipStream_t)stream));
+  LAUNCH_OK(nr_launch_igemm(&p, op_workspace(p), (hipStream_t)stream));
   NR_CATCH
 }
 
@@ -1144,7 +1167,7 @@ extern "C" nr_status nr_op_conv3x3(nr_stream stream, const void* x0, int32_t c0,
   p.w = (const bf16*)w; p.M = nimg * OH * OW; p.N = Cout; p.K = 9 * (p.c0 + p.c1);
   p.bias = bias; p.rowvec = rowvec; p.rowvec_div = rowvec_div > 0 ? rowvec_div : 1; p.rowvec_ld = Cout;
   p.res = (const bf16*)res; p.ldr = Cout; p.out = (bf16*)out; p.ldo = Cout; p.out_scale = 1.f;
-  LAUNCH_OK(nr_launch_igemm(&p, (hipStream_t)stream));
+  LAUNCH_OK(nr_launch_igemm(&p, op_workspace(p), (hipStream_t)stream));
   NR_CATCH
 }
 

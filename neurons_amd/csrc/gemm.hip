@@ -8,106 +8,119 @@
 // with fused epilogues: +bias, +time-embedding row vector (resnet.py:193-194), *scale, +residual,
 // GEGLU gate (motion_module_new.py:516-518).
 //
-// Tiling: BMxBN block tile, BK=64, 256 threads = 2x2 waves, each wave (BM/2)x(BN/2) as 16x16 MFMA
-// tiles.  The MFMA is issued "transposed" (weights as the A operand, activations as B) so that a
-// lane's 4 accumulator registers are 4 consecutive output channels of one pixel -> 8-byte stores.
-// LDS tiles are [rows][64] bf16 (128-B rows) with the 16-B chunk index XOR-swizzled by (row&7)
-// so ds_read_b128 fragment reads are bank-conflict free.  Global->LDS is register staged and
-// software pipelined (loads for tile k+1 in flight while tile k is multiplied).
+// Structure (per 256-thread workgroup = 2x2 waves, BMxBN output tile, BK = 64):
+//   * global -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB = 8 tile rows per wave-instruction, no
+//     VGPR staging).  The im2col gather, the zero padding and the M/N tails are all expressed through the
+//     per-lane SOURCE address (invalid lanes read a 16-byte zero word), the LDS image stays lane-linear.
+//   * LDS image [rows][64] bf16 (128-B rows); the 16-B chunk index is XOR-swizzled with (row & 7) on the
+//     source side and on the ds_read_b128 side (same involution) -> conflict-free fragment reads.
+//   * two LDS buffers, ONE barrier per k-tile: tile k+1 streams in while tile k is multiplied.
+//   * the MFMA is issued "transposed" (weights = A operand, activations = B operand) so a lane's 4
+//     accumulator registers are 4 consecutive output channels of one pixel -> 8/16-byte epilogue accesses.
+//   * split-K for small-M / huge-K layers (the 4x4 and 8x8 levels: M = 512..2048, K up to 23 040):
+//     each slice writes an fp32 slab, a second kernel sums the slabs in fixed order (deterministic, no
+//     atomics) and applies the epilogue.
 #include "common.h"
 
 namespace {
 
+__device__ __attribute__((aligned(16))) const unsigned int nr_zero16[4] = {0u, 0u, 0u, 0u};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void igemm_bf16_kernel(NrGemmParams p) {
+__global__ __launch_bounds__(256) void igemm_bf16_kernel(NrGemmParams p, int splitk, float* partial) {
   constexpr int BK = 64;
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 16, NT = WN / 16;
-  constexpr int AI = BM / 32, BI = BN / 32;
-  __shared__ __attribute__((aligned(16))) bf16 smem[(BM + BN) * BK];
-  bf16* sA = smem;            // activations tile  [BM][64]
-  bf16* sB = smem + BM * BK;  // weights tile      [BN][64]
+  constexpr int GA = BM / 32, GB = BN / 32;          // 8-row groups per wave for the A / B tile
+  constexpr int TILE = (BM + BN) * BK;               // elements per LDS buffer
+  extern __shared__ __attribute__((aligned(16))) bf16 smem[];   // 2 * TILE elements (up to 72 KiB)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int ntn = (p.N + BN - 1) / BN;
-  const int bm = blockIdx.x / ntn, bn = blockIdx.x - bm * ntn;
+  const int ntm = (p.M + BM - 1) / BM;
+  int bid = blockIdx.x;
+  const int slice = bid / (ntn * ntm);
+  bid -= slice * ntn * ntm;
+  const int bm = bid / ntn, bn = bid - bm * ntn;
   const int m0 = bm * BM, n0 = bn * BN;
-  const int chunk = tid & 7;   // 16-byte chunk within the 128-byte k-tile row
-  const int lrow = tid >> 3;   // 0..31
+  const int lr = lane >> 3;                 // row within the 8-row group
+  const int lp = lane & 7;                  // physical 16-B chunk
+  const int lchunk = (lp ^ lr) << 3;        // logical chunk (elements) this lane must fetch
 
   const int Cin = p.c0 + p.c1;
 
-  // ---- per-thread A-row bookkeeping (rows lrow + 32*i of the block tile) ----
-  int a_pix[AI];  // ksize==1: linear pixel index; ksize==3: image index n
-  int a_oy[AI], a_ox[AI];
-  bool a_ok[AI];
+  // ---- per-lane A rows: group g = wave*GA + j, tile row = 8*g + lr ----
+  int a_pix[GA], a_oy[GA], a_ox[GA];
+  bool a_ok[GA];
 #pragma unroll
-  for (int i = 0; i < AI; ++i) {
-    const int m = m0 + lrow + 32 * i;
-    a_ok[i] = m < p.M;
-    const int mm = a_ok[i] ? m : 0;
+  for (int j = 0; j < GA; ++j) {
+    const int m = m0 + 8 * (wave * GA + j) + lr;
+    a_ok[j] = m < p.M;
+    const int mm = a_ok[j] ? m : 0;
     if (p.ksize == 1) {
-      a_pix[i] = mm; a_oy[i] = 0; a_ox[i] = 0;
+      a_pix[j] = mm; a_oy[j] = 0; a_ox[j] = 0;
     } else {
       const int ohw = p.OH * p.OW;
       const int n = mm / ohw;
       const int r = mm - n * ohw;
-      a_pix[i] = n; a_oy[i] = r / p.OW; a_ox[i] = r - a_oy[i] * p.OW;
+      a_pix[j] = n; a_oy[j] = r / p.OW; a_ox[j] = r - a_oy[j] * p.OW;
     }
   }
-  const bf16* wrow[BI];
-  bool b_ok[BI];
+  const bf16* wsrc[GB];
 #pragma unroll
-  for (int i = 0; i < BI; ++i) {
-    const int n = n0 + lrow + 32 * i;
-    b_ok[i] = n < p.N;
-    wrow[i] = p.w + (size_t)(b_ok[i] ? n : 0) * p.K + chunk * 8;
+  for (int j = 0; j < GB; ++j) {
+    const int n = n0 + 8 * (wave * GB + j) + lr;
+    wsrc[j] = n < p.N ? p.w + (size_t)n * p.K + lchunk : nullptr;
   }
+  const bf16* zsrc = (const bf16*)nr_zero16;
 
-  bf16x8 ra[AI], rb[BI];
-  const bf16x8 zero8 = bf16x8_zero();
+  const int nk_total = p.K / BK;
+  const int kt_begin = (int)(((long long)nk_total * slice) / splitk);
+  const int kt_end = (int)(((long long)nk_total * (slice + 1)) / splitk);
 
-  auto load_tiles = [&](int kt) {
+  auto stage = [&](int buf, int kt) {
+    bf16* sA = smem + buf * TILE;
+    bf16* sB = sA + BM * BK;
     const int kbase = kt * BK;
     int tap = 0, c = kbase;
     if (p.ksize == 3) { tap = kbase / Cin; c = kbase - tap * Cin; }
     const bf16* src; int ld;
     if (c < p.c0) { src = p.a0 + c; ld = p.lda0; } else { src = p.a1 + (c - p.c0); ld = p.lda1; }
+    src += lchunk;
     if (p.ksize == 1) {
 #pragma unroll
-      for (int i = 0; i < AI; ++i)
-        ra[i] = a_ok[i] ? *(const bf16x8*)(src + (size_t)a_pix[i] * ld + chunk * 8) : zero8;
+      for (int j = 0; j < GA; ++j) {
+        const bf16* s = a_ok[j] ? src + (size_t)a_pix[j] * ld : zsrc;
+        glds16(s, sA + (wave * GA + j) * 8 * BK);
+      }
     } else {
       const int ky = tap / 3, kx = tap - ky * 3;
-      // virtual (post-upsample) input extent
       const int VH = p.ups ? p.H * 2 : p.H, VW = p.ups ? p.W * 2 : p.W;
 #pragma unroll
-      for (int i = 0; i < AI; ++i) {
-        int iy = a_oy[i] * p.stride + ky - 1;
-        int ix = a_ox[i] * p.stride + kx - 1;
-        const bool ok = a_ok[i] && iy >= 0 && iy < VH && ix >= 0 && ix < VW;
+      for (int j = 0; j < GA; ++j) {
+        int iy = a_oy[j] * p.stride + ky - 1;
+        int ix = a_ox[j] * p.stride + kx - 1;
+        const bool ok = a_ok[j] && iy >= 0 && iy < VH && ix >= 0 && ix < VW;
         if (p.ups) { iy >>= 1; ix >>= 1; }
-        const size_t pix = ((size_t)a_pix[i] * p.H + iy) * p.W + ix;
-        ra[i] = ok ? *(const bf16x8*)(src + pix * ld + chunk * 8) : zero8;
+        const size_t pix = ((size_t)a_pix[j] * p.H + iy) * p.W + ix;
+        const bf16* s = ok ? src + pix * ld : zsrc;
+        glds16(s, sA + (wave * GA + j) * 8 * BK);
       }
     }
 #pragma unroll
-    for (int i = 0; i < BI; ++i) rb[i] = b_ok[i] ? *(const bf16x8*)(wrow[i] + kbase) : zero8;
-  };
-
-  auto store_tiles = [&]() {
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      const int row = lrow + 32 * i;
-      *(bf16x8*)(sA + row * BK + ((chunk ^ (row & 7)) << 3)) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      const int row = lrow + 32 * i;
-      *(bf16x8*)(sB + row * BK + ((chunk ^ (row & 7)) << 3)) = rb[i];
+    for (int j = 0; j < GB; ++j) {
+      const bf16* s = wsrc[j] ? wsrc[j] + kbase : zsrc;
+      glds16(s, sB + (wave * GB + j) * 8 * BK);
     }
   };
 
@@ -117,15 +130,16 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(NrGemmParams p) {
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / BK;
   const int fr = lane & 15, fg = lane >> 4;
 
-  load_tiles(0);
-  for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();
-    store_tiles();
-    __syncthreads();
-    if (kt + 1 < nk) load_tiles(kt + 1);
+  if (kt_begin < kt_end) stage(0, kt_begin);
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int cur = (kt - kt_begin) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my LDS-DMA pieces of tile kt have landed
+    __syncthreads();                                    // everyone's have; everyone left buffer cur^1
+    if (kt + 1 < kt_end) stage(cur ^ 1, kt + 1);        // streams in under the MFMAs below
+    const bf16* sA = smem + cur * TILE;
+    const bf16* sB = sA + BM * BK;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 wf[NT], xf[MT];
@@ -149,6 +163,21 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(NrGemmParams p) {
   }
 
   // ---- epilogue: lane holds out[m = ..+fr][n = ..+4*fg + r], r = 0..3 ----
+  if (partial) {
+    float* slab = partial + (size_t)slice * p.M * p.N;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int m = m0 + wm * WM + j * 16 + fr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int n = n0 + wn * WN + i * 16 + 4 * fg;
+        if (n >= p.N) continue;
+        *(f32x4*)(slab + (size_t)m * p.N + n) = acc[i][j];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
     const int m = m0 + wm * WM + j * 16 + fr;
@@ -174,45 +203,120 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(NrGemmParams p) {
         *(bf16x4*)(p.out + (size_t)m * p.ldo + n) = o;
       }
     } else {
+      if constexpr (NT % 2 == 0) {
 #pragma unroll
-      for (int i = 0; i < NT; i += 2) {
-        const int nv = n0 + wn * WN + i * 16 + 4 * fg;  // value columns (permuted W row index)
-        if (nv >= p.N) continue;
-        const int ng = nv + 16;                          // matching gate columns
-        f32x4 v = acc[i][j], g = acc[i + 1][j];
-        if (p.bias) {
-          v += *(const f32x4*)(p.bias + nv);
-          g += *(const f32x4*)(p.bias + ng);
+        for (int i = 0; i < NT; i += 2) {
+          const int nv = n0 + wn * WN + i * 16 + 4 * fg;  // value columns (permuted W row index)
+          if (nv >= p.N) continue;
+          const int ng = nv + 16;                          // matching gate columns
+          f32x4 v = acc[i][j], g = acc[i + 1][j];
+          if (p.bias) {
+            v += *(const f32x4*)(p.bias + nv);
+            g += *(const f32x4*)(p.bias + ng);
+          }
+          const int oc = ((n0 + wn * WN + i * 16) >> 1) + 4 * fg;
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (bf16)(v[e] * gelu_erf_f(g[e]));
+          *(bf16x4*)(p.out + (size_t)m * p.ldo + oc) = o;
         }
-        const int oc = ((n0 + wn * WN + i * 16) >> 1) + 4 * fg;
-        bf16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (bf16)(v[e] * gelu_erf_f(g[e]));
-        *(bf16x4*)(p.out + (size_t)m * p.ldo + oc) = o;
       }
     }
   }
 }
 
+// out[m][n] = epilogue( sum_s partial[s][m][n] ), 4 consecutive n per thread
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(NrGemmParams p, int splitk, const float* __restrict__ partial) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = p.N >> 2;
+  if (idx >= (long long)p.M * n4) return;
+  const int m = (int)(idx / n4);
+  const int n = (int)(idx - (long long)m * n4) << 2;
+  const size_t slab = (size_t)p.M * p.N;
+  const float* src = partial + (size_t)m * p.N + n;
+  f32x4 v = *(const f32x4*)src;
+  for (int s = 1; s < splitk; ++s) v += *(const f32x4*)(src + s * slab);
+  if (p.bias) v += *(const f32x4*)(p.bias + n);
+  if (p.rowvec) v += *(const f32x4*)(p.rowvec + (size_t)(m / p.rowvec_div) * p.rowvec_ld + n);
+  v *= p.out_scale;
+  if (p.res) {
+    const bf16x4 r = *(const bf16x4*)(p.res + (size_t)m * p.ldr + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+  }
+  bf16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+  *(bf16x4*)(p.out + (size_t)m * p.ldo + n) = o;
+}
+
+struct Plan { int bm, bn, splitk; };
+
+Plan choose_plan(const NrGemmParams& p) {
+  auto nblk = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  const int nk = p.K / 64;
+  Plan pl;
+  // widths on the path are multiples of 320 (N in {320, 960, 1920, ...}: 160 | N) or of 128
+  if (!p.geglu && p.N % 160 == 0 && p.N % 128 != 0 && nblk(128, 160) >= 256) { pl.bm = 128; pl.bn = 160; }
+  else if (p.N % 128 == 0 && nblk(128, 128) >= 256) { pl.bm = 128; pl.bn = 128; }
+  else if (nblk(128, 64) >= 512) { pl.bm = 128; pl.bn = 64; }
+  else { pl.bm = 64; pl.bn = 64; }
+  pl.splitk = 1;
+  if (!p.geglu) {
+    // small-M layers: prefer big tiles + split-K so that the weight stream is spread over the whole chip
+    if (nblk(pl.bm, pl.bn) < 384 && nk >= 8) {
+      if (p.N % 128 == 0 && p.M >= 256) { pl.bm = 128; pl.bn = 128; }
+      const long long b = nblk(pl.bm, pl.bn);
+      int s = (int)((768 + b - 1) / b);
+      if (s > nk / 4) s = nk / 4;
+      if (s > 32) s = 32;
+      if (s < 1) s = 1;
+      pl.splitk = s;
+    }
+  }
+  return pl;
+}
+
 }  // namespace
 
-// Host launcher.  Returns 0 on success, nonzero on unsupported shape.
-extern "C" int nr_launch_igemm(const NrGemmParams* pp, hipStream_t stream) {
+// fp32 scratch (bytes) a launch of this shape needs for split-K slabs (0 if none)
+extern "C" size_t nr_igemm_workspace_bytes(const NrGemmParams* pp) {
+  const Plan pl = choose_plan(*pp);
+  return pl.splitk > 1 ? (size_t)pl.splitk * pp->M * pp->N * sizeof(float) : 0;
+}
+
+// Host launcher.  Returns 0 on success, nonzero on unsupported shape.  `workspace` must hold
+// nr_igemm_workspace_bytes() bytes when that is nonzero.
+extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStream_t stream) {
   const NrGemmParams& p = *pp;
   const int Cin = p.c0 + p.c1;
   if (p.K % 64 != 0 || Cin % 64 != 0 || p.N % 32 != 0) return 1;
   if (p.a1 && (p.c0 % 64 != 0)) return 2;
   if (p.K != p.ksize * p.ksize * Cin) return 3;
   if (p.ksize != 1 && p.ksize != 3) return 4;
-  if (p.geglu && (p.N % 32 != 0)) return 5;
-  auto nblk = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
-  // pick the largest tile that still yields >= 2 blocks per CU; else the smallest tile
-  if (nblk(128, 128) >= 512 && p.N % 128 == 0) {
-    hipLaunchKernelGGL((igemm_bf16_kernel<128, 128>), dim3((unsigned)nblk(128, 128)), dim3(256), 0, stream, p);
-  } else if (nblk(128, 64) >= 512) {
-    hipLaunchKernelGGL((igemm_bf16_kernel<128, 64>), dim3((unsigned)nblk(128, 64)), dim3(256), 0, stream, p);
-  } else {
-    hipLaunchKernelGGL((igemm_bf16_kernel<64, 64>), dim3((unsigned)nblk(64, 64)), dim3(256), 0, stream, p);
+  const Plan pl = choose_plan(p);
+  if (pl.splitk > 1 && !workspace) return 6;
+  float* partial = pl.splitk > 1 ? workspace : nullptr;
+  const unsigned grid = (unsigned)(((p.M + pl.bm - 1) / pl.bm) * ((p.N + pl.bn - 1) / pl.bn) * pl.splitk);
+  const size_t shm = (size_t)2 * (pl.bm + pl.bn) * 64 * sizeof(bf16);
+  static bool attr_set = false;
+  if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (gfx950 has 160 KiB per CU)
+    (void)hipFuncSetAttribute((const void*)igemm_bf16_kernel<128, 160>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 160) * 64 * 2);
+    (void)hipFuncSetAttribute((const void*)igemm_bf16_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * 64 * 2);
+    attr_set = true;
+  }
+  if (pl.bm == 128 && pl.bn == 160)
+    hipLaunchKernelGGL((igemm_bf16_kernel<128, 160>), dim3(grid), dim3(256), shm, stream, p, pl.splitk, partial);
+  else if (pl.bm == 128 && pl.bn == 128)
+    hipLaunchKernelGGL((igemm_bf16_kernel<128, 128>), dim3(grid), dim3(256), shm, stream, p, pl.splitk, partial);
+  else if (pl.bm == 128 && pl.bn == 64)
+    hipLaunchKernelGGL((igemm_bf16_kernel<128, 64>), dim3(grid), dim3(256), shm, stream, p, pl.splitk, partial);
+  else
+    hipLaunchKernelGGL((igemm_bf16_kernel<64, 64>), dim3(grid), dim3(256), shm, stream, p, pl.splitk, partial);
+  if (pl.splitk > 1) {
+    const long long total = (long long)p.M * (p.N / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p, pl.splitk,
+                       (const float*)partial);
   }
   return 0;
 }

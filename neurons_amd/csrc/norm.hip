@@ -119,24 +119,28 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(NrGnParams p) {
   }
 }
 
-// LayerNorm over the last dim C (C % 8 == 0, C <= 64*8*MAXV); one wave per row; two-pass in registers.
+// LayerNorm over the last dim C (C % 8 == 0).  TPR threads cooperate on one row (TPR in {8,16,32,64}, each
+// thread holds <= MAXV 16-byte chunks), 256/TPR rows per block: every lane is busy and has 2-3 loads in
+// flight even at C = 320 (640-byte rows).  Two-pass statistics in registers (mean, then centred variance).
 // pe: optional [pe_len][C] fp32 table added after the affine; frame index = (row / pe_hw) % pe_F.
-template <int MAXV>
+template <int TPR, int MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__ x, int ldx, bf16* __restrict__ out,
                                                         int ldo, int M, int C, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
                                                         const float* __restrict__ pe, int pe_hw, int pe_F) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  constexpr int RPB = 256 / TPR;
+  const int sub = threadIdx.x % TPR;
+  const int row = blockIdx.x * RPB + threadIdx.x / TPR;
+  const bool rok = row < M;
+  const int rowc = rok ? row : M - 1;
   const int CP = C >> 3;
   float v[MAXV][8];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int cc = lane + 64 * i;
+    const int cc = sub + TPR * i;
     if (cc < CP) {
-      const bf16x8 t = *(const bf16x8*)(x + (size_t)row * ldx + cc * 8);
+      const bf16x8 t = *(const bf16x8*)(x + (size_t)rowc * ldx + cc * 8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) { v[i][e] = (float)t[e]; s += v[i][e]; }
     } else {
@@ -144,35 +148,54 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__
       for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
     }
   }
-  s = wave_sum(s);
+#pragma unroll
+  for (int o = TPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   const float mean = s / (float)C;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int cc = lane + 64 * i;
+    const int cc = sub + TPR * i;
     if (cc < CP) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
     }
   }
-  q = wave_sum(q);
+#pragma unroll
+  for (int o = TPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
   const float rstd = rsqrtf(q / (float)C + eps);
+  if (!rok) return;
   const float* perow = pe ? pe + (size_t)((row / pe_hw) % pe_F) * C : nullptr;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int cc = lane + 64 * i;
+    const int cc = sub + TPR * i;
     if (cc < CP) {
+      const f32x4 g0 = *(const f32x4*)(gamma + cc * 8), g1 = *(const f32x4*)(gamma + cc * 8 + 4);
+      const f32x4 b0 = *(const f32x4*)(beta + cc * 8), b1 = *(const f32x4*)(beta + cc * 8 + 4);
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        f[e] = (v[i][e] - mean) * rstd * g0[e] + b0[e];
+        f[4 + e] = (v[i][4 + e] - mean) * rstd * g1[e] + b1[e];
+      }
+      if (perow) {
+        const f32x4 p0 = *(const f32x4*)(perow + cc * 8), p1 = *(const f32x4*)(perow + cc * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { f[e] += p0[e]; f[4 + e] += p1[e]; }
+      }
       bf16x8 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int c = cc * 8 + e;
-        float f = (v[i][e] - mean) * rstd * gamma[c] + beta[c];
-        if (perow) f += perow[c];
-        o[e] = (bf16)f;
-      }
+      for (int e = 0; e < 8; ++e) o[e] = (bf16)f[e];
       *(bf16x8*)(out + (size_t)row * ldo + cc * 8) = o;
     }
   }
+}
+
+template <int TPR, int MAXV>
+void launch_ln(const bf16* x, int ldx, bf16* out, int ldo, int M, int C, const float* gamma, const float* beta, float eps,
+               const float* pe, int pe_hw, int pe_F, hipStream_t stream) {
+  constexpr int RPB = 256 / TPR;
+  hipLaunchKernelGGL((layernorm_kernel<TPR, MAXV>), dim3((M + RPB - 1) / RPB), dim3(256), 0, stream, x, ldx, out, ldo, M, C,
+                     gamma, beta, eps, pe, pe_hw, pe_F);
 }
 
 }  // namespace
@@ -208,16 +231,17 @@ extern "C" int nr_launch_groupnorm(NrGnParams* pp, hipStream_t stream) {
 extern "C" int nr_launch_layernorm(const bf16* x, int ldx, bf16* out, int ldo, int M, int C, const float* gamma,
                                    const float* beta, float eps, const float* pe, int pe_hw, int pe_F,
                                    hipStream_t stream) {
-  if (C % 8 != 0) return 1;
+  if (C % 8 != 0 || M <= 0) return 1;
   const int CP = C / 8;
-  dim3 grid((M + 3) / 4);
-  if (CP <= 64)
-    hipLaunchKernelGGL((layernorm_kernel<1>), grid, dim3(256), 0, stream, x, ldx, out, ldo, M, C, gamma, beta, eps, pe, pe_hw, pe_F);
-  else if (CP <= 128)
-    hipLaunchKernelGGL((layernorm_kernel<2>), grid, dim3(256), 0, stream, x, ldx, out, ldo, M, C, gamma, beta, eps, pe, pe_hw, pe_F);
-  else if (CP <= 256)
-    hipLaunchKernelGGL((layernorm_kernel<4>), grid, dim3(256), 0, stream, x, ldx, out, ldo, M, C, gamma, beta, eps, pe, pe_hw, pe_F);
-  else
-    return 2;
+#define NR_LN(T, V) launch_ln<T, V>(x, ldx, out, ldo, M, C, gamma, beta, eps, pe, pe_hw, pe_F, stream)
+  if (CP <= 8) NR_LN(8, 1);
+  else if (CP <= 16) NR_LN(16, 1);
+  else if (CP <= 24) NR_LN(8, 3);
+  else if (CP <= 48) NR_LN(16, 3);      // C = 320 (40 chunks)
+  else if (CP <= 96) NR_LN(32, 3);      // C = 640
+  else if (CP <= 192) NR_LN(64, 3);     // C = 1280
+  else if (CP <= 512) NR_LN(64, 8);
+  else return 2;
+#undef NR_LN
   return 0;
 }
