@@ -158,8 +158,187 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(NrAttnParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Block-shared variant for long sequences (spatial self-attention, text cross-attention): a 256-thread
+// workgroup = 4 waves = 64 queries of one (batch, head); K and V tiles of 64 keys are staged ONCE per
+// workgroup into LDS (row-major, 16-byte loads -> ds_write_b128, register-prefetched one tile ahead,
+// two LDS buffers, one barrier per tile).  K rows are the A operand of S^T = K Q^T (ds_read_b128, row
+// stride an odd number of 16-B units => conflict-free); V is consumed through the CDNA4 transpose read
+// ds_read_b64_tr_b16, which hands each lane V[4 keys][its dv column] = the A fragment of O^T = V^T P^T.
+// ------------------------------------------------------------------------------------------------
+constexpr int KT2 = 64;
+
+template <int DK, int DT>
+__global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p, int KS) {
+  constexpr int CH = (DT + 1) / 2;            // 16-B chunks per thread per matrix per tile
+  extern __shared__ __attribute__((aligned(16))) bf16 lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int TILE = KT2 * KS;                  // elements per matrix per buffer
+  const int qblocks = (p.Lq + 63) >> 6;
+  const int qb = blockIdx.x % qblocks;
+  const int h = (blockIdx.x / qblocks) % p.heads;
+  const int nb = blockIdx.x / (qblocks * p.heads);
+  const int nbkv = nb / p.kv_div;
+  const long long qbase = (long long)(nb / p.inner) * p.q_outer + (long long)(nb % p.inner) * p.q_inner_stride + (long long)h * p.d;
+  const long long obase = (long long)(nb / p.inner) * p.o_outer + (long long)(nb % p.inner) * p.o_inner_stride + (long long)h * p.d;
+  const long long kbase = (long long)(nbkv / p.kv_inner) * p.kv_outer + (long long)(nbkv % p.kv_inner) * p.kv_inner_stride + (long long)h * p.d;
+
+  const bf16x8 zero8 = bf16x8_zero();
+  const int qrow = qb * 64 + wave * 16 + c;
+  const int qrow_c = min(qrow, p.Lq - 1);
+  bf16x8 qf[DK];
+#pragma unroll
+  for (int ks = 0; ks < DK; ++ks) {
+    const int dim0 = ks * 32 + g * 8;
+    qf[ks] = dim0 < p.d ? *(const bf16x8*)(p.q + qbase + (long long)qrow_c * p.q_seq + dim0) : zero8;
+  }
+
+  const int cpk = p.d >> 3;                   // chunks per key row
+  const int nchunk = KT2 * cpk;
+  bf16x8 rk[CH], rv[CH];
+  auto load_regs = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int id = tid + 256 * i;
+      rk[i] = zero8; rv[i] = zero8;
+      if (id < nchunk) {
+        const int kk = id / cpk, x0 = (id - kk * cpk) << 3;
+        const int key = k0 + kk;
+        if (key < p.Lk) {
+          const long long off = kbase + (long long)key * p.kv_seq + x0;
+          rk[i] = *(const bf16x8*)(p.k + off);
+          rv[i] = *(const bf16x8*)(p.v + off);
+        }
+      }
+    }
+  };
+  auto write_lds = [&](int buf) {
+    bf16* sk = lds + buf * 2 * TILE;
+    bf16* sv = sk + TILE;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int id = tid + 256 * i;
+      if (id < nchunk) {
+        const int kk = id / cpk, x0 = (id - kk * cpk) << 3;
+        *(bf16x8*)(sk + kk * KS + x0) = rk[i];
+        *(bf16x8*)(sv + kk * KS + x0) = rv[i];
+      }
+    }
+  };
+
+  f32x4 acc[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_i = -1e30f, l_i = 0.f;
+
+  const int ntile = (p.Lk + KT2 - 1) / KT2;
+  load_regs(0);
+  write_lds(0);
+  __syncthreads();
+  const int tq = c >> 2, tp = c & 3;          // transpose-read role inside the 16-lane group
+  for (int it = 0; it < ntile; ++it) {
+    const int k0 = it * KT2;
+    if (it + 1 < ntile) load_regs(k0 + KT2);
+    const bf16* sk = lds + (it & 1) * 2 * TILE;
+    const bf16* sv = sk + TILE;
+    // ---- S^T = K Q^T for four 16-key tiles ----
+    f32x4 s[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < DK; ++ks) {
+        const int dim0 = ks * 32 + g * 8;
+        const bf16x8 kf = dim0 < p.d ? *(const bf16x8*)(sk + (16 * t + c) * KS + dim0) : zero8;
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
+      }
+    }
+    float mx = -1e30f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = k0 + 16 * t + 4 * g + r;
+        const float v = key < p.Lk ? s[t][r] * p.scale : -1e30f;
+        s[t][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_i, mx);
+    const float alpha = __expf(m_i - m_new);
+    float rs = 0.f;
+    bf16x8 pf[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = k0 + 16 * t + 4 * g + r;
+        const float e = key < p.Lk ? __expf(s[t][r] - m_new) : 0.f;
+        rs += e;
+        pf[t >> 1][(t & 1) * 4 + r] = (bf16)e;
+      }
+    rs += __shfl_xor(rs, 16, 64);
+    rs += __shfl_xor(rs, 32, 64);
+    l_i = l_i * alpha + rs;
+    m_i = m_new;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) acc[i] *= alpha;
+    // ---- O^T += V^T P^T ; k-slot j of step u -> key 32u + (j<4 ? 4g+j : 16+4g+j-4) ----
+#pragma unroll
+    for (int i = 0; i < DT; ++i) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const bf16* a0 = sv + (32 * u + 4 * g + tq) * KS + 16 * i + 4 * tp;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a0);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0 + 16 * KS));
+        bf16x8 vf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u], acc[i], 0, 0, 0);
+      }
+    }
+    if (it + 1 < ntile) write_lds((it + 1) & 1);
+    __syncthreads();
+  }
+
+  if (qrow < p.Lq) {
+    const float inv = 1.0f / l_i;
+    bf16* op = p.out + obase + (long long)qrow * p.o_seq;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) {
+      const int dv0 = i * 16 + 4 * g;
+      if (dv0 < p.d) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[i][e] * inv);
+        *(bf16x4*)(op + dv0) = o;
+      }
+    }
+  }
+}
+
 template <int DK, int DT>
 int launch_attn(const NrAttnParams& p, hipStream_t stream) {
+  if (p.Lq >= 48 && p.inner == 1) {
+    // long sequences: block-shared K/V tiles
+    int u = p.d / 8;                       // row stride in 16-byte units, forced odd (bank-conflict-free b128 reads)
+    if ((u & 1) == 0) u += 1;
+    const int KS = u * 8;
+    const size_t shm = (size_t)2 * 2 * KT2 * KS * sizeof(bf16) + 256;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)attn_fwd_shared_kernel<DK, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+      attr_set = true;
+    }
+    const int qblocks = (p.Lq + 63) / 64;
+    const unsigned blocks = (unsigned)((long long)p.nbatch * p.heads * qblocks);
+    hipLaunchKernelGGL((attn_fwd_shared_kernel<DK, DT>), dim3(blocks), dim3(256), shm, stream, p, KS);
+    return 0;
+  }
   const int qtiles = (p.Lq + 15) / 16;
   const long long total = (long long)p.nbatch * p.heads * qtiles;
   const unsigned blocks = (unsigned)((total + 3) / 4);

@@ -48,7 +48,15 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(NrGemmParams p, int spl
   const int wm = wave >> 1, wn = wave & 1;
   const int ntn = (p.N + BN - 1) / BN;
   const int ntm = (p.M + BM - 1) / BM;
-  int bid = blockIdx.x;
+  // XCD-aware remap (bijective): workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
+  // CONTIGUOUS range of logical tiles: the n-tiles that share one A row-panel then hit the same L2
+  // instead of re-fetching the panel from HBM once per XCD.  Placement only affects speed.
+  int bid;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7, local = orig >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
   const int slice = bid / (ntn * ntm);
   bid -= slice * ntn * ntm;
   const int bm = bid / ntn, bn = bid - bm * ntn;
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(NrGemmParams p, int spl
           const int oc = ((n0 + wn * WN + i * 16) >> 1) + 4 * fg;
           bf16x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (bf16)(v[e] * gelu_erf_f(g[e]));
+          for (int e = 0; e < 4; ++e) o[e] = (bf16)(v[e] * gelu_erf_fast(g[e]));
           *(bf16x4*)(p.out + (size_t)m * p.ldo + oc) = o;
         }
       }
@@ -255,25 +263,39 @@ struct Plan { int bm, bn, splitk; };
 Plan choose_plan(const NrGemmParams& p) {
   auto nblk = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
   const int nk = p.K / 64;
+  // candidate tiles, largest first.  Widths on the path are multiples of 320 (160 | N) or of 128.
+  int cand[4][2];
+  int nc = 0;
+  if (!p.geglu && p.N % 160 == 0 && p.N % 128 != 0) { cand[nc][0] = 128; cand[nc][1] = 160; ++nc; }
+  if (p.N % 128 == 0) { cand[nc][0] = 128; cand[nc][1] = 128; ++nc; }
+  cand[nc][0] = 128; cand[nc][1] = 64; ++nc;
+  cand[nc][0] = 64; cand[nc][1] = 64; ++nc;
   Plan pl;
-  // widths on the path are multiples of 320 (N in {320, 960, 1920, ...}: 160 | N) or of 128
-  if (!p.geglu && p.N % 160 == 0 && p.N % 128 != 0 && nblk(128, 160) >= 256) { pl.bm = 128; pl.bn = 160; }
-  else if (p.N % 128 == 0 && nblk(128, 128) >= 256) { pl.bm = 128; pl.bn = 128; }
-  else if (nblk(128, 64) >= 512) { pl.bm = 128; pl.bn = 64; }
-  else { pl.bm = 64; pl.bn = 64; }
   pl.splitk = 1;
-  if (!p.geglu) {
-    // small-M layers: prefer big tiles + split-K so that the weight stream is spread over the whole chip
-    if (nblk(pl.bm, pl.bn) < 384 && nk >= 8) {
-      if (p.N % 128 == 0 && p.M >= 256) { pl.bm = 128; pl.bn = 128; }
-      const long long b = nblk(pl.bm, pl.bn);
-      int s = (int)((768 + b - 1) / b);
-      if (s > nk / 4) s = nk / 4;
-      if (s > 32) s = 32;
-      if (s < 1) s = 1;
-      pl.splitk = s;
-    }
+  // 1) enough tiles to fill the chip without splitting K
+  for (int i = 0; i < nc; ++i) {
+    if (nblk(cand[i][0], cand[i][1]) >= 256) { pl.bm = cand[i][0]; pl.bn = cand[i][1]; return pl; }
   }
+  // 2) small M x N: split K (deterministic slab reduction) so the weight stream is spread over all CUs.
+  //    Each slice keeps >= min_tiles k-tiles; slab traffic (4*M*N*splitk bytes, written + read) must stay
+  //    small against the weight bytes, so big-M layers only split when K is long.
+  const int min_tiles = p.M <= 1024 ? 4 : 16;
+  if (!p.geglu && nk >= 2 * min_tiles) {
+    int pick = nc - 1;
+    for (int i = 0; i < nc; ++i) {
+      if (cand[i][0] <= p.M && nblk(cand[i][0], cand[i][1]) >= 96) { pick = i; break; }
+    }
+    pl.bm = cand[pick][0]; pl.bn = cand[pick][1];
+    const long long b = nblk(pl.bm, pl.bn);
+    int s = (int)((640 + b - 1) / b);
+    if (s > nk / min_tiles) s = nk / min_tiles;
+    if (s > 32) s = 32;
+    if (s < 1) s = 1;
+    pl.splitk = s;
+    return pl;
+  }
+  // 3) short K, few tiles: the smallest tile gives the most workgroups
+  pl.bm = 64; pl.bn = 64;
   return pl;
 }
 
