@@ -34,7 +34,7 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
 }
 
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void igemm_bf16_kernel(NrGemmParams p, int splitk, float* partial) {
+__global__ __launch_bounds__(256) void igemm_bf16_kernel(NrGemmParams p, int splitk, float* partial, int m_fast) {
   constexpr int BK = 64;
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 16, NT = WN / 16;
@@ -59,7 +59,10 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(NrGemmParams p, int spl
   }
   const int slice = bid / (ntn * ntm);
   bid -= slice * ntn * ntm;
-  const int bm = bid / ntn, bn = bid - bm * ntn;
+  // tile order inside an XCD's range: the operand that is re-used by neighbouring tiles should be the BIG
+  // one.  m_fast: neighbours share a weight panel (weight-heavy 4x4 / 8x8 levels); else an activation panel.
+  int bm, bn;
+  if (m_fast) { bn = bid / ntm; bm = bid - bn * ntm; } else { bm = bid / ntn; bn = bid - bm * ntn; }
   const int m0 = bm * BM, n0 = bn * BN;
   const int lr = lane >> 3;                 // row within the 8-row group
   const int lp = lane & 7;                  // physical 16-B chunk
@@ -279,15 +282,11 @@ Plan choose_plan(const NrGemmParams& p) {
   // 2) small M x N: split K (deterministic slab reduction) so the weight stream is spread over all CUs.
   //    Each slice keeps >= min_tiles k-tiles; slab traffic (4*M*N*splitk bytes, written + read) must stay
   //    small against the weight bytes, so big-M layers only split when K is long.
-  const int min_tiles = p.M <= 1024 ? 4 : 16;
+  const int min_tiles = p.M <= 1024 ? 4 : 24;
   if (!p.geglu && nk >= 2 * min_tiles) {
-    int pick = nc - 1;
-    for (int i = 0; i < nc; ++i) {
-      if (cand[i][0] <= p.M && nblk(cand[i][0], cand[i][1]) >= 96) { pick = i; break; }
-    }
-    pl.bm = cand[pick][0]; pl.bn = cand[pick][1];
+    pl.bm = p.M >= 128 && nblk(128, 64) >= 64 ? 128 : 64; pl.bn = 64;
     const long long b = nblk(pl.bm, pl.bn);
-    int s = (int)((640 + b - 1) / b);
+    int s = (int)((512 + b - 1) / b);
     if (s > nk / min_tiles) s = nk / min_tiles;
     if (s > 32) s = 32;
     if (s < 1) s = 1;
@@ -320,6 +319,9 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
   if (pl.splitk > 1 && !workspace) return 6;
   float* partial = pl.splitk > 1 ? workspace : nullptr;
   const unsigned grid = (unsigned)(((p.M + pl.bm - 1) / pl.bm) * ((p.N + pl.bn - 1) / pl.bn) * pl.splitk);
+  const double w_elems = (double)p.N * p.K;
+  const double a_elems = (double)p.M * Cin * (p.ksize == 3 ? (p.stride == 2 ? 4.0 : (p.ups ? 0.25 : 1.0)) : 1.0);
+  const int m_fast = w_elems > a_elems ? 1 : 0;
   const size_t shm = (size_t)2 * (pl.bm + pl.bn) * 64 * sizeof(bf16);
   static bool attr_set = false;
   if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (gfx950 has 160 KiB per CU)
@@ -328,13 +330,13 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
     attr_set = true;
   }
   if (pl.bm == 128 && pl.bn == 160)
-    hipLaunchKernelGGL((igemm_bf16_kernel<128, 160>), dim3(grid), dim3(256), shm, stream, p, pl.splitk, partial);
+    hipLaunchKernelGGL((igemm_bf16_kernel<128, 160>), dim3(grid), dim3(256), shm, stream, p, pl.splitk, partial, m_fast);
   else if (pl.bm == 128 && pl.bn == 128)
-    hipLaunchKernelGGL((igemm_bf16_kernel<128, 128>), dim3(grid), dim3(256), shm, stream, p, pl.splitk, partial);
+    hipLaunchKernelGGL((igemm_bf16_kernel<128, 128>), dim3(grid), dim3(256), shm, stream, p, pl.splitk, partial, m_fast);
   else if (pl.bm == 128 && pl.bn == 64)
-    hipLaunchKernelGGL((igemm_bf16_kernel<128, 64>), dim3(grid), dim3(256), shm, stream, p, pl.splitk, partial);
+    hipLaunchKernelGGL((igemm_bf16_kernel<128, 64>), dim3(grid), dim3(256), shm, stream, p, pl.splitk, partial, m_fast);
   else
-    hipLaunchKernelGGL((igemm_bf16_kernel<64, 64>), dim3(grid), dim3(256), shm, stream, p, pl.splitk, partial);
+    hipLaunchKernelGGL((igemm_bf16_kernel<64, 64>), dim3(grid), dim3(256), shm, stream, p, pl.splitk, partial, m_fast);
   if (pl.splitk > 1) {
     const long long total = (long long)p.M * (p.N / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p, pl.splitk,
