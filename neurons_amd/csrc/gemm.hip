@@ -21,6 +21,8 @@
 //     each slice writes an fp32 slab, a second kernel sums the slabs in fixed order (deterministic, no
 //     atomics) and applies the epilogue.
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -33,14 +35,20 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN>
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N <= 63) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int BM, int BN, int NS>
 __global__ __launch_bounds__(256) void igemm_bf16_kernel(NrGemmParams p, int splitk, float* partial, int m_fast) {
   constexpr int BK = 64;
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 16, NT = WN / 16;
   constexpr int GA = BM / 32, GB = BN / 32;          // 8-row groups per wave for the A / B tile
   constexpr int TILE = (BM + BN) * BK;               // elements per LDS buffer
-  extern __shared__ __attribute__((aligned(16))) bf16 smem[];   // 2 * TILE elements (up to 72 KiB)
+  extern __shared__ __attribute__((aligned(16))) bf16 smem[];   // NS * TILE elements (ring of NS k-tiles)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -143,12 +151,21 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(NrGemmParams p, int spl
 
   const int fr = lane & 15, fg = lane >> 4;
 
-  if (kt_begin < kt_end) stage(0, kt_begin);
+  // ---- main loop: ring of NS LDS buffers, tiles kt+1 .. kt+NS-2 stay in flight across the barrier ----
+  constexpr int G = GA + GB;                 // LDS-DMA instructions per wave per k-tile (wave-uniform)
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 1; ++s0)
+    if (kt_begin + s0 < kt_end) stage(s0, kt_begin + s0);
+  int cur = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int cur = (kt - kt_begin) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my LDS-DMA pieces of tile kt have landed
-    __syncthreads();                                    // everyone's have; everyone left buffer cur^1
-    if (kt + 1 < kt_end) stage(cur ^ 1, kt + 1);        // streams in under the MFMAs below
+    // tile kt must have landed; the younger (NS-2) tiles may stay outstanding (vmcnt counts in issue order)
+    if (kt + (NS - 2) < kt_end) wait_vmcnt<(NS - 2) * G>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();            // everyone's pieces of tile kt landed; everyone left tile kt-1
+    {
+      const int nxt = kt + NS - 1;           // refill the buffer tile kt-1 occupied
+      int nb = cur + NS - 1; if (nb >= NS) nb -= NS;
+      if (nxt < kt_end) stage(nb, nxt);
+    }
     const bf16* sA = smem + cur * TILE;
     const bf16* sB = sA + BM * BK;
 #pragma unroll
@@ -171,6 +188,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(NrGemmParams p, int spl
         for (int j = 0; j < MT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     }
+    cur = cur + 1 == NS ? 0 : cur + 1;
   }
 
   // ---- epilogue: lane holds out[m = ..+fr][n = ..+4*fg + r], r = 0..3 ----
@@ -261,7 +279,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(NrGemmParams p, int 
   *(bf16x4*)(p.out + (size_t)m * p.ldo + n) = o;
 }
 
-struct Plan { int bm, bn, splitk; };
+struct Plan { int bm, bn, splitk, stages; };
 
 Plan choose_plan(const NrGemmParams& p) {
   auto nblk = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
@@ -275,6 +293,7 @@ Plan choose_plan(const NrGemmParams& p) {
   cand[nc][0] = 64; cand[nc][1] = 64; ++nc;
   Plan pl;
   pl.splitk = 1;
+  pl.stages = 3;
   // 1) enough tiles to fill the chip without splitting K
   for (int i = 0; i < nc; ++i) {
     if (nblk(cand[i][0], cand[i][1]) >= 256) { pl.bm = cand[i][0]; pl.bn = cand[i][1]; return pl; }
@@ -298,11 +317,46 @@ Plan choose_plan(const NrGemmParams& p) {
   return pl;
 }
 
+template <int BM, int BN, int NS>
+void launch_cfg(const NrGemmParams& p, unsigned grid, int splitk, float* partial, int m_fast, hipStream_t stream) {
+  const size_t shm = (size_t)NS * (BM + BN) * 64 * sizeof(bf16);
+  static bool attr_set = false;
+  if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (gfx950 has 160 KiB per CU)
+    (void)hipFuncSetAttribute((const void*)igemm_bf16_kernel<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, NS>), dim3(grid), dim3(256), shm, stream, p, splitk, partial, m_fast);
+}
+
+template <int BM, int BN>
+void launch_tile(const NrGemmParams& p, unsigned grid, const Plan& pl, float* partial, int m_fast, hipStream_t stream) {
+  if (pl.stages <= 2) launch_cfg<BM, BN, 2>(p, grid, pl.splitk, partial, m_fast, stream);
+  else if (pl.stages == 3) launch_cfg<BM, BN, 3>(p, grid, pl.splitk, partial, m_fast, stream);
+  else launch_cfg<BM, BN, 4>(p, grid, pl.splitk, partial, m_fast, stream);
+}
+
+// test/tuning override: NR_IGEMM_FORCE="bm,bn,splitk,stages,order" (any field <0 keeps the heuristic's choice)
+void apply_override(const NrGemmParams& p, Plan& pl, int& m_fast) {
+  const char* e = getenv("NR_IGEMM_FORCE");
+  if (!e) return;
+  int bm = -1, bn = -1, sk = -1, st = -1, ord = -1;
+  sscanf(e, "%d,%d,%d,%d,%d", &bm, &bn, &sk, &st, &ord);
+  if (bm > 0 && bn > 0) {
+    const bool ok = (bm == 128 && (bn == 160 || bn == 128 || bn == 64)) || (bm == 64 && bn == 64);
+    if (ok && !(p.geglu && bn == 160)) { pl.bm = bm; pl.bn = bn; }
+  }
+  if (sk > 0 && !p.geglu) { const int nk = p.K / 64; pl.splitk = sk > nk ? nk : sk; }
+  if (st >= 2 && st <= 4) pl.stages = st;
+  if (ord >= 0) m_fast = ord;
+}
+
 }  // namespace
 
 // fp32 scratch (bytes) a launch of this shape needs for split-K slabs (0 if none)
 extern "C" size_t nr_igemm_workspace_bytes(const NrGemmParams* pp) {
-  const Plan pl = choose_plan(*pp);
+  Plan pl = choose_plan(*pp);
+  int mf = 0;
+  apply_override(*pp, pl, mf);
   return pl.splitk > 1 ? (size_t)pl.splitk * pp->M * pp->N * sizeof(float) : 0;
 }
 
@@ -315,28 +369,18 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
   if (p.a1 && (p.c0 % 64 != 0)) return 2;
   if (p.K != p.ksize * p.ksize * Cin) return 3;
   if (p.ksize != 1 && p.ksize != 3) return 4;
-  const Plan pl = choose_plan(p);
+  Plan pl = choose_plan(p);
+  const double w_elems = (double)p.N * p.K;
+  const double a_elems = (double)p.M * Cin * (p.ksize == 3 ? (p.stride == 2 ? 4.0 : (p.ups ? 0.25 : 1.0)) : 1.0);
+  int m_fast = w_elems > a_elems ? 1 : 0;
+  apply_override(p, pl, m_fast);
   if (pl.splitk > 1 && !workspace) return 6;
   float* partial = pl.splitk > 1 ? workspace : nullptr;
   const unsigned grid = (unsigned)(((p.M + pl.bm - 1) / pl.bm) * ((p.N + pl.bn - 1) / pl.bn) * pl.splitk);
-  const double w_elems = (double)p.N * p.K;
-  const double a_elems = (double)p.M * Cin * (p.ksize == 3 ? (p.stride == 2 ? 4.0 : (p.ups ? 0.25 : 1.0)) : 1.0);
-  const int m_fast = w_elems > a_elems ? 1 : 0;
-  const size_t shm = (size_t)2 * (pl.bm + pl.bn) * 64 * sizeof(bf16);
-  static bool attr_set = false;
-  if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (gfx950 has 160 KiB per CU)
-    (void)hipFuncSetAttribute((const void*)igemm_bf16_kernel<128, 160>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 160) * 64 * 2);
-    (void)hipFuncSetAttribute((const void*)igemm_bf16_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * 64 * 2);
-    attr_set = true;
-  }
-  if (pl.bm == 128 && pl.bn == 160)
-    hipLaunchKernelGGL((igemm_bf16_kernel<128, 160>), dim3(grid), dim3(256), shm, stream, p, pl.splitk, partial, m_fast);
-  else if (pl.bm == 128 && pl.bn == 128)
-    hipLaunchKernelGGL((igemm_bf16_kernel<128, 128>), dim3(grid), dim3(256), shm, stream, p, pl.splitk, partial, m_fast);
-  else if (pl.bm == 128 && pl.bn == 64)
-    hipLaunchKernelGGL((igemm_bf16_kernel<128, 64>), dim3(grid), dim3(256), shm, stream, p, pl.splitk, partial, m_fast);
-  else
-    hipLaunchKernelGGL((igemm_bf16_kernel<64, 64>), dim3(grid), dim3(256), shm, stream, p, pl.splitk, partial, m_fast);
+  if (pl.bm == 128 && pl.bn == 160) launch_tile<128, 160>(p, grid, pl, partial, m_fast, stream);
+  else if (pl.bm == 128 && pl.bn == 128) launch_tile<128, 128>(p, grid, pl, partial, m_fast, stream);
+  else if (pl.bm == 128 && pl.bn == 64) launch_tile<128, 64>(p, grid, pl, partial, m_fast, stream);
+  else launch_tile<64, 64>(p, grid, pl, partial, m_fast, stream);
   if (pl.splitk > 1) {
     const long long total = (long long)p.M * (p.N / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p, pl.splitk,
