@@ -41,19 +41,22 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int BM, int BN, int NS>
-__global__ __launch_bounds__(256) void igemm_bf16_kernel(NrGemmParams p, int splitk, float* partial, int m_fast) {
+// WGM x WGN = wave grid over the (M, N) tile; 64*WGM*WGN threads
+template <int BM, int BN, int NS, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams p, int splitk, float* partial, int m_fast) {
   constexpr int BK = 64;
-  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int NW = WGM * WGN;
+  constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int MT = WM / 16, NT = WN / 16;
-  constexpr int GA = BM / 32, GB = BN / 32;          // 8-row groups per wave for the A / B tile
+  constexpr int GA = BM / (8 * NW), GB = BN / (8 * NW);   // 8-row groups per wave for the A / B tile
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split evenly over the waves");
   constexpr int TILE = (BM + BN) * BK;               // elements per LDS buffer
   extern __shared__ __attribute__((aligned(16))) bf16 smem[];   // NS * TILE elements (ring of NS k-tiles)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
   const int ntn = (p.N + BN - 1) / BN;
   const int ntm = (p.M + BM - 1) / BM;
   // XCD-aware remap (bijective): workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(NrGemmParams p, int 
   *(bf16x4*)(p.out + (size_t)m * p.ldo + n) = o;
 }
 
-struct Plan { int bm, bn, splitk, stages; };
+struct Plan { int bm, bn, splitk, stages, waves; };
 
 Plan choose_plan(const NrGemmParams& p) {
   auto nblk = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
@@ -293,7 +296,8 @@ Plan choose_plan(const NrGemmParams& p) {
   cand[nc][0] = 64; cand[nc][1] = 64; ++nc;
   Plan pl;
   pl.splitk = 1;
-  pl.stages = 3;
+  pl.stages = 2;
+  pl.waves = 4;
   // 1) enough tiles to fill the chip without splitting K
   for (int i = 0; i < nc; ++i) {
     if (nblk(cand[i][0], cand[i][1]) >= 256) { pl.bm = cand[i][0]; pl.bn = cand[i][1]; return pl; }
@@ -317,36 +321,39 @@ Plan choose_plan(const NrGemmParams& p) {
   return pl;
 }
 
-template <int BM, int BN, int NS>
+template <int BM, int BN, int NS, int WGM, int WGN>
 void launch_cfg(const NrGemmParams& p, unsigned grid, int splitk, float* partial, int m_fast, hipStream_t stream) {
   const size_t shm = (size_t)NS * (BM + BN) * 64 * sizeof(bf16);
   static bool attr_set = false;
   if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (gfx950 has 160 KiB per CU)
-    (void)hipFuncSetAttribute((const void*)igemm_bf16_kernel<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    (void)hipFuncSetAttribute((const void*)igemm_bf16_kernel<BM, BN, NS, WGM, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, NS>), dim3(grid), dim3(256), shm, stream, p, splitk, partial, m_fast);
+  hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, NS, WGM, WGN>), dim3(grid), dim3(64 * WGM * WGN), shm, stream, p, splitk,
+                     partial, m_fast);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int WGM, int WGN>
 void launch_tile(const NrGemmParams& p, unsigned grid, const Plan& pl, float* partial, int m_fast, hipStream_t stream) {
-  if (pl.stages <= 2) launch_cfg<BM, BN, 2>(p, grid, pl.splitk, partial, m_fast, stream);
-  else if (pl.stages == 3) launch_cfg<BM, BN, 3>(p, grid, pl.splitk, partial, m_fast, stream);
-  else launch_cfg<BM, BN, 4>(p, grid, pl.splitk, partial, m_fast, stream);
+  if (pl.stages <= 2) launch_cfg<BM, BN, 2, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);
+  else launch_cfg<BM, BN, 3, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);
 }
 
 // test/tuning override: NR_IGEMM_FORCE="bm,bn,splitk,stages,order" (any field <0 keeps the heuristic's choice)
 void apply_override(const NrGemmParams& p, Plan& pl, int& m_fast) {
   const char* e = getenv("NR_IGEMM_FORCE");
   if (!e) return;
-  int bm = -1, bn = -1, sk = -1, st = -1, ord = -1;
-  sscanf(e, "%d,%d,%d,%d,%d", &bm, &bn, &sk, &st, &ord);
+  int bm = -1, bn = -1, sk = -1, st = -1, ord = -1, wv = -1;
+  sscanf(e, "%d,%d,%d,%d,%d,%d", &bm, &bn, &sk, &st, &ord, &wv);
   if (bm > 0 && bn > 0) {
-    const bool ok = (bm == 128 && (bn == 160 || bn == 128 || bn == 64)) || (bm == 64 && bn == 64);
+    const bool ok = (bm == 128 && (bn == 160 || bn == 128 || bn == 64)) || (bm == 64 && bn == 64) || (bm == 256 && bn == 128);
     if (ok && !(p.geglu && bn == 160)) { pl.bm = bm; pl.bn = bn; }
   }
+  if (wv == 4 || wv == 8) pl.waves = wv;
+  if (pl.bm == 256) pl.waves = 8;
+  if (pl.bn == 160 || pl.bm == 64) pl.waves = 4;
   if (sk > 0 && !p.geglu) { const int nk = p.K / 64; pl.splitk = sk > nk ? nk : sk; }
-  if (st >= 2 && st <= 4) pl.stages = st;
+  if (st >= 2 && st <= 3) pl.stages = st;
   if (ord >= 0) m_fast = ord;
 }
 
@@ -377,10 +384,13 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
   if (pl.splitk > 1 && !workspace) return 6;
   float* partial = pl.splitk > 1 ? workspace : nullptr;
   const unsigned grid = (unsigned)(((p.M + pl.bm - 1) / pl.bm) * ((p.N + pl.bn - 1) / pl.bn) * pl.splitk);
-  if (pl.bm == 128 && pl.bn == 160) launch_tile<128, 160>(p, grid, pl, partial, m_fast, stream);
-  else if (pl.bm == 128 && pl.bn == 128) launch_tile<128, 128>(p, grid, pl, partial, m_fast, stream);
-  else if (pl.bm == 128 && pl.bn == 64) launch_tile<128, 64>(p, grid, pl, partial, m_fast, stream);
-  else launch_tile<64, 64>(p, grid, pl, partial, m_fast, stream);
+  if (pl.bm == 256) launch_tile<256, 128, 4, 2>(p, grid, pl, partial, m_fast, stream);
+  else if (pl.bm == 128 && pl.bn == 160) launch_tile<128, 160, 2, 2>(p, grid, pl, partial, m_fast, stream);
+  else if (pl.bm == 128 && pl.bn == 128 && pl.waves == 8) launch_tile<128, 128, 2, 4>(p, grid, pl, partial, m_fast, stream);
+  else if (pl.bm == 128 && pl.bn == 128) launch_tile<128, 128, 2, 2>(p, grid, pl, partial, m_fast, stream);
+  else if (pl.bm == 128 && pl.bn == 64 && pl.waves == 8) launch_tile<128, 64, 4, 2>(p, grid, pl, partial, m_fast, stream);
+  else if (pl.bm == 128 && pl.bn == 64) launch_tile<128, 64, 2, 2>(p, grid, pl, partial, m_fast, stream);
+  else launch_tile<64, 64, 2, 2>(p, grid, pl, partial, m_fast, stream);
   if (pl.splitk > 1) {
     const long long total = (long long)p.M * (p.N / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p, pl.splitk,

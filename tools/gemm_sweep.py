@@ -20,11 +20,10 @@ SHAPES = [
     ("conv", (32, 8, 8), 1280, 2560, False), ("conv", (32, 4, 4), 1280, 1280, True), ("conv", (32, 4, 4), 1280, 2560, False),
     ("conv", (32, 16, 16), 640, 1920, False), ("conv", (32, 32, 32), 320, 960, False),
 ]
-CONFIGS = ["-1,-1,-1,2,-1", "-1,-1,-1,3,-1", "-1,-1,-1,4,-1",
-           "128,128,1,3,-1", "128,64,1,3,-1", "64,64,1,3,-1", "128,160,1,3,-1",
-           "128,128,2,3,-1", "128,128,4,3,-1", "128,64,2,3,-1", "128,64,4,3,-1", "64,64,2,3,-1", "64,64,4,3,-1", "64,64,8,3,-1",
-           "128,128,1,3,0", "128,128,1,3,1", "128,64,1,3,0", "128,64,1,3,1", "64,64,1,4,-1", "128,64,1,4,-1", "128,64,2,4,-1"]
-
+CONFIGS = ["-1,-1,-1,2,-1,4", "128,128,1,2,-1,4", "128,128,1,2,-1,8", "128,64,1,2,-1,4", "128,64,1,2,-1,8", "64,64,1,2,-1,4",
+           "128,160,1,2,-1,4", "256,128,1,2,-1,8", "128,128,1,3,-1,8", "128,64,1,3,-1,8", "64,64,1,3,-1,4",
+           "128,128,2,2,-1,8", "128,64,2,2,-1,4", "128,64,4,2,-1,4", "128,64,2,2,-1,8", "128,64,4,2,-1,8",
+           "64,64,2,2,-1,4", "64,64,4,2,-1,4", "64,64,8,2,-1,4", "256,128,2,2,-1,8", "256,128,4,2,-1,8"]
 
 def bench(fn, iters=20):
     for _ in range(3):
@@ -62,6 +61,8 @@ for sh in SHAPES:
     results = []
     for cfg in CONFIGS:
         if cfg.startswith("128,160") and N % 160 != 0:
+            continue
+        if cfg.startswith("256,128") and N % 128 != 0:
             continue
         os.environ["NR_IGEMM_FORCE"] = cfg
         try:
