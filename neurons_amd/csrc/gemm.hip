@@ -284,40 +284,32 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(NrGemmParams p, int 
 
 struct Plan { int bm, bn, splitk, stages, waves; };
 
+// Tile / wave-grid / split-K choice.  Rules distilled from tools/gemm_sweep.py on MI355X (profiles/): two LDS
+// stages (2 workgroups per CU) beat a deeper ring; 8 waves help the 128x128 tile; long-K layers with few
+// tiles gain 1.3-1.7x from split-K; 128x160 only pays for N = 320.
 Plan choose_plan(const NrGemmParams& p) {
   auto nblk = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
   const int nk = p.K / 64;
-  // candidate tiles, largest first.  Widths on the path are multiples of 320 (160 | N) or of 128.
-  int cand[4][2];
-  int nc = 0;
-  if (!p.geglu && p.N % 160 == 0 && p.N % 128 != 0) { cand[nc][0] = 128; cand[nc][1] = 160; ++nc; }
-  if (p.N % 128 == 0) { cand[nc][0] = 128; cand[nc][1] = 128; ++nc; }
-  cand[nc][0] = 128; cand[nc][1] = 64; ++nc;
-  cand[nc][0] = 64; cand[nc][1] = 64; ++nc;
   Plan pl;
-  pl.splitk = 1;
-  pl.stages = 2;
-  pl.waves = 4;
-  // 1) enough tiles to fill the chip without splitting K
-  for (int i = 0; i < nc; ++i) {
-    if (nblk(cand[i][0], cand[i][1]) >= 256) { pl.bm = cand[i][0]; pl.bn = cand[i][1]; return pl; }
+  pl.splitk = 1; pl.stages = 2; pl.waves = 4;
+  const bool n128 = p.N % 128 == 0 || p.N >= 960;          // <= 6 % padded columns otherwise
+  if (!p.geglu && p.N % 160 == 0 && p.N < 960 && p.N % 128 != 0 && nblk(128, 160) >= 256) { pl.bm = 128; pl.bn = 160; }
+  else if (n128 && nblk(128, 128) >= 256) { pl.bm = 128; pl.bn = 128; pl.waves = 8; }
+  else if (nblk(128, 64) >= 256) { pl.bm = 128; pl.bn = 64; }
+  else if (p.M >= 1024 && nblk(128, 64) >= 64) { pl.bm = 128; pl.bn = 64; }
+  else { pl.bm = 64; pl.bn = 64; }
+  if (!p.geglu) {
+    const long long tiles = nblk(pl.bm, pl.bn);
+    const int cap_m = p.M >= 8192 ? 2 : (p.M >= 2048 ? 4 : 8);      // bounds the fp32 slab traffic (8*M*N*split bytes)
+    const int min_tiles = p.M <= 1024 ? 8 : 16;                      // k-tiles each slice keeps
+    if (tiles < 1024 && nk >= 4 * min_tiles) {
+      int s_ = (int)((1280 + tiles - 1) / tiles);
+      if (s_ > nk / min_tiles) s_ = nk / min_tiles;
+      if (s_ > cap_m) s_ = cap_m;
+      if (s_ < 1) s_ = 1;
+      pl.splitk = s_;
+    }
   }
-  // 2) small M x N: split K (deterministic slab reduction) so the weight stream is spread over all CUs.
-  //    Each slice keeps >= min_tiles k-tiles; slab traffic (4*M*N*splitk bytes, written + read) must stay
-  //    small against the weight bytes, so big-M layers only split when K is long.
-  const int min_tiles = p.M <= 1024 ? 4 : 24;
-  if (!p.geglu && nk >= 2 * min_tiles) {
-    pl.bm = p.M >= 128 && nblk(128, 64) >= 64 ? 128 : 64; pl.bn = 64;
-    const long long b = nblk(pl.bm, pl.bn);
-    int s = (int)((512 + b - 1) / b);
-    if (s > nk / min_tiles) s = nk / min_tiles;
-    if (s > 32) s = 32;
-    if (s < 1) s = 1;
-    pl.splitk = s;
-    return pl;
-  }
-  // 3) short K, few tiles: the smallest tile gives the most workgroups
-  pl.bm = 64; pl.bn = 64;
   return pl;
 }
 
