@@ -98,28 +98,12 @@ def main():
 
     # ---- weights: rank 0 generates, everyone receives them over RCCL/xGMI (one broadcast per network) ----
     t0 = time.time()
+    from neurons_amd.distributed import broadcast_state_dict, max_over_ranks
     host_sd = {}
     for net, cfg, kind, seed in ((unet, ucfg, _lib.NR_KIND_UNET3D, 1), (ctrl, ccfg, _lib.NR_KIND_SPARSECTRL, 2)):
         schema = state_dict_schema(cfg, kind)
-        total = sum(int(torch.Size(s).numel()) for s in schema.values())
-        flat = torch.empty(total, dtype=torch.float32, device=dev)
-        if rank == 0:
-            sd = gpu_random_state_dict(schema, seed, dev)
-            off = 0
-            for k, s in schema.items():
-                n = sd[k].numel()
-                flat[off:off + n] = sd[k].reshape(-1)
-                off += n
-            del sd
-        if dist is not None:
-            dist.broadcast(flat, src=0)
-        flat_cpu = flat.cpu()
-        del flat
-        sd, off = {}, 0
-        for k, s in schema.items():
-            n = int(torch.Size(s).numel())
-            sd[k] = flat_cpu[off:off + n].view(s)
-            off += n
+        sd = gpu_random_state_dict(schema, seed, dev) if rank == 0 else None
+        sd = broadcast_state_dict(schema, sd, src=0, device=dev)     # one flat RCCL broadcast per network
         net.load_state_dict(sd)
         host_sd[kind] = sd
     torch.cuda.empty_cache()
@@ -158,10 +142,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t1
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = max_over_ranks(elapsed, device=dev)
     finite = bool(torch.isfinite(out).all().item())
 
     result = None

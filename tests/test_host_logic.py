@@ -1,0 +1,172 @@
+"""CPU-only tests: host logic of the drop-in layer, the C-ABI surface, the state-dict schema, the scheduler."""
+import ctypes
+import math
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from neurons_amd import _lib  # noqa: E402
+from neurons_amd.scheduler import DDIMScheduler  # noqa: E402
+from neurons_amd.unet3d import UNet3DConfig, random_state_dict, state_dict_schema  # noqa: E402
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI shared library loads (no GPU needed) and exports every function include/neurons_amd.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "neurons_amd.h")).read()
+    declared = set(re.findall(r"\b(nr_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"nr_status", "nr_stream"}
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libneurons_amd.so does not export {name}"
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+
+
+def test_create_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from neurons_amd import NativeUNet3D
+    net = NativeUNet3D(UNet3DConfig(block_out_channels=(64, 64, 128, 128), cross_attention_dim=64))
+    with pytest.raises(RuntimeError, match="no CPU fallback|MI355X|HIP"):
+        net.to("cpu")
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(2, 4, 8, 8, 8), 1, torch.zeros(2, 77, 64))
+
+
+def test_schema_matches_reference_parameter_counts():
+    """1 206 tensors / 1 276.7 M parameters (U-Net) and 496.7 M (SparseCtrl): SURVEY.md F4, §7."""
+    from neurons_amd.sparsectrl import controlnet_config_from_unet
+    u = state_dict_schema(UNet3DConfig(), _lib.NR_KIND_UNET3D)
+    assert len(u) == 1206
+    assert abs(sum(int(np.prod(s)) for s in u.values()) / 1e6 - 1276.66) < 0.05
+    ccfg = controlnet_config_from_unet(UNet3DConfig(), dict(set_noisy_sample_input_to_zero=True,
+                                                            use_simplified_condition_embedding=True, conditioning_channels=4,
+                                                            motion_module_kwargs=dict(attention_block_types=["Temporal_Self"],
+                                                                                      temporal_position_encoding_max_len=32)))
+    c = state_dict_schema(ccfg, _lib.NR_KIND_SPARSECTRL)
+    assert abs(sum(int(np.prod(s)) for s in c.values()) / 1e6 - 496.73) < 0.05
+    assert "controlnet_down_blocks.11.weight" in c and "controlnet_mid_block.bias" in c and "up_blocks.0.resnets.0.conv1.weight" not in c
+
+
+def test_load_state_dict_errors_mirror_torch():
+    from neurons_amd import NativeUNet3D
+    cfg = UNet3DConfig(block_out_channels=(64, 64, 128, 128), cross_attention_dim=64)
+    net = NativeUNet3D(cfg)
+    sd = random_state_dict(cfg, seed=1)
+    bad = dict(sd)
+    bad.pop("conv_in.weight")
+    with pytest.raises(RuntimeError, match="Missing key"):
+        net.load_state_dict(bad)
+    missing, unexpected = net.load_state_dict(bad, strict=False)
+    assert missing == ["conv_in.weight"] and unexpected == []
+    bad = dict(sd)
+    bad["conv_in.weight"] = torch.zeros(3, 3)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        net.load_state_dict(bad)
+    extra = dict(sd)
+    extra["down_blocks.0.motion_modules.0.temporal_transformer.transformer_blocks.0.attention_blocks.0.pos_encoder.pe"] = torch.zeros(1, 24, 64)
+    net.load_state_dict(extra)      # non-persistent PE buffer is accepted and ignored (animatediff/utils/util.py:116)
+
+
+def test_unsupported_configs_are_rejected():
+    from neurons_amd import NativeUNet3D
+    with pytest.raises(ValueError, match="does not exist"):
+        NativeUNet3D(UNet3DConfig(down_block_types=("Foo", "DownBlock3D", "DownBlock3D", "DownBlock3D")))
+    with pytest.raises(NotImplementedError):
+        NativeUNet3D(UNet3DConfig(use_inflated_groupnorm=False))
+
+
+# ---- scheduler (diffusers 0.11.1 DDIM restated; cross-checked against in-repo siblings) -----------------
+def _sched():
+    return DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
+
+
+def test_ddim_timesteps_match_survey_a2():
+    s = _sched()
+    s.set_timesteps(25)
+    assert s.timesteps_host[0] == 961 and s.timesteps_host[-1] == 1 and len(s.timesteps_host) == 25
+    s.set_timesteps(50)
+    assert s.timesteps_host[0] == 981 and s.timesteps_host[1] == 961 and s.timesteps_host[-1] == 1
+    assert s.init_noise_sigma == 1.0 and s.order == 1
+    x = torch.randn(2, 3)
+    assert s.scale_model_input(x, 5) is x
+
+
+def test_alphas_match_cumprod_mechanics_of_in_repo_discretizer():
+    """generative_models/sgm/modules/diffusionmodules/discretizer.py:51-55 builds alphas_cumprod as
+    cumprod(1 - betas); 'linear' here is linspace in beta, not in sqrt(beta)."""
+    s = _sched()
+    betas = np.linspace(0.00085, 0.012, 1000, dtype=np.float64)
+    ac = np.cumprod(1.0 - betas)
+    assert np.allclose(s.alphas_cumprod.numpy(), ac, rtol=2e-5)
+    s.set_timesteps(50)
+    a_t, a_prev = s.alpha_pair(981)
+    assert math.isclose(a_t, ac[981], rel_tol=2e-5) and math.isclose(a_prev, ac[961], rel_tol=2e-5)
+    a_t, a_prev = s.alpha_pair(1)
+    assert a_prev == 1.0      # set_alpha_to_one: prev timestep < 0 -> final_alpha_cumprod = 1
+
+
+def test_ddim_update_is_inverse_of_in_repo_next_step():
+    """animatediff/utils/util.py:211-221 (``next_step``, DDIM *inversion*) uses the same closed form in the other
+    direction: stepping t -> t' with eps held fixed and back must return the start (exactly, up to fp32)."""
+    from oracle import animatediff_oracle as O
+    ac = O.ddim_alphas_cumprod()
+    x = torch.randn(1, 4, 2, 4, 4, generator=torch.Generator().manual_seed(0))
+    eps = torch.randn(1, 4, 2, 4, 4, generator=torch.Generator().manual_seed(1))
+    t, n = 501, 50
+    prev = O.ddim_step(eps, t, x, ac, n)              # t -> t - 20
+    # next_step formula (util.py:217-220) from timestep t-20 back to t
+    a_t, a_next = ac[t - 20], ac[t]
+    x0 = (prev - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
+    back = a_next ** 0.5 * x0 + (1 - a_next) ** 0.5 * eps
+    assert torch.allclose(back, x, atol=2e-5)
+
+
+def test_add_noise_and_low_strength_quirk():
+    s = _sched()
+    s.set_timesteps(10)
+    x, n = torch.ones(1, 4, 2, 2, 2), torch.full((1, 4, 2, 2, 2), 2.0)
+    t = s.timesteps[:1]
+    y = s.add_noise(x, n, t)
+    a = s.alphas_cumprod[int(t)]
+    assert torch.allclose(y, a.sqrt() * x + (1 - a).sqrt() * n)
+    # low_strength >= 1 -> empty latent_timestep (pipeline_neuroclips.py:410-413)
+    init_timestep = min(int(10 * 1.0), 10)
+    t_start = max(10 - init_timestep, 0)
+    assert s.timesteps[:t_start][:1].numel() == 0
+
+
+def test_scheduler_step_refuses_cpu():
+    s = _sched()
+    s.set_timesteps(10)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        s.step(torch.zeros(1, 4), 901, torch.zeros(1, 4))
+    with pytest.raises(NotImplementedError):
+        s.step(torch.zeros(1, 4), 901, torch.zeros(1, 4), eta=0.5)
+
+
+def test_pipeline_requires_gpu_and_validates_inputs():
+    from neurons_amd import NativeUNet3D, NeuroclipsPipeline
+    cfg = UNet3DConfig(sample_size=8, block_out_channels=(64, 64, 128, 128), cross_attention_dim=64)
+    pipe = NeuroclipsPipeline(None, None, None, NativeUNet3D(cfg), _sched(), None)
+    with pytest.raises(ValueError, match="divisible by 8"):
+        pipe("", video_length=8, height=60, width=64)
+    with pytest.raises(ValueError, match="callback_steps"):
+        pipe("", video_length=8, height=64, width=64, callback_steps=0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pipe("", video_length=8, height=64, width=64, text_embeddings=torch.zeros(2, 77, 64))
+
+
+def test_synth_is_deterministic_and_normal():
+    from neurons_amd.synth import randn
+    a, b = randn("x.y", (257, 3), 5), randn("x.y", (257, 3), 5)
+    assert torch.equal(a, b) and not torch.equal(a, randn("x.z", (257, 3), 5))
+    z = randn("big", (200000,), 1)
+    assert abs(z.mean().item()) < 0.01 and abs(z.std().item() - 1) < 0.01
