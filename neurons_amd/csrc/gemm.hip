@@ -98,35 +98,46 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
       a_pix[j] = n; a_oy[j] = r / p.OW; a_ox[j] = r - a_oy[j] * p.OW;
     }
   }
-  const bf16* wsrc[GB];
-#pragma unroll
-  for (int j = 0; j < GB; ++j) {
-    const int n = n0 + 8 * (wave * GB + j) + lr;
-    wsrc[j] = n < p.N ? p.w + (size_t)n * p.K + lchunk : nullptr;
-  }
   const bf16* zsrc = (const bf16*)nr_zero16;
 
   const int nk_total = p.K / BK;
   const int kt_begin = (int)(((long long)nk_total * slice) / splitk);
   const int kt_end = (int)(((long long)nk_total * (slice + 1)) / splitk);
 
-  auto stage = [&](int buf, int kt) {
-    bf16* sA = smem + buf * TILE;
-    bf16* sB = sA + BM * BK;
-    const int kbase = kt * BK;
-    int tap = 0, c = kbase;
-    if (p.ksize == 3) { tap = kbase / Cin; c = kbase - tap * Cin; }
+  // ---- running source pointers of the NEXT k-tile to stage.  The k index walks (tap, channel) with the
+  // channel fastest, so between two k-tiles every pointer simply advances by 64 elements; the im2col
+  // address arithmetic (border test, pixel index, 64-bit multiply) is redone only when the tap or the concat
+  // source changes (once per Cin/64 tiles).  Rows that are padding / out of range sit on a 16-byte zero word
+  // with increment 0.  This keeps the main loop at ~2 VALU per LDS-DMA instead of ~15. ----
+  const bf16* ap[GA];
+  int ainc[GA];
+  const bf16* wp[GB];
+  int winc[GB];
+  int st_tap, st_c;
+  {
+    const int kbase = kt_begin * BK;
+    st_tap = p.ksize == 3 ? kbase / Cin : 0;
+    st_c = kbase - st_tap * Cin;
+#pragma unroll
+    for (int j = 0; j < GB; ++j) {
+      const int n = n0 + 8 * (wave * GB + j) + lr;
+      const bool ok = n < p.N;
+      wp[j] = ok ? p.w + (size_t)n * p.K + kbase + lchunk : zsrc;
+      winc[j] = ok ? BK : 0;
+    }
+  }
+  auto setup_rows = [&]() {
     const bf16* src; int ld;
-    if (c < p.c0) { src = p.a0 + c; ld = p.lda0; } else { src = p.a1 + (c - p.c0); ld = p.lda1; }
+    if (st_c < p.c0) { src = p.a0 + st_c; ld = p.lda0; } else { src = p.a1 + (st_c - p.c0); ld = p.lda1; }
     src += lchunk;
     if (p.ksize == 1) {
 #pragma unroll
       for (int j = 0; j < GA; ++j) {
-        const bf16* s = a_ok[j] ? src + (size_t)a_pix[j] * ld : zsrc;
-        glds16(s, sA + (wave * GA + j) * 8 * BK);
+        ap[j] = a_ok[j] ? src + (size_t)a_pix[j] * ld : zsrc;
+        ainc[j] = a_ok[j] ? BK : 0;
       }
     } else {
-      const int ky = tap / 3, kx = tap - ky * 3;
+      const int ky = st_tap / 3, kx = st_tap - ky * 3;
       const int VH = p.ups ? p.H * 2 : p.H, VW = p.ups ? p.W * 2 : p.W;
 #pragma unroll
       for (int j = 0; j < GA; ++j) {
@@ -135,14 +146,32 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
         const bool ok = a_ok[j] && iy >= 0 && iy < VH && ix >= 0 && ix < VW;
         if (p.ups) { iy >>= 1; ix >>= 1; }
         const size_t pix = ((size_t)a_pix[j] * p.H + iy) * p.W + ix;
-        const bf16* s = ok ? src + pix * ld : zsrc;
-        glds16(s, sA + (wave * GA + j) * 8 * BK);
+        ap[j] = ok ? src + pix * ld : zsrc;
+        ainc[j] = ok ? BK : 0;
       }
     }
+  };
+  setup_rows();
+
+  auto stage = [&](int buf) {
+    bf16* sA = smem + buf * TILE;
+    bf16* sB = sA + BM * BK;
 #pragma unroll
-    for (int j = 0; j < GB; ++j) {
-      const bf16* s = wsrc[j] ? wsrc[j] + kbase : zsrc;
-      glds16(s, sB + (wave * GB + j) * 8 * BK);
+    for (int j = 0; j < GA; ++j) glds16(ap[j], sA + (wave * GA + j) * 8 * BK);
+#pragma unroll
+    for (int j = 0; j < GB; ++j) glds16(wp[j], sB + (wave * GB + j) * 8 * BK);
+    // advance to the next k-tile
+#pragma unroll
+    for (int j = 0; j < GB; ++j) wp[j] += winc[j];
+    st_c += BK;
+    bool resetup = false;
+    if (st_c == Cin) { st_c = 0; st_tap += 1; resetup = true; }
+    else if (p.c1 > 0 && st_c == p.c0) resetup = true;
+    if (resetup) {
+      if (st_tap < p.ksize * p.ksize) setup_rows();
+    } else {
+#pragma unroll
+      for (int j = 0; j < GA; ++j) ap[j] += ainc[j];
     }
   };
 
@@ -158,7 +187,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
   constexpr int G = GA + GB;                 // LDS-DMA instructions per wave per k-tile (wave-uniform)
 #pragma unroll
   for (int s0 = 0; s0 < NS - 1; ++s0)
-    if (kt_begin + s0 < kt_end) stage(s0, kt_begin + s0);
+    if (kt_begin + s0 < kt_end) stage(s0);
   int cur = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     // tile kt must have landed; the younger (NS-2) tiles may stay outstanding (vmcnt counts in issue order)
@@ -167,7 +196,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
     {
       const int nxt = kt + NS - 1;           // refill the buffer tile kt-1 occupied
       int nb = cur + NS - 1; if (nb >= NS) nb -= NS;
-      if (nxt < kt_end) stage(nb, nxt);
+      if (nxt < kt_end) stage(nb);
     }
     const bf16* sA = smem + cur * TILE;
     const bf16* sB = sA + BM * BK;
