@@ -39,6 +39,7 @@ typedef struct nr_net nr_net;
 
 #define NR_KIND_UNET3D 0     /* animatediff/models/unet.py:38 UNet3DConditionModel            */
 #define NR_KIND_SPARSECTRL 1 /* animatediff/models/sparse_controlnet.py:85 SparseControlNetModel */
+#define NR_KIND_SGM_UNET 2   /* generative_models/sgm/modules/diffusionmodules/openaimodel.py:472 UNetModel (unCLIP keyframes) */
 
 #define NR_MAX_LEVELS 4
 
@@ -65,6 +66,12 @@ typedef struct nr_net_config {
   int32_t motion_module_mid_block;           /* 0                                                 */
   int32_t conditioning_channels;             /* SparseCtrl: 4 (+1 mask channel is implied)        */
   int32_t set_noisy_sample_input_to_zero;    /* SparseCtrl: 1                                     */
+  /* sgm UNetModel only (generative_models/configs/unclip6.yaml:47-63); for that kind block_out_channels[i] =
+   * channel_mult[i]*model_channels, layers_per_block = num_res_blocks, down_block_has_attn[i] = (2^i in
+   * attention_resolutions), cross_attention_dim = context_dim                                                  */
+  int32_t transformer_depth[NR_MAX_LEVELS];  /* 1,2,10 (0 for the other kinds = depth 1)          */
+  int32_t num_head_channels;                 /* 64: heads = C / 64 (0 for the other kinds)        */
+  int32_t adm_in_channels;                   /* 1024: width of the `y` vector                     */
 } nr_net_config;
 
 #define NR_DTYPE_F32 0
@@ -125,6 +132,21 @@ nr_status nr_unet3d_forward(nr_net* h, nr_stream stream, const float* sample_dev
 nr_status nr_sparsectrl_forward(nr_net* h, nr_stream stream, const float* sample_dev, const float* timesteps,
                                 const float* ctx_dev, int32_t ctx_len, const float* cond_dev, const float* mask_dev,
                                 int32_t cond_batch, float scale, void* const* out_down_dev, void* out_mid_dev);
+
+/* replaces OpenAIWrapper.forward -> UNetModel.forward (sgm/modules/diffusionmodules/wrappers.py:23-34,
+ * openaimodel.py:816-853).  x_dev fp32 [batch][4][h][w] is multiplied by in_scale (= c_in of
+ * denoiser.py:36-39) on the fly; timesteps = c_noise (host fp32 [batch]); ctx_dev fp32 [batch][ctx_len][context_dim]
+ * ("crossattn"); y_dev fp32 [batch][adm_in_channels] ("vector"); out_dev fp32 [batch][4][h][w].               */
+nr_status nr_sgm_unet_forward(nr_net* h, nr_stream stream, const float* x_dev, float in_scale, const float* timesteps,
+                              const float* ctx_dev, int32_t ctx_len, const float* y_dev, float* out_dev);
+
+/* replaces Denoiser.forward's output scaling + VanillaCFG + EulerEDMSampler.sampler_step with s_churn = 0
+ * (denoiser.py:36-39, denoiser_scaling.py:29-37, guiders.py:28-31, sampling_utils.py:34-35, sampling.py:98-112):
+ *   den_k = net_k * (-sigma_quantized) + x ;  den = den_u + scale * (den_c - den_u) ;  d = (x - den) / sigma ;
+ *   x_out = x + d * (sigma_next - sigma).     net_dev fp32 [2B][...] (uncond first), x fp32 [B][...], n = numel(x);
+ *   sigma_quantized = nearest table sigma the DiscreteDenoiser evaluates the network at (denoiser.py:61-75)    */
+nr_status nr_edm_cfg_euler_step(nr_stream stream, const float* net_dev, const float* x_dev, float* x_out_dev, int64_t n,
+                                float cfg_scale, float sigma_quantized, float sigma, float sigma_next);
 
 /* replaces the CFG combine + DDIMScheduler.step (pipeline_neuroclips.py:478-483; diffusers 0.11.1 DDIM eta=0)
  *   eps_dev fp32 [2B or B][...], x_dev fp32 [B][...] -> x_out_dev (may alias x_dev); n = elements of x     */

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libneurons_amd.so")
 
 NR_KIND_UNET3D = 0
 NR_KIND_SPARSECTRL = 1
+NR_KIND_SGM_UNET = 2
 NR_MAX_LEVELS = 4
 
 
@@ -36,6 +37,9 @@ class NrNetConfig(C.Structure):
         ("motion_module_mid_block", C.c_int32),
         ("conditioning_channels", C.c_int32),
         ("set_noisy_sample_input_to_zero", C.c_int32),
+        ("transformer_depth", C.c_int32 * NR_MAX_LEVELS),
+        ("num_head_channels", C.c_int32),
+        ("adm_in_channels", C.c_int32),
     ]
 
 
@@ -67,6 +71,8 @@ SYMBOLS = {
     "nr_net_residual_shape": (_I32, [_VP, _I32, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
     "nr_unet3d_forward": (_I32, [_VP, _VP, _VP, _FP, _VP, _I32, C.POINTER(_VP), _VP, _VP]),
     "nr_sparsectrl_forward": (_I32, [_VP, _VP, _VP, _FP, _VP, _I32, _VP, _VP, _I32, C.c_float, C.POINTER(_VP), _VP]),
+    "nr_sgm_unet_forward": (_I32, [_VP, _VP, _VP, C.c_float, _FP, _VP, _I32, _VP, _VP]),
+    "nr_edm_cfg_euler_step": (_I32, [_VP, _VP, _VP, _VP, _I64, C.c_float, C.c_float, C.c_float, C.c_float]),
     "nr_cfg_ddim_step": (_I32, [_VP, _VP, _VP, _VP, _I64, C.c_float, _I32, C.c_double, C.c_double]),
     "nr_net_profile_last": (_I32, [_VP, _VP, C.POINTER(NrProfile)]),
     "nr_net_set_debug": (_I32, [_VP, _I32]),

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void conv_in_small_kernel(const float* __restr
                                                             int c0, int c1, int src_batch, int F, int H, int W,
                                                             const float* __restrict__ wT, const float* __restrict__ bias,
                                                             const float* __restrict__ addend, int Cout,
-                                                            bf16* __restrict__ out) {
+                                                            bf16* __restrict__ out, float in_scale) {
   extern __shared__ float patch[];
   const int Cin = c0 + c1;
   const int y = blockIdx.x, n = blockIdx.y;
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void conv_in_small_kernel(const float* __restr
     if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
       const float* s; int cc, cs;
       if (ci < c0) { s = s0; cc = ci; cs = c0; } else { s = s1; cc = ci - c0; cs = c1; }
-      v = s[((((size_t)b * cs + cc) * F + f) * H + iy) * W + ix];
+      v = s[((((size_t)b * cs + cc) * F + f) * H + iy) * W + ix] * in_scale;
     }
     patch[i] = v;
   }
@@ -112,7 +112,8 @@ __global__ void timestep_sincos_kernel(const float* __restrict__ t, int M, int d
 // out_act: 0 none, 1 SiLU (on output)
 __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ x, int M, int K,
                                                            const bf16* __restrict__ W, const float* __restrict__ b, int N,
-                                                           int in_act, int out_act, float* __restrict__ y) {
+                                                           int in_act, int out_act, float* __restrict__ y,
+                                                           const float* __restrict__ addend) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
       float v = wave_sum(acc[m]);
       if (lane == 0) {
         v += b ? b[n] : 0.f;
+        if (addend) v += addend[(size_t)m * N + n];
         if (out_act) v = silu_f(v);
         y[(size_t)m * N + n] = v;
       }
@@ -169,6 +171,19 @@ __global__ void cfg_ddim_step_kernel(const float* __restrict__ eps, const float*
   x_out[i] = sqrt_ap * x0 + sqrt_1map * e;
 }
 
+// EDM eps-scaling + vanilla CFG + Euler step (see nr_edm_cfg_euler_step in include/neurons_amd.h)
+__global__ void edm_cfg_euler_kernel(const float* __restrict__ net, const float* __restrict__ x, float* __restrict__ x_out,
+                                     long long total, float scale, float sigma_q, float sigma, float sigma_next) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const float xv = x[i];
+  const float du = net[i] * (-sigma_q) + xv;      // c_out = -quantised sigma, c_skip = 1 (denoiser_scaling.py:29-37)
+  const float dc = net[i + total] * (-sigma_q) + xv;
+  const float den = du + scale * (dc - du);
+  const float d = (xv - den) / sigma;
+  x_out[i] = xv + d * (sigma_next - sigma);
+}
+
 __global__ void add_bf16_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ out,
                                 long long n8) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -190,11 +205,11 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ a, bf16* __restrict
 
 extern "C" int nr_launch_conv_in_small(const float* s0, const float* s1, int c0, int c1, int src_batch, int nimg, int F,
                                        int H, int W, const float* wT, const float* bias, const float* addend, int Cout,
-                                       bf16* out, hipStream_t stream) {
+                                       bf16* out, float in_scale, hipStream_t stream) {
   const size_t shm = (size_t)(c0 + c1) * 3 * (W + 2) * sizeof(float);
   if (shm > 60000) return 1;
   hipLaunchKernelGGL(conv_in_small_kernel, dim3(H, nimg), dim3(256), shm, stream, s0, s1, c0, c1, src_batch, F, H, W, wT,
-                     bias, addend, Cout, out);
+                     bias, addend, Cout, out, in_scale);
   return 0;
 }
 
@@ -217,9 +232,17 @@ extern "C" int nr_launch_timestep_sincos(const float* t, int M, int dim, float* 
 }
 
 extern "C" int nr_launch_linear_small(const float* x, int M, int K, const bf16* W, const float* b, int N, int in_act,
-                                      int out_act, float* y, hipStream_t stream) {
+                                      int out_act, float* y, const float* addend, hipStream_t stream) {
   if (M > 16 || K % 8 != 0) return 1;
-  hipLaunchKernelGGL(linear_small_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, x, M, K, W, b, N, in_act, out_act, y);
+  hipLaunchKernelGGL(linear_small_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, x, M, K, W, b, N, in_act, out_act, y,
+                     addend);
+  return 0;
+}
+
+extern "C" int nr_launch_edm_cfg_euler(const float* net, const float* x, float* x_out, long long total, float scale,
+                                       float sigma_q, float sigma, float sigma_next, hipStream_t stream) {
+  hipLaunchKernelGGL(edm_cfg_euler_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, net, x, x_out, total,
+                     scale, sigma_q, sigma, sigma_next);
   return 0;
 }
 

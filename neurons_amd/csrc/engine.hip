@@ -36,13 +36,15 @@ int nr_launch_layernorm(const bf16* x, int ldx, bf16* out, int ldo, int M, int C
                         float eps, const float* pe, int pe_hw, int pe_F, hipStream_t stream);
 int nr_launch_attention(const NrAttnParams* pp, hipStream_t stream);
 int nr_launch_conv_in_small(const float* s0, const float* s1, int c0, int c1, int src_batch, int nimg, int F, int H, int W,
-                            const float* wT, const float* bias, const float* addend, int Cout, bf16* out,
+                            const float* wT, const float* bias, const float* addend, int Cout, bf16* out, float in_scale,
                             hipStream_t stream);
 int nr_launch_conv_out_small(const bf16* x, int Cin, int nimg, int F, int H, int W, const bf16* w, const float* bias,
                              int Cout, float* out, hipStream_t stream);
 int nr_launch_timestep_sincos(const float* t, int M, int dim, float* out, hipStream_t stream);
 int nr_launch_linear_small(const float* x, int M, int K, const bf16* W, const float* b, int N, int in_act, int out_act,
-                           float* y, hipStream_t stream);
+                           float* y, const float* addend, hipStream_t stream);
+int nr_launch_edm_cfg_euler(const float* net, const float* x, float* x_out, long long total, float scale, float sigma_q,
+                            float sigma, float sigma_next, hipStream_t stream);
 int nr_launch_cfg_ddim_step(const float* eps, const float* x, float* x_out, long long total, float guidance, int do_cfg,
                             float sqrt_at, float sqrt_1mat, float sqrt_ap, float sqrt_1map, hipStream_t stream);
 int nr_launch_add_bf16(const bf16* a, const bf16* b, bf16* out, long long n, hipStream_t stream);
@@ -156,6 +158,8 @@ struct IO {
   float scale = 1.f;
   void* out_down[16] = {nullptr};
   void* out_mid = nullptr;
+  const float* y = nullptr;     // sgm "vector" conditioning
+  float in_scale = 1.f;         // sgm c_in
   bool operator==(const IO& o) const { return std::memcmp(this, &o, sizeof(IO)) == 0; }
 };
 
@@ -512,31 +516,42 @@ struct nr_net {
     throw NrError(NR_ERR_STATE, "no temb slot for " + prefix);
   }
 
-  // ResnetBlock3D.forward (resnet.py:182-212); x1 = skip tensor for the up-block concat
+  // parameter names of one residual block: diffusers-style (animatediff) or sgm-style (openaimodel.py:255-312)
+  struct ResKeys { std::string norm1, conv1, norm2, conv2, shortcut; };
+  ResKeys res_keys(const std::string& pre) const {
+    if (cfg.kind == NR_KIND_SGM_UNET)
+      return ResKeys{pre + ".in_layers.0", pre + ".in_layers.2", pre + ".out_layers.0", pre + ".out_layers.3", pre + ".skip_connection"};
+    return ResKeys{pre + ".norm1", pre + ".conv1", pre + ".norm2", pre + ".conv2", pre + ".conv_shortcut"};
+  }
+
+  // ResnetBlock3D.forward (resnet.py:182-212) == sgm ResBlock._forward (openaimodel.py:328-354, no up/down, no
+  // scale-shift): GN+SiLU -> conv (+bias +Linear(SiLU(emb))) -> GN+SiLU -> conv (+bias) + skip(x).
+  // x1 = skip tensor for the decoder concat.
   Act resnet(const Act& x0, const Act* x1, const std::string& pre, int Cout) {
+    const ResKeys k = res_keys(pre);
     const int Cin = x0.C + (x1 ? x1->C : 0);
     const int hw = x0.H * x0.W;
-    Act h = groupnorm(x0, x1, pre + ".norm1", cfg.norm_eps, 1);
+    Act h = groupnorm(x0, x1, k.norm1, cfg.norm_eps, 1);
     GemmOpt o1;
-    o1.bias = w_f32(pre + ".conv1.bias", Cout);
+    o1.bias = w_f32(k.conv1 + ".bias", Cout);
     o1.rowvec = temb_for(pre, Cout); o1.rowvec_div = F * hw; o1.rowvec_ld = temb_total;
-    Act h1 = conv(h, nullptr, w_conv3(pre + ".conv1.weight", Cout, Cin), Cout, 3, 1, 0, o1);
+    Act h1 = conv(h, nullptr, w_conv3(k.conv1 + ".weight", Cout, Cin), Cout, 3, 1, 0, o1);
     h = Act();
-    Act h2 = groupnorm(h1, nullptr, pre + ".norm2", cfg.norm_eps, 1);
+    Act h2 = groupnorm(h1, nullptr, k.norm2, cfg.norm_eps, 1);
     h1 = Act();
     Act sc;
-    const bool shortcut = has(pre + ".conv_shortcut.weight");
+    const bool shortcut = has(k.shortcut + ".weight");
     if (shortcut) {
-      GemmOpt os; os.bias = w_f32(pre + ".conv_shortcut.bias", Cout);
-      sc = conv(x0, x1, w_linear(pre + ".conv_shortcut.weight", Cout, Cin), Cout, 1, 1, 0, os);
+      GemmOpt os; os.bias = w_f32(k.shortcut + ".bias", Cout);
+      sc = conv(x0, x1, w_linear(k.shortcut + ".weight", Cout, Cin), Cout, 1, 1, 0, os);
     } else {
-      if (x1 || Cin != Cout) throw NrError(NR_ERR_MISSING_WEIGHT, "missing state-dict entry: " + pre + ".conv_shortcut.weight");
+      if (x1 || Cin != Cout) throw NrError(NR_ERR_MISSING_WEIGHT, "missing state-dict entry: " + k.shortcut + ".weight");
       sc = x0;
     }
     GemmOpt o2;
-    o2.bias = w_f32(pre + ".conv2.bias", Cout);
+    o2.bias = w_f32(k.conv2 + ".bias", Cout);
     o2.res = &sc;
-    Act out = conv(h2, nullptr, w_conv3(pre + ".conv2.weight", Cout, Cout), Cout, 3, 1, 0, o2);
+    Act out = conv(h2, nullptr, w_conv3(k.conv2 + ".weight", Cout, Cout), Cout, 3, 1, 0, o2);
     tap(pre, out);
     return out;
   }
@@ -550,39 +565,44 @@ struct nr_net {
     linear(hmid, w_linear(pre + ".net.2.weight", C, inner), C, o2);
   }
 
-  // Transformer3DModel.forward (attention.py:95-142) with one BasicTransformerBlock (:256-300)
-  Act spatial_transformer(const Act& x, const Act& ctx_bf, const std::string& pre) {
-    const int C = x.C, heads = cfg.num_heads;
+  // Transformer3DModel.forward (attention.py:95-142) with one BasicTransformerBlock (:256-300); also sgm
+  // SpatialTransformer.forward (sgm/modules/attention.py:702-723) with `depth` BasicTransformerBlocks (:551-572):
+  // same arithmetic and parameter names (proj_in/out are nn.Linear there: same [C][C] matrix).
+  Act spatial_transformer(const Act& x, const Act& ctx_bf, const std::string& pre, int depth = 1) {
+    const int C = x.C;
+    const int heads = cfg.num_head_channels > 0 ? C / cfg.num_head_channels : cfg.num_heads;
     Act hn = groupnorm(x, nullptr, pre + ".norm", 1e-6f, 0);
     GemmOpt oi; oi.bias = w_f32(pre + ".proj_in.bias", C);
     Act t = linear(hn, w_linear(pre + ".proj_in.weight", C, C), C, oi);
     hn = Act();
-    const std::string b = pre + ".transformer_blocks.0";
-    {  // self-attention
-      Act n1 = layernorm(t, b + ".norm1", nullptr, 1);
-      GemmOpt oq;
-      Act qkv = linear(n1, w_linear_cat({b + ".attn1.to_q.weight", b + ".attn1.to_k.weight", b + ".attn1.to_v.weight"}, C, C), 3 * C, oq);
-      n1 = Act();
-      Act a = attention(0, qkv, nullptr, C, heads);
-      qkv = Act();
-      GemmOpt oo; oo.bias = w_f32(b + ".attn1.to_out.0.bias", C); oo.res = &t; oo.out = &t;
-      linear(a, w_linear(b + ".attn1.to_out.0.weight", C, C), C, oo);
-    }
-    {  // cross-attention on the text context (attention.py:100: context repeated per frame)
-      Act n2 = layernorm(t, b + ".norm2", nullptr, 1);
-      GemmOpt oq;
-      Act q = linear(n2, w_linear(b + ".attn2.to_q.weight", C, C), C, oq);
-      n2 = Act();
-      GemmOpt ok;
-      Act kv = linear(ctx_bf, w_linear_cat({b + ".attn2.to_k.weight", b + ".attn2.to_v.weight"}, C, cfg.cross_attention_dim), 2 * C, ok);
-      Act a = attention(1, q, &kv, C, heads);
-      q = Act(); kv = Act();
-      GemmOpt oo; oo.bias = w_f32(b + ".attn2.to_out.0.bias", C); oo.res = &t; oo.out = &t;
-      linear(a, w_linear(b + ".attn2.to_out.0.weight", C, C), C, oo);
-    }
-    {
-      Act n3 = layernorm(t, b + ".norm3", nullptr, 1);
-      feed_forward(t, n3, b + ".ff");
+    for (int dd = 0; dd < depth; ++dd) {
+      const std::string b = pre + ".transformer_blocks." + std::to_string(dd);
+      {  // self-attention
+        Act n1 = layernorm(t, b + ".norm1", nullptr, 1);
+        GemmOpt oq;
+        Act qkv = linear(n1, w_linear_cat({b + ".attn1.to_q.weight", b + ".attn1.to_k.weight", b + ".attn1.to_v.weight"}, C, C), 3 * C, oq);
+        n1 = Act();
+        Act a = attention(0, qkv, nullptr, C, heads);
+        qkv = Act();
+        GemmOpt oo; oo.bias = w_f32(b + ".attn1.to_out.0.bias", C); oo.res = &t; oo.out = &t;
+        linear(a, w_linear(b + ".attn1.to_out.0.weight", C, C), C, oo);
+      }
+      {  // cross-attention on the context (attention.py:100: context repeated per frame)
+        Act n2 = layernorm(t, b + ".norm2", nullptr, 1);
+        GemmOpt oq;
+        Act q = linear(n2, w_linear(b + ".attn2.to_q.weight", C, C), C, oq);
+        n2 = Act();
+        GemmOpt ok;
+        Act kv = linear(ctx_bf, w_linear_cat({b + ".attn2.to_k.weight", b + ".attn2.to_v.weight"}, C, cfg.cross_attention_dim), 2 * C, ok);
+        Act a = attention(1, q, &kv, C, heads);
+        q = Act(); kv = Act();
+        GemmOpt oo; oo.bias = w_f32(b + ".attn2.to_out.0.bias", C); oo.res = &t; oo.out = &t;
+        linear(a, w_linear(b + ".attn2.to_out.0.weight", C, C), C, oo);
+      }
+      {
+        Act n3 = layernorm(t, b + ".norm3", nullptr, 1);
+        feed_forward(t, n3, b + ".ff");
+      }
     }
     GemmOpt op; op.bias = w_f32(pre + ".proj_out.bias", C); op.res = &x;
     Act out = linear(t, w_linear(pre + ".proj_out.weight", C, C), C, op);
@@ -641,7 +661,166 @@ struct nr_net {
           add("up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), cfg.block_out_channels[L - 1 - i]);
   }
 
+  // ---------------------------------------------------------------------------------------------------
+  // sgm UNetModel (generative_models/sgm/modules/diffusionmodules/openaimodel.py:472; forward :816-853;
+  // construction order :640-807 fixes the input_blocks / output_blocks numbering used for the key names)
+  // ---------------------------------------------------------------------------------------------------
+  struct SgmLayout {
+    struct In { int idx; int kind; int level; int Cout; };          // kind 0 conv_in, 1 res(+attn), 2 downsample
+    struct Out { int idx; int level; int Cout; bool attn; bool up; };
+    std::vector<In> in;
+    std::vector<Out> out;
+  };
+  SgmLayout sgm_layout() const {
+    SgmLayout l;
+    const int L = cfg.num_levels;
+    int idx = 0;
+    l.in.push_back({idx++, 0, 0, cfg.block_out_channels[0]});
+    for (int lev = 0; lev < L; ++lev) {
+      for (int r = 0; r < cfg.layers_per_block; ++r) l.in.push_back({idx++, 1, lev, cfg.block_out_channels[lev]});
+      if (lev != L - 1) l.in.push_back({idx++, 2, lev, cfg.block_out_channels[lev]});
+    }
+    idx = 0;
+    for (int lev = L - 1; lev >= 0; --lev)
+      for (int i = 0; i <= cfg.layers_per_block; ++i)
+        l.out.push_back({idx++, lev, cfg.block_out_channels[lev], cfg.down_block_has_attn[lev] != 0,
+                         lev > 0 && i == cfg.layers_per_block});
+    return l;
+  }
+
+  void build_sgm() {
+    const int L = cfg.num_levels;
+    const int C0 = cfg.block_out_channels[0];
+    const int temb_dim = 4 * C0;
+    const int nimg = B2 * F;
+    if (F != 1) throw NrError(NR_ERR_ARG, "sgm UNetModel is a 2-D network: plan with frames = 1");
+    const SgmLayout lay = sgm_layout();
+    ops.clear(); op_meta.clear(); taps.clear(); arena.reset();
+    temb_slots.clear();
+    {
+      int off = 0;
+      auto add = [&](const std::string& p, int C) { temb_slots.push_back(TembSlot{p, off, C}); off += C; };
+      for (auto& b : lay.in) if (b.kind == 1) add("input_blocks." + std::to_string(b.idx) + ".0", b.Cout);
+      add("middle_block.0", cfg.block_out_channels[L - 1]);
+      add("middle_block.2", cfg.block_out_channels[L - 1]);
+      for (auto& b : lay.out) add("output_blocks." + std::to_string(b.idx) + ".0", b.Cout);
+      temb_total = off;
+    }
+    // ---- emb = time_embed(sinusoid(t)) + label_emb(y)  (openaimodel.py:836-841); every ResBlock then applies
+    // Linear(SiLU(emb)) (emb_layers, :283-289): batched into ONE launch ----
+    t_dev = new_scratch<float>(16);
+    float* sincos = new_scratch<float>((size_t)B2 * C0);
+    float* e1 = new_scratch<float>((size_t)B2 * temb_dim);
+    float* et = new_scratch<float>((size_t)B2 * temb_dim);
+    float* y1 = new_scratch<float>((size_t)B2 * temb_dim);
+    float* emb = new_scratch<float>((size_t)B2 * temb_dim);
+    temb_all = new_scratch<float>((size_t)B2 * temb_total);
+    {
+      const int adm = cfg.adm_in_channels;
+      const bf16* w1 = w_linear("time_embed.0.weight", temb_dim, C0);
+      const float* b1 = w_f32("time_embed.0.bias", temb_dim);
+      const bf16* w2 = w_linear("time_embed.2.weight", temb_dim, temb_dim);
+      const float* b2 = w_f32("time_embed.2.bias", temb_dim);
+      const bf16* wy1 = w_linear("label_emb.0.0.weight", temb_dim, adm);
+      const float* by1 = w_f32("label_emb.0.0.bias", temb_dim);
+      const bf16* wy2 = w_linear("label_emb.0.2.weight", temb_dim, temb_dim);
+      const float* by2 = w_f32("label_emb.0.2.bias", temb_dim);
+      std::vector<std::string> wk, bk;
+      for (auto& sl : temb_slots) {
+        wk.push_back(sl.prefix + ".emb_layers.1.weight"); bk.push_back(sl.prefix + ".emb_layers.1.bias");
+        check_shape(wk.back(), need(wk.back()), {sl.C, temb_dim});
+        check_shape(bk.back(), need(bk.back()), {sl.C});
+      }
+      const std::string wname = "tembw:sgm", bname = "tembb:sgm";
+      const bf16* wp = (const bf16*)cached(wname, [&]() {
+        std::vector<uint16_t> h((size_t)temb_total * temb_dim);
+        size_t o = 0;
+        for (auto& k : wk) { const HostTensor& t = data_of(k); for (float f : t.data) h[o++] = f2bf_host(f); }
+        return upload(wname, h.data(), h.size() * 2);
+      });
+      const float* bp = (const float*)cached(bname, [&]() {
+        std::vector<float> h; h.reserve(temb_total);
+        for (auto& k : bk) { const HostTensor& t = data_of(k); h.insert(h.end(), t.data.begin(), t.data.end()); }
+        return upload(bname, h.data(), h.size() * 4);
+      });
+      float* td = t_dev; float* ta = temb_all;
+      const int b2n = B2, tt = temb_total;
+      emit([=, this](hipStream_t s) {
+        LAUNCH_OK(nr_launch_timestep_sincos(td, b2n, C0, sincos, s));
+        LAUNCH_OK(nr_launch_linear_small(sincos, b2n, C0, w1, b1, temb_dim, 0, 1, e1, nullptr, s));
+        LAUNCH_OK(nr_launch_linear_small(e1, b2n, temb_dim, w2, b2, temb_dim, 0, 0, et, nullptr, s));
+        LAUNCH_OK(nr_launch_linear_small(io.y, b2n, adm, wy1, by1, temb_dim, 0, 1, y1, nullptr, s));
+        LAUNCH_OK(nr_launch_linear_small(y1, b2n, temb_dim, wy2, by2, temb_dim, 0, 0, emb, et, s));   // emb = time + label
+        LAUNCH_OK(nr_launch_linear_small(emb, b2n, temb_dim, wp, bp, tt, 1, 0, ta, nullptr, s));
+      });
+    }
+    // ---- context fp32 -> bf16 ----
+    Act ctx_bf = new_act(1, 1, B2 * ctx_len, cfg.cross_attention_dim);
+    {
+      bf16* cp = ctx_bf.ptr; const long long n = (long long)B2 * ctx_len * cfg.cross_attention_dim;
+      emit([this, cp, n](hipStream_t s) { LAUNCH_OK(nr_launch_f32_to_bf16(io.ctx, cp, n, s)); });
+    }
+    // ---- input blocks ----
+    std::vector<Act> hs;
+    Act x;
+    for (auto& b : lay.in) {
+      const std::string bp = "input_blocks." + std::to_string(b.idx);
+      if (b.kind == 0) {
+        x = new_act(nimg, H, W, C0);
+        const float* wT = w_conv_in(bp + ".0.weight", C0, cfg.in_channels);
+        const float* bi = w_f32(bp + ".0.bias", C0);
+        bf16* xp = x.ptr; const int ic = cfg.in_channels, b2n = B2, Hn = H, Wn = W;
+        emit([=, this](hipStream_t s) {
+          LAUNCH_OK(nr_launch_conv_in_small(io.sample, nullptr, ic, 0, b2n, nimg, 1, Hn, Wn, wT, bi, nullptr, C0, xp, io.in_scale, s));
+        });
+        tap(bp, x);
+      } else if (b.kind == 1) {
+        x = resnet(x, nullptr, bp + ".0", b.Cout);
+        if (cfg.down_block_has_attn[b.level]) x = spatial_transformer(x, ctx_bf, bp + ".1", cfg.transformer_depth[b.level]);
+      } else {
+        GemmOpt o; o.bias = w_f32(bp + ".0.op.bias", b.Cout);
+        x = conv(x, nullptr, w_conv3(bp + ".0.op.weight", b.Cout, b.Cout), b.Cout, 3, 2, 0, o);
+        tap(bp, x);
+      }
+      hs.push_back(x);
+    }
+    // ---- middle block ----
+    {
+      const int Cm = cfg.block_out_channels[L - 1];
+      x = resnet(x, nullptr, "middle_block.0", Cm);
+      x = spatial_transformer(x, ctx_bf, "middle_block.1", cfg.transformer_depth[L - 1]);
+      x = resnet(x, nullptr, "middle_block.2", Cm);
+    }
+    // ---- output blocks: h = cat([h, hs.pop()]) -> ResBlock -> [SpatialTransformer] -> [Upsample] ----
+    for (auto& b : lay.out) {
+      const std::string bp = "output_blocks." + std::to_string(b.idx);
+      Act skip = hs.back();
+      hs.pop_back();
+      x = resnet(x, &skip, bp + ".0", b.Cout);
+      skip = Act();
+      int sub = 1;
+      if (b.attn) { x = spatial_transformer(x, ctx_bf, bp + ".1", cfg.transformer_depth[b.level]); sub = 2; }
+      if (b.up) {
+        const std::string up = bp + "." + std::to_string(sub) + ".conv";
+        GemmOpt o; o.bias = w_f32(up + ".bias", b.Cout);
+        x = conv(x, nullptr, w_conv3(up + ".weight", b.Cout, b.Cout), b.Cout, 3, 1, 1, o);
+        tap(bp + "." + std::to_string(sub), x);
+      }
+    }
+    // ---- out: GroupNorm32 -> SiLU -> conv (openaimodel.py:809-813) ----
+    Act hn = groupnorm(x, nullptr, "out.0", cfg.norm_eps, 1);
+    {
+      const bf16* wo = w_conv3("out.2.weight", cfg.out_channels, C0);
+      const float* bo = w_f32("out.2.bias", cfg.out_channels);
+      const bf16* hp = hn.ptr; const int Hn = H, Wn = W, oc = cfg.out_channels;
+      emit([=, this](hipStream_t s) { LAUNCH_OK(nr_launch_conv_out_small(hp, C0, nimg, 1, Hn, Wn, wo, bo, oc, io.out, s)); });
+    }
+    n_res = 0;
+    res_shapes.clear();
+  }
+
   void build() {
+    if (cfg.kind == NR_KIND_SGM_UNET) { build_sgm(); return; }
     const int L = cfg.num_levels;
     const int C0 = cfg.block_out_channels[0];
     const int temb_dim = 4 * C0;
@@ -687,9 +866,9 @@ struct nr_net {
       const int b2n = B2, tt = temb_total;
       emit([=](hipStream_t s) {
         LAUNCH_OK(nr_launch_timestep_sincos(td, b2n, C0, sincos, s));
-        LAUNCH_OK(nr_launch_linear_small(sincos, b2n, C0, w1, b1, temb_dim, 0, 1, emb1, s));   // Linear + SiLU
-        LAUNCH_OK(nr_launch_linear_small(emb1, b2n, temb_dim, w2, b2, temb_dim, 0, 0, emb, s)); // emb
-        LAUNCH_OK(nr_launch_linear_small(emb, b2n, temb_dim, wp, bp, tt, 1, 0, ta, s));         // Linear(SiLU(emb)) for all resnets
+        LAUNCH_OK(nr_launch_linear_small(sincos, b2n, C0, w1, b1, temb_dim, 0, 1, emb1, nullptr, s));   // Linear + SiLU
+        LAUNCH_OK(nr_launch_linear_small(emb1, b2n, temb_dim, w2, b2, temb_dim, 0, 0, emb, nullptr, s)); // emb
+        LAUNCH_OK(nr_launch_linear_small(emb, b2n, temb_dim, wp, bp, tt, 1, 0, ta, nullptr, s));         // Linear(SiLU(emb)) for all resnets
       });
     }
 
@@ -707,7 +886,7 @@ struct nr_net {
       const float* bi = w_f32("conv_in.bias", C0);
       bf16* xp = x.ptr; const int ic = cfg.in_channels, b2n = B2, Fn = F, Hn = H, Wn = W;
       emit([=, this](hipStream_t s) {
-        LAUNCH_OK(nr_launch_conv_in_small(io.sample, nullptr, ic, 0, b2n, nimg, Fn, Hn, Wn, wT, bi, nullptr, C0, xp, s));
+        LAUNCH_OK(nr_launch_conv_in_small(io.sample, nullptr, ic, 0, b2n, nimg, Fn, Hn, Wn, wT, bi, nullptr, C0, xp, 1.f, s));
       });
     } else {
       // sparse_controlnet.py:467-521: sample := 0 -> conv_in(0) = bias; + cond_embedding(cat[cond, mask])
@@ -718,7 +897,7 @@ struct nr_net {
       bf16* xp = x.ptr; const int Fn = F, Hn = H, Wn = W;
       if (cfg.set_noisy_sample_input_to_zero) {
         emit([=, this](hipStream_t s) {
-          LAUNCH_OK(nr_launch_conv_in_small(io.cond, io.mask, cc, 1, io.cond_batch, nimg, Fn, Hn, Wn, wTe, be, bi, C0, xp, s));
+          LAUNCH_OK(nr_launch_conv_in_small(io.cond, io.mask, cc, 1, io.cond_batch, nimg, Fn, Hn, Wn, wTe, be, bi, C0, xp, 1.f, s));
         });
       } else {
         const float* wT = w_conv_in("conv_in.weight", C0, cfg.in_channels);
@@ -726,8 +905,8 @@ struct nr_net {
         bf16* x2p = x2.ptr; const int ic = cfg.in_channels, b2n = B2;
         const long long n = (long long)nimg * H * W * C0;
         emit([=, this](hipStream_t s) {
-          LAUNCH_OK(nr_launch_conv_in_small(io.sample, nullptr, ic, 0, b2n, nimg, Fn, Hn, Wn, wT, bi, nullptr, C0, xp, s));
-          LAUNCH_OK(nr_launch_conv_in_small(io.cond, io.mask, cc, 1, io.cond_batch, nimg, Fn, Hn, Wn, wTe, be, nullptr, C0, x2p, s));
+          LAUNCH_OK(nr_launch_conv_in_small(io.sample, nullptr, ic, 0, b2n, nimg, Fn, Hn, Wn, wT, bi, nullptr, C0, xp, 1.f, s));
+          LAUNCH_OK(nr_launch_conv_in_small(io.cond, io.mask, cc, 1, io.cond_batch, nimg, Fn, Hn, Wn, wTe, be, nullptr, C0, x2p, 1.f, s));
           LAUNCH_OK(nr_launch_add_bf16(xp, x2p, xp, n, s));
         });
       }
@@ -954,13 +1133,14 @@ extern "C" nr_status nr_net_create(const nr_net_config* cfg, nr_net** out) {
   NR_TRY
   if (!cfg || !out) throw NrError(NR_ERR_ARG, "null argument");
   if (cfg->num_levels < 2 || cfg->num_levels > NR_MAX_LEVELS) throw NrError(NR_ERR_ARG, "num_levels must be 2..4");
-  if (cfg->kind != NR_KIND_UNET3D && cfg->kind != NR_KIND_SPARSECTRL) throw NrError(NR_ERR_ARG, "bad kind");
+  if (cfg->kind != NR_KIND_UNET3D && cfg->kind != NR_KIND_SPARSECTRL && cfg->kind != NR_KIND_SGM_UNET) throw NrError(NR_ERR_ARG, "bad kind");
   for (int i = 0; i < cfg->num_levels; ++i) {
     const int C = cfg->block_out_channels[i];
     if (C % 64 != 0) throw NrError(NR_ERR_UNSUPPORTED, "block_out_channels must be multiples of 64");
     if (C % cfg->norm_num_groups != 0) throw NrError(NR_ERR_ARG, "channels not divisible by norm_num_groups");
-    if (C % cfg->num_heads != 0 || (C / cfg->num_heads) % 8 != 0 || C / cfg->num_heads > 160)
-      throw NrError(NR_ERR_UNSUPPORTED, "head dim must be a multiple of 8 and <= 160");
+    const int hd = cfg->num_head_channels > 0 ? cfg->num_head_channels : (cfg->num_heads > 0 ? C / cfg->num_heads : 0);
+    if (hd <= 0 || C % hd != 0 || hd % 8 != 0 || hd > 160)
+      throw NrError(NR_ERR_UNSUPPORTED, "head dim must divide the channels, be a multiple of 8 and <= 160");
   }
   if (cfg->cross_attention_dim % 64 != 0) throw NrError(NR_ERR_UNSUPPORTED, "cross_attention_dim must be a multiple of 64");
   if (cfg->norm_num_groups > 64) throw NrError(NR_ERR_UNSUPPORTED, "norm_num_groups > 64");
@@ -1081,6 +1261,29 @@ extern "C" nr_status nr_sparsectrl_forward(nr_net* h, nr_stream stream, const fl
   io.out_mid = out_mid_dev;
   h->io = io;
   h->run((hipStream_t)stream, timesteps);
+  NR_CATCH
+}
+
+extern "C" nr_status nr_sgm_unet_forward(nr_net* h, nr_stream stream, const float* x_dev, float in_scale, const float* timesteps,
+                                         const float* ctx_dev, int32_t ctx_len, const float* y_dev, float* out_dev) {
+  NR_TRY
+  if (!h || h->cfg.kind != NR_KIND_SGM_UNET) throw NrError(NR_ERR_ARG, "handle is not an sgm UNetModel");
+  if (!h->planned) throw NrError(NR_ERR_STATE, "nr_net_plan() has not been called (or weights changed since)");
+  if (!x_dev || !timesteps || !ctx_dev || !y_dev || !out_dev) throw NrError(NR_ERR_ARG, "null tensor argument");
+  if (ctx_len != h->ctx_len) throw NrError(NR_ERR_ARG, "ctx_len differs from the planned value");
+  IO io;
+  std::memset(&io, 0, sizeof(io));
+  io.sample = x_dev; io.ctx = ctx_dev; io.y = y_dev; io.out = out_dev; io.in_scale = in_scale; io.scale = 1.f; io.cond_batch = 1;
+  h->io = io;
+  h->run((hipStream_t)stream, timesteps);
+  NR_CATCH
+}
+
+extern "C" nr_status nr_edm_cfg_euler_step(nr_stream stream, const float* net_dev, const float* x_dev, float* x_out_dev,
+                                           int64_t n, float cfg_scale, float sigma_quantized, float sigma, float sigma_next) {
+  NR_TRY
+  if (!net_dev || !x_dev || !x_out_dev || n <= 0 || sigma <= 0.f) throw NrError(NR_ERR_ARG, "bad argument");
+  LAUNCH_OK(nr_launch_edm_cfg_euler(net_dev, x_dev, x_out_dev, n, cfg_scale, sigma_quantized, sigma, sigma_next, (hipStream_t)stream));
   NR_CATCH
 }
 

@@ -254,23 +254,31 @@ class _NativeNet:
     """Shared handle management for the two networks."""
     _kind = _lib.NR_KIND_UNET3D
 
-    def __init__(self, config: Optional[UNet3DConfig] = None, **kwargs):
+    _config_cls = UNet3DConfig
+
+    def __init__(self, config=None, **kwargs):
         if config is None:
-            config = UNet3DConfig(**kwargs)
+            config = self._config_cls(**kwargs)
         elif kwargs:
             raise TypeError("pass either a UNet3DConfig or keyword arguments")
         self.config = config
         self.in_channels = config.in_channels
-        self.sample_size = config.sample_size
+        self.sample_size = getattr(config, "sample_size", None)
         self.dtype = torch.float32          # dtype at the API boundary; compute is bf16/fp32-accumulate in HIP
         self.device = torch.device("cpu")
-        self._cconf = make_c_config(config, self._kind)
-        self._schema = state_dict_schema(config, self._kind)
+        self._cconf = self._build_cconf(config)
+        self._schema = self._build_schema(config)
         self._h = None
         self._plan_key = None
         self._loaded = set()
         self._pending = {}
         self._graph = True
+
+    def _build_cconf(self, config):
+        return make_c_config(config, self._kind)
+
+    def _build_schema(self, config):
+        return state_dict_schema(config, self._kind)
 
     # -- module-like surface ---------------------------------------------------------------------------
     def to(self, device=None, dtype=None):

@@ -358,6 +358,81 @@ def gen_leaf_ops(out_dir):
     print("leaf_ops:", {k: v.shape for k, v in out.items()})
 
 
+# --------------------------------------------------------------------------------------------------
+# sgm unCLIP path: import the reference's own UNetModel / sampler (bypass sgm/__init__.py, which
+# pulls Lightning/open_clip, by pre-registering namespace packages; omegaconf is only used in annotations)
+# --------------------------------------------------------------------------------------------------
+def install_sgm_scaffolding():
+    if "sgm" in sys.modules and getattr(sys.modules["sgm"], "_nr_stub", False):
+        return
+    base = f"{REF}/generative_models/sgm"
+    for name, path in (("sgm", base), ("sgm.modules", f"{base}/modules"), ("sgm.modules.diffusionmodules", f"{base}/modules/diffusionmodules")):
+        m = types.ModuleType(name)
+        m.__path__ = [path]
+        m._nr_stub = True
+        sys.modules[name] = m
+    if "omegaconf" not in sys.modules:
+        _mod("omegaconf", ListConfig=list, OmegaConf=type("OmegaConf", (), {}), DictConfig=dict)
+
+
+def tiny_sgm_config():
+    from neurons_amd.sgm import SGMUNetConfig
+    return SGMUNetConfig(model_channels=64, channel_mult=(1, 2, 4), num_res_blocks=2, attention_resolutions=(4, 2),
+                         num_head_channels=32, transformer_depth=(1, 2, 3), context_dim=128, adm_in_channels=64)
+
+
+def build_reference_sgm(cfg, sd):
+    install_sgm_scaffolding()
+    from sgm.modules.diffusionmodules.openaimodel import UNetModel
+    net = UNetModel(in_channels=cfg.in_channels, model_channels=cfg.model_channels, out_channels=cfg.out_channels,
+                    num_res_blocks=cfg.num_res_blocks, attention_resolutions=list(cfg.attention_resolutions),
+                    channel_mult=list(cfg.channel_mult), num_classes="sequential", use_checkpoint=False,
+                    num_head_channels=cfg.num_head_channels, use_linear_in_transformer=True,
+                    transformer_depth=list(cfg.transformer_depth), context_dim=cfg.context_dim,
+                    adm_in_channels=cfg.adm_in_channels, spatial_transformer_attn_type="softmax")
+    assert set(net.state_dict().keys()) == set(sd.keys()), set(net.state_dict().keys()) ^ set(sd.keys())
+    net.load_state_dict(sd, strict=True)
+    return net.eval()
+
+
+@torch.no_grad()
+def gen_sgm(out_dir):
+    from neurons_amd.sgm import sgm_random_state_dict
+    from neurons_amd.synth import randn
+    install_sgm_scaffolding()
+    from sgm.modules.diffusionmodules.denoiser import DiscreteDenoiser
+    from sgm.modules.diffusionmodules.discretizer import LegacyDDPMDiscretization
+    from sgm.modules.diffusionmodules.sampling import EulerEDMSampler
+    from sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
+    cfg = tiny_sgm_config()
+    sd = sgm_random_state_dict(cfg, seed=71)
+    net = build_reference_sgm(cfg, sd)
+    x = randn("sgm.x", (2, 4, 16, 16), 72)
+    ctx = randn("sgm.ctx", (2, 24, cfg.context_dim), 73)
+    y = randn("sgm.y", (2, cfg.adm_in_channels), 74)
+    t = torch.tensor([437, 437])
+    out = dict(x=x.numpy(), ctx=ctx.numpy(), y=y.numpy(), t=t.numpy())
+    out["eps"] = net(x, timesteps=t, context=ctx, y=y).numpy()
+    disc = LegacyDDPMDiscretization()
+    out["sigmas38"] = disc(38).numpy()
+    out["sigmas50"] = disc(50).numpy()
+    # 4-step Euler-EDM + VanillaCFG(5.0) loop exactly as utils.unclip_recon wires it (utils.py:337-340)
+    sampler = EulerEDMSampler(num_steps=4, discretization_config={"target": "sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization"},
+                              guider_config={"target": "sgm.modules.diffusionmodules.guiders.VanillaCFG", "params": {"scale": 5.0}},
+                              device="cpu")
+    denoiser = DiscreteDenoiser(scaling_config={"target": "sgm.modules.diffusionmodules.denoiser_scaling.EpsScaling"}, num_idx=1000,
+                                discretization_config={"target": "sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization"})
+    model = OpenAIWrapper(net)
+    z = randn("sgm.z", (1, 4, 16, 16), 75)
+    c = {"crossattn": ctx[1:2], "vector": y[1:2]}
+    uc = {"crossattn": ctx[0:1], "vector": y[1:2]}
+    final = sampler(lambda xx, sigma, cc: denoiser(model, xx, sigma, cc), z.clone(), cond=c, uc=uc)
+    out["z"] = z.numpy()
+    out["loop_final"] = final.numpy()
+    np.savez_compressed(os.path.join(out_dir, "sgm_tiny.npz"), **out)
+    print("sgm_tiny:", {k: v.shape for k, v in out.items()}, "final abs mean", final.abs().mean().item())
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -366,5 +441,6 @@ if __name__ == "__main__":
     unet, ctrl, *_ = gen_networks(out_dir)
     gen_loop(out_dir, unet, ctrl)
     gen_leaf_ops(out_dir)
+    gen_sgm(out_dir)
     for f in sorted(os.listdir(out_dir)):
         print(f, os.path.getsize(os.path.join(out_dir, f)) // 1024, "KiB")

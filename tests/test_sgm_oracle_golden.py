@@ -1,0 +1,59 @@
+"""CPU: pin oracle/sgm_oracle.py and the sgm host logic against vectors produced by the reference's own sgm classes."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+GOLD = os.path.join(HERE, "golden", "sgm_tiny.npz")
+
+from neurons_amd.sgm import DiscreteDenoiser, LegacyDDPMDiscretization, SGMUNetConfig, sgm_random_state_dict, sgm_state_dict_schema  # noqa: E402
+from oracle import sgm_oracle as S  # noqa: E402
+from oracle.gen_golden import tiny_sgm_config  # noqa: E402
+
+
+def _close(name, got, want, tol=2e-4):
+    got, want = got.detach().float(), torch.as_tensor(want).float()
+    assert got.shape == want.shape
+    err, scale = (got - want).abs().max().item(), want.abs().max().item()
+    assert err <= tol * scale + 1e-6, f"{name}: {err:.3e} vs scale {scale:.3e}"
+
+
+@torch.no_grad()
+def test_unet_forward_matches_reference():
+    g = np.load(GOLD)
+    cfg = tiny_sgm_config()
+    sd = sgm_random_state_dict(cfg, seed=71)
+    eps = S.unet_forward(sd, cfg, torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), torch.from_numpy(g["ctx"]), torch.from_numpy(g["y"]))
+    _close("sgm eps", eps, g["eps"])
+
+
+def test_sigma_tables_match_reference():
+    g = np.load(GOLD)
+    for n in (38, 50):
+        assert np.allclose(S.legacy_ddpm_sigmas(n).numpy(), g[f"sigmas{n}"], rtol=1e-6, atol=0)
+        assert np.allclose(LegacyDDPMDiscretization()(n).numpy(), g[f"sigmas{n}"], rtol=1e-6, atol=0)
+    s = LegacyDDPMDiscretization()(38)
+    assert len(s) == 39 and abs(float(s[0]) - 14.61) < 0.01 and abs(float(s[-2]) - 0.158) < 1e-3 and float(s[-1]) == 0.0
+    den = DiscreteDenoiser()
+    sq, c_in, idx = den.scalars(float(s[0]))
+    assert sq == float(s[0]) and idx == 999 and abs(c_in - 1 / (sq * sq + 1) ** 0.5) < 1e-7
+
+
+@torch.no_grad()
+def test_euler_cfg_loop_matches_reference():
+    g = np.load(GOLD)
+    cfg = tiny_sgm_config()
+    sd = sgm_random_state_dict(cfg, seed=71)
+    ctx, y = torch.from_numpy(g["ctx"]), torch.from_numpy(g["y"])
+    c = {"crossattn": ctx[1:2], "vector": y[1:2]}
+    uc = {"crossattn": ctx[0:1], "vector": y[1:2]}
+    final = S.euler_edm_sample(sd, cfg, torch.from_numpy(g["z"]), c, uc, 4, 5.0)
+    _close("sgm 4-step loop", final, g["loop_final"], tol=2e-3)
+
+
+def test_full_size_schema_matches_survey():
+    sc = sgm_state_dict_schema(SGMUNetConfig())
+    assert abs(sum(int(np.prod(s)) for s in sc.values()) / 1e6 - 2501.3) < 0.1     # 2 501 M parameters
