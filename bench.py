@@ -42,7 +42,63 @@ def parse():
     ap.add_argument("--latent", type=int, default=32, help="latent side (pixels/8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--workload", choices=["video", "keyframe"], default="video",
+                    help="video = BASELINE config 2 (headline); keyframe = config 3: sgm unCLIP U-Net, Euler-EDM + CFG 5.0")
+    ap.add_argument("--keyframe-steps", type=int, default=50)
+    ap.add_argument("--keyframe-latent", type=int, default=64, help="64 = BASELINE config 3 (512 px); 96 = reference-faithful (768 px, 38 steps)")
     return ap.parse_args()
+
+
+def keyframe_main(args):
+    """BASELINE config 3 (single GPU): one keyframe = `keyframe_steps` x {sgm UNetModel on the CFG batch of 2 + fused
+    EDM/CFG/Euler update}.  Prints one JSON line with keyframes/s."""
+    import numpy as np
+    from neurons_amd.sgm import EulerEDMSampler, NativeSGMUNet, SGMUNetConfig, sgm_state_dict_schema
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    cfg = SGMUNetConfig()
+    g = torch.Generator(device=dev).manual_seed(3)
+    sd = {}
+    for k, shape in sgm_state_dict_schema(cfg).items():
+        z = torch.randn(shape, generator=g, device=dev)
+        if k.endswith(".bias"):
+            z = 0.02 * z
+        elif len(shape) == 1:
+            z = 1.0 + 0.1 * z
+        else:
+            z = z / (int(np.prod(shape[1:])) ** 0.5)
+        sd[k] = z.cpu()
+    net = NativeSGMUNet(cfg).to(dev)
+    net.load_state_dict(sd)
+    del sd
+    L = args.keyframe_latent
+    sampler = EulerEDMSampler(num_steps=args.keyframe_steps, scale=5.0)
+    items = []
+    for _ in range(args.warmup + args.steps):
+        items.append(dict(z=torch.randn(1, 4, L, L, generator=g, device=dev),
+                          c={"crossattn": torch.randn(1, 256, 1664, generator=g, device=dev), "vector": torch.randn(1, 1024, generator=g, device=dev)},
+                          uc={"crossattn": torch.randn(1, 256, 1664, generator=g, device=dev), "vector": torch.randn(1, 1024, generator=g, device=dev)}))
+    for it in items[:args.warmup]:
+        sampler(net, it["z"], cond=it["c"], uc=it["uc"])
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for it in items[args.warmup:]:
+        out = sampler(net, it["z"], cond=it["c"], uc=it["uc"])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t1
+    p = net.profile_last()
+    ig = p["igemm"]
+    print(json.dumps({
+        "metric": "unCLIP keyframes/sec (sgm UNetModel, Euler-EDM, CFG 5.0)", "value": round(args.steps / el, 4), "unit": "keyframes/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"BASELINE config 3: (1,4,{L},{L}) latent, {args.keyframe_steps} Euler steps, context 256x1664, "
+                               f"2 501 M-parameter UNetModel, random-init weights",
+                   "ms_per_euler_step": round(1e3 * el / args.steps / args.keyframe_steps, 3), "output_finite": bool(torch.isfinite(out).all())},
+        "roofline": {"bound": "mfma", "kernel": "igemm_bf16_kernel", "achieved": round(ig["flops"] / (ig["ms"] * 1e-3) / 1e12, 2),
+                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ig["flops"] / (ig["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                     "traffic": None, "per_class_ms_per_step": {k: round(v["ms"], 3) for k, v in p.items()},
+                     "algorithmic_tflop_per_step": round(sum(v["flops"] for v in p.values()) / 1e12, 3)}}))
 
 
 def gpu_random_state_dict(schema, seed, device):
@@ -68,6 +124,8 @@ def gpu_random_state_dict(schema, seed, device):
 
 def main():
     args = parse()
+    if args.workload == "keyframe":
+        return keyframe_main(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
