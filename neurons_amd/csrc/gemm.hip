@@ -239,6 +239,71 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
     }
     return;
   }
+  // Staged epilogue (whenever the fp32 C tile fits in the LDS ring): accumulators -> LDS (16-byte chunks
+  // XOR-swizzled with row&7: conflict-free both ways) -> each thread handles 8 consecutive output channels of one
+  // row, so bias / time-embedding / residual loads and the bf16 store are 16/32-byte accesses that cover whole
+  // 128..256-byte row segments (the direct path below writes 8 bytes per lane in 32-byte segments).
+  constexpr bool STAGED = (size_t)BM * BN * sizeof(float) <= (size_t)NS * TILE * sizeof(bf16);
+  if constexpr (STAGED) {
+    constexpr int NTH = 64 * NW;
+    float* sC = reinterpret_cast<float*>(smem);
+    __syncthreads();                       // every wave is done with the operand tiles
+    const int bno = p.geglu ? BN / 2 : BN; // output columns of this tile
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int row = wm * WM + j * 16 + fr;
+      if (!p.geglu) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+          const int c4 = ((wn * WN + i * 16) >> 2) + fg;
+          *(f32x4*)(sC + row * BN + ((c4 ^ (row & 7)) << 2)) = acc[i][j];
+        }
+      } else {
+        if constexpr (NT % 2 == 0) {
+#pragma unroll
+          for (int i = 0; i < NT; i += 2) {
+            const int nv = n0 + wn * WN + i * 16 + 4 * fg;
+            f32x4 v = acc[i][j], g = acc[i + 1][j];
+            if (p.bias && nv < p.N) { v += *(const f32x4*)(p.bias + nv); g += *(const f32x4*)(p.bias + nv + 16); }
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = v[e] * gelu_erf_fast(g[e]);
+            const int c4 = (((wn * WN + i * 16) >> 1) >> 2) + fg;
+            *(f32x4*)(sC + row * BN + ((c4 ^ (row & 7)) << 2)) = o;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const int c8n = bno >> 3;
+    const int nout = p.geglu ? p.N / 2 : p.N;
+    const int nb0 = p.geglu ? n0 / 2 : n0;
+    for (int idx = tid; idx < BM * c8n; idx += NTH) {
+      const int row = idx / c8n, c8 = idx - row * c8n;
+      const int m = m0 + row, n = nb0 + c8 * 8;
+      if (m >= p.M || n >= nout) continue;
+      f32x4 va = *(const f32x4*)(sC + row * BN + (((2 * c8) ^ (row & 7)) << 2));
+      f32x4 vb = *(const f32x4*)(sC + row * BN + (((2 * c8 + 1) ^ (row & 7)) << 2));
+      if (!p.geglu) {
+        if (p.bias) { va += *(const f32x4*)(p.bias + n); vb += *(const f32x4*)(p.bias + n + 4); }
+        if (p.rowvec) {
+          const float* rv = p.rowvec + (size_t)(m / p.rowvec_div) * p.rowvec_ld + n;
+          va += *(const f32x4*)rv; vb += *(const f32x4*)(rv + 4);
+        }
+        va *= p.out_scale; vb *= p.out_scale;
+        if (p.res) {
+          const bf16x8 r = *(const bf16x8*)(p.res + (size_t)m * p.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { va[e] += (float)r[e]; vb[e] += (float)r[4 + e]; }
+        }
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[e] = (bf16)va[e]; o[4 + e] = (bf16)vb[e]; }
+      *(bf16x8*)(p.out + (size_t)m * p.ldo + n) = o;
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
     const int m = m0 + wm * WM + j * 16 + fr;
