@@ -22,6 +22,8 @@ __global__ __launch_bounds__(256) void conv_in_small_kernel(const float* __restr
                                                             const float* __restrict__ wT, const float* __restrict__ bias,
                                                             const float* __restrict__ addend, int Cout,
                                                             bf16* __restrict__ out, float in_scale) {
+  // thread = one output channel (coalesced weight reads and output stores), register-blocked over 8 pixels of the
+  // row; the 3-row input patch sits in LDS and is read as wave-uniform broadcasts.
   extern __shared__ float patch[];
   const int Cin = c0 + c1;
   const int y = blockIdx.x, n = blockIdx.y;
@@ -42,16 +44,24 @@ __global__ __launch_bounds__(256) void conv_in_small_kernel(const float* __restr
   }
   __syncthreads();
   const int K = Cin * 9;
-  for (int idx = threadIdx.x; idx < W * Cout; idx += 256) {
-    const int x = idx / Cout, co = idx - x * Cout;
-    float acc = bias[co];
-    for (int k = 0; k < K; ++k) {
-      const int ci = k / 9, t = k - ci * 9;
-      const int ky = t / 3, kx = t - ky * 3;
-      acc += wT[(size_t)k * Cout + co] * patch[(ci * 3 + ky) * PW + x + kx];
+  for (int co = threadIdx.x; co < Cout; co += 256) {
+    const float b0 = bias[co] + (addend ? addend[co] : 0.f);
+    for (int x0 = 0; x0 < W; x0 += 8) {
+      float acc[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = b0;
+      for (int k = 0; k < K; ++k) {
+        const int ci = k / 9, t = k - ci * 9;
+        const int ky = t / 3, kx = t - ky * 3;
+        const float w = wT[(size_t)k * Cout + co];
+        const float* pr = patch + (ci * 3 + ky) * PW + x0 + kx;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += w * pr[e];   // pr[e] beyond W+1 only when x0+e >= W (masked at the store)
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (x0 + e < W) out[(((size_t)n * H + y) * W + x0 + e) * Cout + co] = (bf16)acc[e];
     }
-    if (addend) acc += addend[co];
-    out[(((size_t)n * H + y) * W + x) * Cout + co] = (bf16)acc;
   }
 }
 
@@ -206,7 +216,7 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ a, bf16* __restrict
 extern "C" int nr_launch_conv_in_small(const float* s0, const float* s1, int c0, int c1, int src_batch, int nimg, int F,
                                        int H, int W, const float* wT, const float* bias, const float* addend, int Cout,
                                        bf16* out, float in_scale, hipStream_t stream) {
-  const size_t shm = (size_t)(c0 + c1) * 3 * (W + 2) * sizeof(float);
+  const size_t shm = ((size_t)(c0 + c1) * 3 * (W + 2) + 16) * sizeof(float);   // +16: masked over-read of the last row
   if (shm > 60000) return 1;
   hipLaunchKernelGGL(conv_in_small_kernel, dim3(H, nimg), dim3(256), shm, stream, s0, s1, c0, c1, src_batch, F, H, W, wT,
                      bias, addend, Cout, out, in_scale);

@@ -387,9 +387,10 @@ Plan choose_plan(const NrGemmParams& p) {
   Plan pl;
   pl.splitk = 1; pl.stages = 2; pl.waves = 4;
   const bool n128 = p.N % 128 == 0 || p.N >= 960;          // <= 6 % padded columns otherwise
-  if (!p.geglu && p.N % 160 == 0 && p.N < 960 && p.N % 128 != 0 && nblk(128, 160) >= 256) { pl.bm = 128; pl.bn = 160; }
-  else if (n128 && nblk(128, 128) >= 256) { pl.bm = 128; pl.bn = 128; pl.waves = 8; }
-  else if (nblk(128, 64) >= 256) { pl.bm = 128; pl.bn = 64; }
+  if (!p.geglu && p.N % 160 == 0 && p.N < 960 && p.N % 128 != 0 && nk >= 20 && nblk(128, 160) >= 256) { pl.bm = 128; pl.bn = 160; }
+  else if (n128 && nblk(128, 128) >= 512) { pl.bm = 128; pl.bn = 128; pl.waves = 8; }
+  else if (nblk(128, 64) >= 512 || (nblk(128, 64) >= 256 && nk > 32)) { pl.bm = 128; pl.bn = 64; pl.waves = nk <= 32 ? 8 : 4; }
+  else if (nblk(64, 64) >= 256 && nk <= 96) { pl.bm = 64; pl.bn = 64; }
   else if (p.M >= 1024 && nblk(128, 64) >= 64) { pl.bm = 128; pl.bn = 64; }
   else { pl.bm = 64; pl.bn = 64; }
   if (!p.geglu) {

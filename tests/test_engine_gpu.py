@@ -139,3 +139,27 @@ def test_wider_unet_vs_oracle(cuda, boc, F, hw, ctxd):
         ref = O.unet3d_forward({k: v.cuda() for k, v in sd.items()}, O.OracleConfig.from_native(cfg), sample, 501, ctx)
     rel, psnr = metrics(f"unet {boc} F{F} {hw}x{hw} vs oracle", eps, ref)
     assert rel < 2.5e-2 and psnr > 35
+
+
+def test_batch_of_clips_equals_independent_clips(cuda):
+    """BASELINE config 4 runs several clips per GPU.  The reference's SparseCtrl only broadcasts a batch-1 condition
+    (sparse_controlnet.py:521); here B clips in one call must equal B independent B=1 calls bit-for-bit
+    in layout (CFG order: [uncond clips..., text clips...]) and to rounding in value."""
+    from neurons_amd import DDIMScheduler, NeuroclipsPipeline
+    from neurons_amd.synth import randn
+    unet, ctrl = _tiny()
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
+    pipe = NeuroclipsPipeline(None, None, None, unet, sched, ctrl).to("cuda")
+    B = 2
+    lat = randn("b.lat", (B, 4, 8, 8, 8), 1).cuda()
+    noise = randn("b.noise", (B, 4, 8, 8, 8), 2)
+    ctx_u, ctx_t = randn("b.ctxu", (B, 77, 64), 3), randn("b.ctxt", (B, 77, 64), 4)
+    cimg = (randn("b.cimg", (B, 4, 1, 8, 8), 5) * 0.18215).cuda()
+    kw = dict(video_length=8, height=64, width=64, num_inference_steps=3, guidance_scale=8.5, controlnet_image_index=[0],
+              low_strength=0.3, output_type="latent")
+    both = pipe([""] * B, latents=lat, noise=noise, text_embeddings=torch.cat([ctx_u, ctx_t]).cuda(), controlnet_images=cimg, **kw).videos
+    for i in range(B):
+        one = pipe("", latents=lat[i:i + 1], noise=noise[i:i + 1], text_embeddings=torch.cat([ctx_u[i:i + 1], ctx_t[i:i + 1]]).cuda(),
+                   controlnet_images=cimg[i:i + 1], **kw).videos
+        rel, psnr = metrics(f"clip {i} of a batch of {B} vs alone", both[i:i + 1], one)
+        assert psnr > 60, "batched and independent clips must agree (same kernels, only tile boundaries differ)"
