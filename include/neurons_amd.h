@@ -133,6 +133,16 @@ nr_status nr_sparsectrl_forward(nr_net* h, nr_stream stream, const float* sample
                                 const float* ctx_dev, int32_t ctx_len, const float* cond_dev, const float* mask_dev,
                                 int32_t cond_batch, float scale, void* const* out_down_dev, void* out_mid_dev);
 
+/* One denoising-step network evaluation = SparseControlNetModel.forward followed by UNet3DConditionModel.forward
+ * (pipeline_neuroclips.py:460-475) in ONE call: SparseCtrl runs on its own stream concurrently with the U-Net's
+ * encoder + mid block (which do not depend on it); the residual adds and the decoder wait for it.  Same results as
+ * nr_sparsectrl_forward + nr_unet3d_forward.  res_*_dev: caller-owned channels-last bf16 residual buffers
+ * (written by SparseCtrl, read by the U-Net).  Requires set_noisy_sample_input_to_zero (sample is not read by SparseCtrl). */
+nr_status nr_denoise_step_forward(nr_net* unet, nr_net* ctrl, nr_stream stream, const float* sample_dev,
+                                  const float* timesteps, const float* ctx_dev, int32_t ctx_len, const float* cond_dev,
+                                  const float* mask_dev, int32_t cond_batch, float scale, void* const* res_down_dev,
+                                  void* res_mid_dev, float* out_dev);
+
 /* replaces OpenAIWrapper.forward -> UNetModel.forward (sgm/modules/diffusionmodules/wrappers.py:23-34,
  * openaimodel.py:816-853).  x_dev fp32 [batch][4][h][w] is multiplied by in_scale (= c_in of
  * denoiser.py:36-39) on the fly; timesteps = c_noise (host fp32 [batch]); ctx_dev fp32 [batch][ctx_len][context_dim]

@@ -199,8 +199,9 @@ struct nr_net {
 
   // graph
   bool use_graph = false;
-  hipGraphExec_t gexec = nullptr;
-  IO captured;
+  hipGraphExec_t gexec[2] = {nullptr, nullptr};   // [0] ops before the ControlNet-residual adds, [1] the rest
+  IO captured[2];
+  size_t split_op = 0;                            // index of the first op of segment 1 (== ops.size() if none)
   // graph replay happens on an engine-owned non-blocking stream (capture is illegal on the legacy default
   // stream PyTorch hands over); it is fenced to the caller's stream with two events per forward
   hipStream_t own_stream = nullptr;
@@ -209,7 +210,7 @@ struct nr_net {
   ~nr_net() {
     for (auto& kv : dev) if (kv.second) (void)hipFree(kv.second);
     if (arena_base) (void)hipFree(arena_base);
-    if (gexec) (void)hipGraphExecDestroy(gexec);
+    for (auto& g : gexec) if (g) (void)hipGraphExecDestroy(g);
     if (ev_in) (void)hipEventDestroy(ev_in);
     if (ev_out) (void)hipEventDestroy(ev_out);
     if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -974,7 +975,9 @@ struct nr_net {
       return;
     }
 
-    // ---- ControlNet residual adds (unet.py:422-428,436-439) ----
+    // ---- ControlNet residual adds (unet.py:422-428,436-439).  Everything above is independent of the ControlNet,
+    // so segment 0 can run concurrently with it (nr_denoise_step_forward) ----
+    split_op = ops.size();
     {
       std::vector<Act> added(skips.size());
       for (int i = 0; i < n_res; ++i) {
@@ -1031,7 +1034,7 @@ struct nr_net {
     if (h % down != 0 || w % down != 0)
       throw NrError(NR_ERR_ARG, "plan: latent h,w must be multiples of " + std::to_string(down));
     HIP_OK(hipDeviceSynchronize());
-    if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
+    for (auto& g : gexec) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     B2 = batch; F = frames; H = h; W = w; ctx_len = ctxl;
     planned = false;
     // pass 1: sizes only
@@ -1047,46 +1050,62 @@ struct nr_net {
       arena_bytes = need_bytes;
     }
     // pass 2: real pointers, weights uploaded
+    split_op = 0;
     build();
+    if (split_op == 0 || split_op > ops.size()) split_op = ops.size();
     HIP_OK(hipDeviceSynchronize());
     planned = true;
   }
 
-  void run(hipStream_t caller, const float* timesteps) {
-    TimestepVals tv;
-    for (int i = 0; i < 16; ++i) tv.v[i] = i < B2 ? timesteps[i] : 0.f;
-    if (!use_graph) {
-      hipLaunchKernelGGL(set_timesteps_kernel, dim3(1), dim3(64), 0, caller, t_dev, tv, B2);
-      for (auto& op : ops) op(caller);
-      return;
-    }
+  void ensure_streams() {
     if (!own_stream) {
       HIP_OK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
       HIP_OK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
       HIP_OK(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
     }
-    hipStream_t s = own_stream;
-    HIP_OK(hipEventRecord(ev_in, caller));
-    HIP_OK(hipStreamWaitEvent(s, ev_in, 0));
+  }
+  void set_timesteps(hipStream_t s, const float* timesteps) {
+    TimestepVals tv;
+    for (int i = 0; i < 16; ++i) tv.v[i] = i < B2 ? timesteps[i] : 0.f;
     hipLaunchKernelGGL(set_timesteps_kernel, dim3(1), dim3(64), 0, s, t_dev, tv, B2);
-    if (!gexec || !(captured == io)) {
-      if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
+  }
+  // launch ops [begin, end) of segment `seg` on `s` as a (re)captured hipGraph
+  void launch_segment(hipStream_t s, int seg) {
+    const size_t begin = seg == 0 ? 0 : split_op, end = seg == 0 ? split_op : ops.size();
+    if (begin >= end) return;
+    if (!gexec[seg] || !(captured[seg] == io)) {
+      if (gexec[seg]) { (void)hipGraphExecDestroy(gexec[seg]); gexec[seg] = nullptr; }
       hipGraph_t g = nullptr;
       HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
       try {
-        for (auto& op : ops) op(s);
+        for (size_t i = begin; i < end; ++i) ops[i](s);
       } catch (...) {
         (void)hipStreamEndCapture(s, &g);
         if (g) (void)hipGraphDestroy(g);
         throw;
       }
       HIP_OK(hipStreamEndCapture(s, &g));
-      hipError_t e = hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0);
+      hipError_t e = hipGraphInstantiate(&gexec[seg], g, nullptr, nullptr, 0);
       (void)hipGraphDestroy(g);
-      if (e != hipSuccess) { gexec = nullptr; throw NrError(NR_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
-      captured = io;
+      if (e != hipSuccess) { gexec[seg] = nullptr; throw NrError(NR_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+      captured[seg] = io;
     }
-    HIP_OK(hipGraphLaunch(gexec, s));
+    HIP_OK(hipGraphLaunch(gexec[seg], s));
+  }
+
+  void run(hipStream_t caller, const float* timesteps) {
+    if (!use_graph) {
+      set_timesteps(caller, timesteps);
+      for (auto& op : ops) op(caller);
+      return;
+    }
+    ensure_streams();
+    hipStream_t s = own_stream;
+    HIP_OK(hipEventRecord(ev_in, caller));
+    HIP_OK(hipStreamWaitEvent(s, ev_in, 0));
+    set_timesteps(s, timesteps);
+    launch_segment(s, 0);
+    launch_segment(s, 1);
     HIP_OK(hipEventRecord(ev_out, s));
     HIP_OK(hipStreamWaitEvent(caller, ev_out, 0));
   }
@@ -1261,6 +1280,59 @@ extern "C" nr_status nr_sparsectrl_forward(nr_net* h, nr_stream stream, const fl
   io.out_mid = out_mid_dev;
   h->io = io;
   h->run((hipStream_t)stream, timesteps);
+  NR_CATCH
+}
+
+extern "C" nr_status nr_denoise_step_forward(nr_net* unet, nr_net* ctrl, nr_stream stream, const float* sample_dev,
+                                             const float* timesteps, const float* ctx_dev, int32_t ctx_len,
+                                             const float* cond_dev, const float* mask_dev, int32_t cond_batch, float scale,
+                                             void* const* res_down_dev, void* res_mid_dev, float* out_dev) {
+  NR_TRY
+  if (!unet || unet->cfg.kind != NR_KIND_UNET3D || !ctrl || ctrl->cfg.kind != NR_KIND_SPARSECTRL) throw NrError(NR_ERR_ARG, "need a UNet3D and a SparseCtrl handle");
+  if (!unet->planned || !ctrl->planned) throw NrError(NR_ERR_STATE, "nr_net_plan() has not been called on both handles");
+  if (!sample_dev || !timesteps || !ctx_dev || !cond_dev || !mask_dev || !res_down_dev || !res_mid_dev || !out_dev) throw NrError(NR_ERR_ARG, "null tensor argument");
+  if (ctx_len != unet->ctx_len || ctx_len != ctrl->ctx_len) throw NrError(NR_ERR_ARG, "ctx_len differs from the planned value");
+  if (unet->n_res != ctrl->n_res || unet->B2 != ctrl->B2 || unet->F != ctrl->F || unet->H != ctrl->H || unet->W != ctrl->W)
+    throw NrError(NR_ERR_ARG, "the two handles are planned for different shapes");
+  if (!ctrl->cfg.set_noisy_sample_input_to_zero) throw NrError(NR_ERR_UNSUPPORTED, "overlapped step requires set_noisy_sample_input_to_zero");
+  if (cond_batch <= 0 || ctrl->B2 % cond_batch != 0) throw NrError(NR_ERR_ARG, "cond_batch must divide the planned batch");
+  hipStream_t caller = (hipStream_t)stream;
+  IO ic;
+  std::memset(&ic, 0, sizeof(ic));
+  ic.ctx = ctx_dev; ic.cond = cond_dev; ic.mask = mask_dev; ic.cond_batch = cond_batch; ic.scale = scale; ic.in_scale = 1.f;
+  IO iu;
+  std::memset(&iu, 0, sizeof(iu));
+  iu.sample = sample_dev; iu.ctx = ctx_dev; iu.out = out_dev; iu.scale = 1.f; iu.cond_batch = 1; iu.in_scale = 1.f; iu.has_res = 1;
+  for (int i = 0; i < ctrl->n_res; ++i) {
+    if (!res_down_dev[i]) throw NrError(NR_ERR_ARG, "null residual pointer");
+    ic.out_down[i] = res_down_dev[i];
+    iu.down_res[i] = res_down_dev[i];
+  }
+  ic.out_mid = res_mid_dev; iu.mid_res = res_mid_dev;
+  ctrl->io = ic; unet->io = iu;
+  if (!unet->use_graph || !ctrl->use_graph) {   // eager: plain sequential launches on the caller's stream
+    ctrl->set_timesteps(caller, timesteps);
+    for (auto& op : ctrl->ops) op(caller);
+    unet->set_timesteps(caller, timesteps);
+    for (auto& op : unet->ops) op(caller);
+  } else {
+    unet->ensure_streams(); ctrl->ensure_streams();
+    HIP_OK(hipEventRecord(unet->ev_in, caller));
+    HIP_OK(hipStreamWaitEvent(unet->own_stream, unet->ev_in, 0));
+    HIP_OK(hipStreamWaitEvent(ctrl->own_stream, unet->ev_in, 0));
+    // SparseCtrl on its stream ...
+    ctrl->set_timesteps(ctrl->own_stream, timesteps);
+    ctrl->launch_segment(ctrl->own_stream, 0);
+    ctrl->launch_segment(ctrl->own_stream, 1);
+    HIP_OK(hipEventRecord(ctrl->ev_out, ctrl->own_stream));
+    // ... concurrently with the U-Net's encoder + mid block; the residual adds + decoder wait for SparseCtrl
+    unet->set_timesteps(unet->own_stream, timesteps);
+    unet->launch_segment(unet->own_stream, 0);
+    HIP_OK(hipStreamWaitEvent(unet->own_stream, ctrl->ev_out, 0));
+    unet->launch_segment(unet->own_stream, 1);
+    HIP_OK(hipEventRecord(unet->ev_out, unet->own_stream));
+    HIP_OK(hipStreamWaitEvent(caller, unet->ev_out, 0));
+  }
   NR_CATCH
 }
 

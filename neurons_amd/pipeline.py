@@ -58,6 +58,7 @@ class NeuroclipsPipeline:
             self.vae_scale_factor = 8
         self._progress_bar_config = {}
         self._device = torch.device("cpu")
+        self.overlap_controlnet = True   # run SparseCtrl concurrently with the U-Net encoder (nr_denoise_step_forward)
 
     # ---- DiffusionPipeline surface used by the scripts (SURVEY §8c "Python harness rows") ----
     def register_modules(self, **kwargs):
@@ -254,14 +255,22 @@ class NeuroclipsPipeline:
                 latent_model_input = torch.cat([latents] * 2) if do_classifier_free_guidance else latents
                 latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)
                 down_res = mid_res = None
-                if use_ctrl:
+                fused = use_ctrl and hasattr(self.unet, "forward_with_controlnet") and \
+                    getattr(self.controlnet, "set_noisy_sample_input_to_zero", False) and self.overlap_controlnet
+                if fused:
+                    # same two network evaluations (:460-475), issued as one library call that overlaps them
+                    noise_pred = self.unet.forward_with_controlnet(
+                        self.controlnet, latent_model_input, t, text_embeddings, controlnet_cond,
+                        controlnet_conditioning_mask, controlnet_conditioning_scale).sample
+                elif use_ctrl:
                     down_res, mid_res = self.controlnet(
                         latent_model_input, t, encoder_hidden_states=text_embeddings, controlnet_cond=controlnet_cond,
                         conditioning_mask=controlnet_conditioning_mask, conditioning_scale=controlnet_conditioning_scale,
                         guess_mode=False, return_dict=False)
-                noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=text_embeddings,
-                                       down_block_additional_residuals=down_res,
-                                       mid_block_additional_residual=mid_res).sample
+                if not fused:
+                    noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=text_embeddings,
+                                           down_block_additional_residuals=down_res,
+                                           mid_block_additional_residual=mid_res).sample
                 # CFG combine + DDIM step fused in one HIP kernel (reference: :478-483)
                 a_t, a_prev = self.scheduler.alpha_pair(t)
                 new_latents = torch.empty_like(latents)

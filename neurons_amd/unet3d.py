@@ -452,6 +452,40 @@ class NativeUNet3D(_NativeNet):
 
     __call__ = forward
 
+    def forward_with_controlnet(self, controlnet, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_mask,
+                                conditioning_scale: float = 1.0):
+        """``controlnet(...)`` then ``self(..., down_block_additional_residuals=..., mid_block_additional_residual=...)``
+        (pipeline_neuroclips.py:460-475) as ONE library call that overlaps SparseCtrl with the U-Net encoder
+        (C ABI ``nr_denoise_step_forward``).  Returns the same ``.sample`` tensor as the two separate calls."""
+        if not sample.is_cuda:
+            raise RuntimeError("forward_with_controlnet: CUDA (ROCm) tensors required; there is no CPU fallback")
+        b, c, f, h, w = sample.shape
+        ctx = encoder_hidden_states
+        if ctx.shape[0] != b:
+            raise ValueError("encoder_hidden_states batch must equal the sample batch")
+        cb = controlnet_cond.shape[0]
+        if b % cb != 0 or conditioning_mask.shape[0] != cb:
+            raise ValueError("controlnet_cond batch must divide the sample batch")
+        L = ctx.shape[1]
+        self._ensure_plan(b, f, h, w, L)
+        controlnet._ensure_plan(b, f, h, w, L)
+        self._io_sample.copy_(sample)
+        self._io_ctx.copy_(ctx)
+        if controlnet._io_cond is None or controlnet._io_cond.shape[0] != cb:
+            controlnet._io_cond = torch.empty(cb, controlnet.config.conditioning_channels, f, h, w, dtype=torch.float32, device=sample.device)
+            controlnet._io_mask = torch.empty(cb, 1, f, h, w, dtype=torch.float32, device=sample.device)
+        controlnet._io_cond.copy_(controlnet_cond)
+        controlnet._io_mask.copy_(conditioning_mask)
+        ts = self._timesteps_host(timestep, b)
+        n = len(controlnet._out_bufs) - 1
+        lib = _lib.load()
+        _lib.check(lib.nr_denoise_step_forward(self._h, controlnet._h, torch.cuda.current_stream().cuda_stream,
+                                               self._io_sample.data_ptr(), ts, self._io_ctx.data_ptr(), L,
+                                               controlnet._io_cond.data_ptr(), controlnet._io_mask.data_ptr(), cb,
+                                               float(conditioning_scale), controlnet._out_ptrs,
+                                               controlnet._out_bufs[n].data_ptr(), self._io_out.data_ptr()))
+        return UNet3DConditionOutput(sample=self._io_out.clone())
+
     def _on_plan(self):
         b, f, h, w, L = self._plan_key
         dev = torch.device("cuda", torch.cuda.current_device())

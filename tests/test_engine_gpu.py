@@ -163,3 +163,19 @@ def test_batch_of_clips_equals_independent_clips(cuda):
                    controlnet_images=cimg[i:i + 1], **kw).videos
         rel, psnr = metrics(f"clip {i} of a batch of {B} vs alone", both[i:i + 1], one)
         assert psnr > 60, "batched and independent clips must agree (same kernels, only tile boundaries differ)"
+
+
+def test_overlapped_step_equals_separate_calls(cuda):
+    """nr_denoise_step_forward (SparseCtrl overlapped with the U-Net encoder on two streams) must give exactly the
+    result of controlnet(...) followed by unet(..., residuals)."""
+    g = np.load(os.path.join(GOLD, "tiny_networks.npz"))
+    unet, ctrl = _tiny()
+    sample, ctx = torch.from_numpy(g["sample"]).cuda(), torch.from_numpy(g["ctx"]).cuda()
+    cond, mask = torch.from_numpy(g["cond"]).cuda(), torch.from_numpy(g["mask"]).cuda()
+    down, mid = ctrl(sample, int(g["t"]), encoder_hidden_states=ctx, controlnet_cond=cond, conditioning_mask=mask, return_dict=False)
+    a = unet(sample, int(g["t"]), encoder_hidden_states=ctx, down_block_additional_residuals=down, mid_block_additional_residual=mid).sample
+    for _ in range(3):
+        b = unet.forward_with_controlnet(ctrl, sample, int(g["t"]), ctx, cond, mask, 1.0).sample
+        assert torch.equal(a, b)
+    rel, psnr = metrics("overlapped step vs reference golden", b, g["eps_ctrl"])
+    assert rel < 2.5e-2
