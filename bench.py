@@ -228,7 +228,7 @@ def main():
                        "hip_graph": not args.no_graph, "output_finite": finite, "setup_s": round(setup_s, 1)},
             "roofline": {"bound": "mfma", "kernel": "igemm_bf16_kernel (3x3/1x1 conv + Linear)", "achieved": round(achieved, 2),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                         "traffic": None, "launches_per_ddim_step": ig_n, "ms_per_ddim_step": round(ig_ms, 3),
+                         "traffic": pmc_traffic(), "launches_per_ddim_step": ig_n, "ms_per_ddim_step": round(ig_ms, 3),
                          "algorithmic_tflop_per_ddim_step": round(ig_fl / 1e12, 3),
                          "per_class_ms_per_ddim_step": breakdown,
                          "whole_step_algorithmic": {"tflop": round(step_flops / 1e12, 3), "gbytes": round(step_bytes / 1e9, 2)}},
@@ -240,6 +240,20 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+
+
+def pmc_traffic():
+    """HBM bytes of the igemm kernel class per DDIM step from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): bench.py cannot
+    run the profiler itself, so it reports the most recent committed measurement, or null."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_pmc.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    return {"igemm_hbm_gbytes_per_ddim_step": round(d["igemm_hbm_bytes_per_ddim_step"] / 1e9, 2),
+            "whole_step_hbm_gbytes": round(d["whole_step_hbm_bytes"] / 1e9, 2), "source": os.path.basename(files[-1])}
 
 
 def cpu_baseline(host_sd, ucfg, ccfg, args):
