@@ -119,6 +119,55 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(NrGnParams p) {
   }
 }
 
+// Small-image GroupNorm(+SiLU) in ONE launch (the 8x8 and 4x4 levels, where the two-kernel version is pure launch
+// latency): one workgroup per (image, group).  The group's hw x cg elements (<= 48 bf16 pairs per thread) are read
+// once into registers, reduced with a fixed-order wave/LDS tree (deterministic), normalised and written.
+template <int MAXP>
+__global__ __launch_bounds__(256) void gn_fused_small_kernel(NrGnParams p) {
+  __shared__ float red[2][4];
+  const int C = p.c0 + p.c1;
+  const int cg = C / p.groups;
+  const int hp = cg >> 1;                       // bf16 pairs per pixel of this group
+  const int img = blockIdx.y, g = blockIdx.x;
+  const int cbase = g * cg;
+  const int total = p.hw * hp;
+  const int tid = threadIdx.x;
+  bf16x2 v[MAXP];
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const int idx = tid + 256 * i;
+    if (idx < total) {
+      const int px = idx / hp, c = cbase + ((idx - px * hp) << 1);
+      const bf16* src = c < p.c0 ? p.x0 + ((size_t)img * p.hw + px) * p.ld0 + c
+                                 : p.x1 + ((size_t)img * p.hw + px) * p.ld1 + (c - p.c0);
+      v[i] = *(const bf16x2*)src;
+      const float a = (float)v[i][0], b = (float)v[i][1];
+      s += a + b; q += a * a + b * b;
+    }
+  }
+  s = wave_sum(s); q = wave_sum(q);
+  if ((tid & 63) == 0) { red[0][tid >> 6] = s; red[1][tid >> 6] = q; }
+  __syncthreads();
+  s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+  q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  const float inv = 1.0f / ((float)cg * (float)p.hw);
+  const float mean = s * inv;
+  const float rstd = rsqrtf(fmaxf(q * inv - mean * mean, 0.f) + p.eps);
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const int idx = tid + 256 * i;
+    if (idx < total) {
+      const int px = idx / hp, c = cbase + ((idx - px * hp) << 1);
+      float a = ((float)v[i][0] - mean) * rstd * p.gamma[c] + p.beta[c];
+      float b = ((float)v[i][1] - mean) * rstd * p.gamma[c + 1] + p.beta[c + 1];
+      if (p.silu) { a = silu_f(a); b = silu_f(b); }
+      bf16x2 o; o[0] = (bf16)a; o[1] = (bf16)b;
+      *(bf16x2*)(p.out + ((size_t)img * p.hw + px) * p.ldo + c) = o;
+    }
+  }
+}
+
 // LayerNorm over the last dim C (C % 8 == 0).  TPR threads cooperate on one row (TPR in {8,16,32,64}, each
 // thread holds <= MAXV 16-byte chunks), 256/TPR rows per block: every lane is busy and has 2-3 loads in
 // flight even at C = 320 (640-byte rows).  Two-pass statistics in registers (mean, then centred variance).
@@ -216,6 +265,18 @@ extern "C" int nr_launch_groupnorm(NrGnParams* pp, hipStream_t stream) {
   const int C = p.c0 + p.c1;
   if (C % 8 != 0 || C % p.groups != 0 || p.groups > 64) return 1;
   if (p.x1 && p.c0 % 8 != 0) return 2;
+  {
+    // small images: single fused launch (needs an even channels-per-group and an even split point of the concat)
+    const int cg = C / p.groups;
+    const long long pairs = (long long)p.hw * (cg / 2);
+    if (p.hw <= 64 && cg % 2 == 0 && p.c0 % 2 == 0 && pairs <= 256LL * 48) {
+      dim3 grid(p.groups, p.nimg);
+      if (pairs <= 256LL * 8) hipLaunchKernelGGL((gn_fused_small_kernel<8>), grid, dim3(256), 0, stream, p);
+      else if (pairs <= 256LL * 16) hipLaunchKernelGGL((gn_fused_small_kernel<16>), grid, dim3(256), 0, stream, p);
+      else hipLaunchKernelGGL((gn_fused_small_kernel<48>), grid, dim3(256), 0, stream, p);
+      return 0;
+    }
+  }
   nr_gn_workspace_floats(p.nimg, p.hw, p.groups, &p.pix_per_blk, &p.nchunk);
   const int CP = C / 8;
   const int PL = CP <= 256 ? 256 / CP : 1;
