@@ -99,6 +99,11 @@ nr_status nr_net_plan(nr_net* h, int32_t batch, int32_t frames, int32_t lat_h, i
  * device weights stay.  Re-planning with another shape keeps working; loading new tensors re-converts. */
 nr_status nr_net_release_host_weights(nr_net* h);
 
+/* The cross-attention context (encoder_hidden_states / "crossattn") is constant over the denoising steps of a clip:
+ * its bf16 copy and every to_k|to_v projection are computed on the first forward and reused until this is called.
+ * Call it whenever the CONTENTS behind ctx_dev change (a new pointer value alone is not detected). */
+nr_status nr_net_invalidate_context(nr_net* h);
+
 /* 1: run forward as a captured hipGraph (re-captured when an I/O pointer changes); 0: eager launches */
 nr_status nr_net_set_graph(nr_net* h, int32_t enable);
 

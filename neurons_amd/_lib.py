@@ -64,6 +64,7 @@ SYMBOLS = {
     "nr_net_load_tensor": (_I32, [_VP, C.c_char_p, _VP, C.POINTER(_I64), _I32]),
     "nr_net_plan": (_I32, [_VP, _I32, _I32, _I32, _I32, _I32]),
     "nr_net_release_host_weights": (_I32, [_VP]),
+    "nr_net_invalidate_context": (_I32, [_VP]),
     "nr_net_set_graph": (_I32, [_VP, _I32]),
     "nr_net_workspace_bytes": (_I64, [_VP]),
     "nr_net_weight_bytes": (_I64, [_VP]),

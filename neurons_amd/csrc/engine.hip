@@ -184,6 +184,12 @@ struct nr_net {
   char* arena_base = nullptr;
   size_t arena_bytes = 0;
   std::vector<std::function<void(hipStream_t)>> ops;
+  // ops that depend only on the cross-attention context (fp32->bf16 convert + every to_k|to_v projection): the
+  // context is constant over all denoising steps of a clip, so they run once per context (nr_net_invalidate_context)
+  std::vector<std::function<void(hipStream_t)>> ctx_ops;
+  std::vector<Act> ctx_persist;      // K|V buffers that must survive between forwards
+  bool building_ctx = false;
+  bool ctx_dirty = true;
   struct OpMeta { int kind; double flops, bytes; std::string desc; };
   std::vector<OpMeta> op_meta;   // parallel to ops: kernel class + algorithmic work (for roofline reporting)
   std::vector<Tap> taps;
@@ -377,6 +383,7 @@ struct nr_net {
   void emit(std::function<void(hipStream_t)> fn, int kind = NR_PROF_OTHER, double flops = 0, double bytes = 0,
             const std::string& desc = std::string()) {
     if (dry) return;
+    if (building_ctx) { ctx_ops.push_back(std::move(fn)); return; }
     ops.push_back(std::move(fn));
     op_meta.push_back(OpMeta{kind, flops, bytes, desc});
   }
@@ -594,7 +601,10 @@ struct nr_net {
         Act q = linear(n2, w_linear(b + ".attn2.to_q.weight", C, C), C, oq);
         n2 = Act();
         GemmOpt ok;
+        building_ctx = true;      // K|V of the context: recomputed only when the context changes
         Act kv = linear(ctx_bf, w_linear_cat({b + ".attn2.to_k.weight", b + ".attn2.to_v.weight"}, C, cfg.cross_attention_dim), 2 * C, ok);
+        building_ctx = false;
+        ctx_persist.push_back(kv);
         Act a = attention(1, q, &kv, C, heads);
         q = Act(); kv = Act();
         GemmOpt oo; oo.bias = w_f32(b + ".attn2.to_out.0.bias", C); oo.res = &t; oo.out = &t;
@@ -696,7 +706,8 @@ struct nr_net {
     const int nimg = B2 * F;
     if (F != 1) throw NrError(NR_ERR_ARG, "sgm UNetModel is a 2-D network: plan with frames = 1");
     const SgmLayout lay = sgm_layout();
-    ops.clear(); op_meta.clear(); taps.clear(); arena.reset();
+    ctx_persist.clear(); ops.clear(); ctx_ops.clear(); op_meta.clear(); taps.clear(); arena.reset();
+    ctx_dirty = true;
     temb_slots.clear();
     {
       int off = 0;
@@ -759,7 +770,10 @@ struct nr_net {
     Act ctx_bf = new_act(1, 1, B2 * ctx_len, cfg.cross_attention_dim);
     {
       bf16* cp = ctx_bf.ptr; const long long n = (long long)B2 * ctx_len * cfg.cross_attention_dim;
+      building_ctx = true;
       emit([this, cp, n](hipStream_t s) { LAUNCH_OK(nr_launch_f32_to_bf16(io.ctx, cp, n, s)); });
+      building_ctx = false;
+      ctx_persist.push_back(ctx_bf);
     }
     // ---- input blocks ----
     std::vector<Act> hs;
@@ -826,7 +840,8 @@ struct nr_net {
     const int C0 = cfg.block_out_channels[0];
     const int temb_dim = 4 * C0;
     const int nimg = B2 * F;
-    ops.clear(); op_meta.clear(); taps.clear(); arena.reset();
+    ctx_persist.clear(); ops.clear(); ctx_ops.clear(); op_meta.clear(); taps.clear(); arena.reset();
+    ctx_dirty = true;
     temb_slots.clear();
     enumerate_resnets(temb_slots);
     temb_total = 0;
@@ -877,7 +892,10 @@ struct nr_net {
     Act ctx_bf = new_act(1, 1, B2 * ctx_len, cfg.cross_attention_dim);
     {
       bf16* cp = ctx_bf.ptr; const long long n = (long long)B2 * ctx_len * cfg.cross_attention_dim;
+      building_ctx = true;
       emit([this, cp, n](hipStream_t s) { LAUNCH_OK(nr_launch_f32_to_bf16(io.ctx, cp, n, s)); });
+      building_ctx = false;
+      ctx_persist.push_back(ctx_bf);
     }
 
     // ---- conv_in ----
@@ -1064,6 +1082,12 @@ struct nr_net {
       HIP_OK(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
     }
   }
+  // context-only work (eager, stream-ordered before the main graph); no-op while the context is unchanged
+  void run_context(hipStream_t s) {
+    if (!ctx_dirty) return;
+    for (auto& op : ctx_ops) op(s);
+    ctx_dirty = false;
+  }
   void set_timesteps(hipStream_t s, const float* timesteps) {
     TimestepVals tv;
     for (int i = 0; i < 16; ++i) tv.v[i] = i < B2 ? timesteps[i] : 0.f;
@@ -1096,6 +1120,7 @@ struct nr_net {
   void run(hipStream_t caller, const float* timesteps) {
     if (!use_graph) {
       set_timesteps(caller, timesteps);
+      run_context(caller);
       for (auto& op : ops) op(caller);
       return;
     }
@@ -1104,6 +1129,7 @@ struct nr_net {
     HIP_OK(hipEventRecord(ev_in, caller));
     HIP_OK(hipStreamWaitEvent(s, ev_in, 0));
     set_timesteps(s, timesteps);
+    run_context(s);
     launch_segment(s, 0);
     launch_segment(s, 1);
     HIP_OK(hipEventRecord(ev_out, s));
@@ -1205,6 +1231,13 @@ extern "C" nr_status nr_net_release_host_weights(nr_net* h) {
   if (!h) throw NrError(NR_ERR_ARG, "null handle");
   if (!h->planned) throw NrError(NR_ERR_STATE, "plan first: the converted device copies must exist");
   for (auto& kv : h->host) { std::vector<float>().swap(kv.second.data); }
+  NR_CATCH
+}
+
+extern "C" nr_status nr_net_invalidate_context(nr_net* h) {
+  NR_TRY
+  if (!h) throw NrError(NR_ERR_ARG, "null handle");
+  h->ctx_dirty = true;
   NR_CATCH
 }
 
@@ -1312,8 +1345,10 @@ extern "C" nr_status nr_denoise_step_forward(nr_net* unet, nr_net* ctrl, nr_stre
   ctrl->io = ic; unet->io = iu;
   if (!unet->use_graph || !ctrl->use_graph) {   // eager: plain sequential launches on the caller's stream
     ctrl->set_timesteps(caller, timesteps);
+    ctrl->run_context(caller);
     for (auto& op : ctrl->ops) op(caller);
     unet->set_timesteps(caller, timesteps);
+    unet->run_context(caller);
     for (auto& op : unet->ops) op(caller);
   } else {
     unet->ensure_streams(); ctrl->ensure_streams();
@@ -1322,11 +1357,13 @@ extern "C" nr_status nr_denoise_step_forward(nr_net* unet, nr_net* ctrl, nr_stre
     HIP_OK(hipStreamWaitEvent(ctrl->own_stream, unet->ev_in, 0));
     // SparseCtrl on its stream ...
     ctrl->set_timesteps(ctrl->own_stream, timesteps);
+    ctrl->run_context(ctrl->own_stream);
     ctrl->launch_segment(ctrl->own_stream, 0);
     ctrl->launch_segment(ctrl->own_stream, 1);
     HIP_OK(hipEventRecord(ctrl->ev_out, ctrl->own_stream));
     // ... concurrently with the U-Net's encoder + mid block; the residual adds + decoder wait for SparseCtrl
     unet->set_timesteps(unet->own_stream, timesteps);
+    unet->run_context(unet->own_stream);
     unet->launch_segment(unet->own_stream, 0);
     HIP_OK(hipStreamWaitEvent(unet->own_stream, ctrl->ev_out, 0));
     unet->launch_segment(unet->own_stream, 1);

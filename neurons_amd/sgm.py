@@ -197,7 +197,7 @@ class NativeSGMUNet(_NativeNet):
             raise AssertionError("batch mismatch")                                                    # :840
         self._ensure_plan(b, 1, h, w, context.shape[1])
         self._io_x.copy_(x)
-        self._io_ctx.copy_(context)
+        self._set_context(context)
         self._io_y.copy_(y)
         ts = self._timesteps_host(timesteps, b)
         lib = _lib.load()

@@ -99,7 +99,7 @@ class NativeSparseCtrl(_NativeNet):
             raise ValueError("controlnet_cond batch must divide the sample batch (it is broadcast over the CFG halves)")
         self._ensure_plan(b, f, h, w, ctx.shape[1])
         lib = _lib.load()
-        self._io_ctx.copy_(ctx)
+        self._set_context(ctx)
         if self._io_cond is None or self._io_cond.shape[0] != cb:
             self._io_cond = torch.empty(cb, self.config.conditioning_channels, f, h, w, dtype=torch.float32, device=sample.device)
             self._io_mask = torch.empty(cb, 1, f, h, w, dtype=torch.float32, device=sample.device)

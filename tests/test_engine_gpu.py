@@ -179,3 +179,24 @@ def test_overlapped_step_equals_separate_calls(cuda):
         assert torch.equal(a, b)
     rel, psnr = metrics("overlapped step vs reference golden", b, g["eps_ctrl"])
     assert rel < 2.5e-2
+
+
+def test_context_cache_tracks_content(cuda):
+    """The to_k|to_v projections of the context are cached across calls; a different or in-place-modified context
+    must invalidate them."""
+    g = np.load(os.path.join(GOLD, "tiny_networks.npz"))
+    unet, _ = _tiny()
+    sample = torch.from_numpy(g["sample"]).cuda()
+    ctx_a = torch.from_numpy(g["ctx"]).cuda()
+    out_a = unet(sample, int(g["t"]), encoder_hidden_states=ctx_a).sample
+    ctx_b = (ctx_a * 0.5 + 0.1).contiguous()
+    out_b = unet(sample, int(g["t"]), encoder_hidden_states=ctx_b).sample
+    assert not torch.equal(out_a, out_b)
+    assert torch.equal(out_a, unet(sample, int(g["t"]), encoder_hidden_states=ctx_a).sample)
+    ctx_b.copy_(ctx_a)                                  # in-place change of a tensor the cache has seen
+    assert torch.equal(out_a, unet(sample, int(g["t"]), encoder_hidden_states=ctx_b).sample)
+    for _ in range(4):                                  # temporaries that may recycle an address
+        tmp = (ctx_a * torch.rand(1, device="cuda")).contiguous()
+        ref = unet(sample, int(g["t"]), encoder_hidden_states=tmp.clone()).sample
+        assert torch.equal(ref, unet(sample, int(g["t"]), encoder_hidden_states=tmp).sample)
+        del tmp
