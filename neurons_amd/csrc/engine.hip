@@ -181,6 +181,10 @@ struct nr_net {
   bool planned = false;
   bool dry = false;
   Arena arena;
+  // buffers written by the context ops live in their OWN region behind the main arena: context ops execute before
+  // everything else, so they must never share memory with any temporary of the main plan
+  Arena parena;
+  size_t main_high = 0;          // bytes of the main region (known after the sizing pass)
   char* arena_base = nullptr;
   size_t arena_bytes = 0;
   std::vector<std::function<void(hipStream_t)>> ops;
@@ -369,6 +373,14 @@ struct nr_net {
     auto b = std::make_shared<Buf>();
     b->arena = &arena; b->bytes = bytes; b->off = arena.alloc(bytes); b->keep = keep_all;
     a.buf = b; a.ptr = at<bf16>(b->off); a.nimg = nimg; a.H = h; a.W = w; a.C = C; a.ld = C;
+    return a;
+  }
+  Act new_act_persistent(int nimg, int h, int w, int C) {
+    Act a;
+    const size_t bytes = (size_t)nimg * h * w * C * sizeof(bf16);
+    auto b = std::make_shared<Buf>();
+    b->arena = &parena; b->bytes = bytes; b->off = parena.alloc(bytes); b->keep = true;
+    a.buf = b; a.ptr = (bf16*)(arena_base + main_high + b->off); a.nimg = nimg; a.H = h; a.W = w; a.C = C; a.ld = C;
     return a;
   }
   // raw pinned scratch (lives for the whole plan)
@@ -602,7 +614,9 @@ struct nr_net {
         n2 = Act();
         GemmOpt ok;
         building_ctx = true;      // K|V of the context: recomputed only when the context changes
-        Act kv = linear(ctx_bf, w_linear_cat({b + ".attn2.to_k.weight", b + ".attn2.to_v.weight"}, C, cfg.cross_attention_dim), 2 * C, ok);
+        Act kv = new_act_persistent(ctx_bf.nimg, ctx_bf.H, ctx_bf.W, 2 * C);
+        ok.out = &kv;
+        linear(ctx_bf, w_linear_cat({b + ".attn2.to_k.weight", b + ".attn2.to_v.weight"}, C, cfg.cross_attention_dim), 2 * C, ok);
         building_ctx = false;
         ctx_persist.push_back(kv);
         Act a = attention(1, q, &kv, C, heads);
@@ -706,7 +720,7 @@ struct nr_net {
     const int nimg = B2 * F;
     if (F != 1) throw NrError(NR_ERR_ARG, "sgm UNetModel is a 2-D network: plan with frames = 1");
     const SgmLayout lay = sgm_layout();
-    ctx_persist.clear(); ops.clear(); ctx_ops.clear(); op_meta.clear(); taps.clear(); arena.reset();
+    ctx_persist.clear(); ops.clear(); ctx_ops.clear(); op_meta.clear(); taps.clear(); arena.reset(); parena.reset();
     ctx_dirty = true;
     temb_slots.clear();
     {
@@ -767,7 +781,7 @@ struct nr_net {
       });
     }
     // ---- context fp32 -> bf16 ----
-    Act ctx_bf = new_act(1, 1, B2 * ctx_len, cfg.cross_attention_dim);
+    Act ctx_bf = new_act_persistent(1, 1, B2 * ctx_len, cfg.cross_attention_dim);
     {
       bf16* cp = ctx_bf.ptr; const long long n = (long long)B2 * ctx_len * cfg.cross_attention_dim;
       building_ctx = true;
@@ -840,7 +854,7 @@ struct nr_net {
     const int C0 = cfg.block_out_channels[0];
     const int temb_dim = 4 * C0;
     const int nimg = B2 * F;
-    ctx_persist.clear(); ops.clear(); ctx_ops.clear(); op_meta.clear(); taps.clear(); arena.reset();
+    ctx_persist.clear(); ops.clear(); ctx_ops.clear(); op_meta.clear(); taps.clear(); arena.reset(); parena.reset();
     ctx_dirty = true;
     temb_slots.clear();
     enumerate_resnets(temb_slots);
@@ -889,7 +903,7 @@ struct nr_net {
     }
 
     // ---- text context fp32 -> bf16 [B2*ctx_len][cross_dim] ----
-    Act ctx_bf = new_act(1, 1, B2 * ctx_len, cfg.cross_attention_dim);
+    Act ctx_bf = new_act_persistent(1, 1, B2 * ctx_len, cfg.cross_attention_dim);
     {
       bf16* cp = ctx_bf.ptr; const long long n = (long long)B2 * ctx_len * cfg.cross_attention_dim;
       building_ctx = true;
@@ -1058,8 +1072,10 @@ struct nr_net {
     // pass 1: sizes only
     dry = true;
     char* old = arena_base; arena_base = nullptr;
+    main_high = 0;
     build();
-    const size_t need_bytes = arena.high + 256;
+    main_high = Arena::align(arena.high + 256);
+    const size_t need_bytes = main_high + parena.high + 256;
     dry = false;
     arena_base = old;
     if (need_bytes > arena_bytes) {
