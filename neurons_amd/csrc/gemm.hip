@@ -193,33 +193,45 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
     // tile kt must have landed; the younger (NS-2) tiles may stay outstanding (vmcnt counts in issue order)
     if (kt + (NS - 2) < kt_end) wait_vmcnt<(NS - 2) * G>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();            // everyone's pieces of tile kt landed; everyone left tile kt-1
+    const bf16* sA = smem + cur * TILE;
+    const bf16* sB = sA + BM * BK;
+    // fragment reads of k-step 0 go out FIRST, so their LDS latency is covered by the staging code below
+    // (pointer bumps + LDS-DMA issue for tile kt+NS-1) instead of sitting exposed in front of the MFMAs
+    bf16x8 wf[2][NT], xf[2][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int row = wn * WN + i * 16 + fr;
+      wf[0][i] = *(const bf16x8*)(sB + row * BK + ((fg ^ (row & 7)) << 3));
+    }
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int row = wm * WM + j * 16 + fr;
+      xf[0][j] = *(const bf16x8*)(sA + row * BK + ((fg ^ (row & 7)) << 3));
+    }
+    __builtin_amdgcn_sched_barrier(0);
     {
       const int nxt = kt + NS - 1;           // refill the buffer tile kt-1 occupied
       int nb = cur + NS - 1; if (nb >= NS) nb -= NS;
       if (nxt < kt_end) stage(nb);
     }
-    const bf16* sA = smem + cur * TILE;
-    const bf16* sB = sA + BM * BK;
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 wf[NT], xf[MT];
-      const int lc = ks * 4 + fg;
+    for (int i = 0; i < NT; ++i) {
+      const int row = wn * WN + i * 16 + fr;
+      wf[1][i] = *(const bf16x8*)(sB + row * BK + (((4 + fg) ^ (row & 7)) << 3));
+    }
 #pragma unroll
-      for (int i = 0; i < NT; ++i) {
-        const int row = wn * WN + i * 16 + fr;
-        wf[i] = *(const bf16x8*)(sB + row * BK + ((lc ^ (row & 7)) << 3));
-      }
+    for (int j = 0; j < MT; ++j) {
+      const int row = wm * WM + j * 16 + fr;
+      xf[1][j] = *(const bf16x8*)(sA + row * BK + (((4 + fg) ^ (row & 7)) << 3));
+    }
 #pragma unroll
-      for (int j = 0; j < MT; ++j) {
-        const int row = wm * WM + j * 16 + fr;
-        xf[j] = *(const bf16x8*)(sA + row * BK + ((lc ^ (row & 7)) << 3));
-      }
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], xf[ks][j], acc[i][j], 0, 0, 0);
     cur = cur + 1 == NS ? 0 : cur + 1;
   }
 
