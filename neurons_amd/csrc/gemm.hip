@@ -400,7 +400,7 @@ Plan choose_plan(const NrGemmParams& p) {
   pl.splitk = 1; pl.stages = 2; pl.waves = 4;
   const bool n128 = p.N % 128 == 0 || p.N >= 960;          // <= 6 % padded columns otherwise
   if (!p.geglu && p.N % 160 == 0 && p.N < 960 && p.N % 128 != 0 && nk >= 20 && nblk(128, 160) >= 256) { pl.bm = 128; pl.bn = 160; }
-  else if (n128 && nblk(128, 128) >= 512) { pl.bm = 128; pl.bn = 128; pl.waves = 8; }
+  else if (n128 && nblk(128, 128) >= 400) { pl.bm = 128; pl.bn = 128; pl.waves = 8; }
   else if (nblk(128, 64) >= 512 || (nblk(128, 64) >= 256 && nk > 32)) { pl.bm = 128; pl.bn = 64; pl.waves = nk <= 32 ? 8 : 4; }
   else if (nblk(64, 64) >= 256 && nk <= 96) { pl.bm = 64; pl.bn = 64; }
   else if (p.M >= 1024 && nblk(128, 64) >= 64) { pl.bm = 128; pl.bn = 64; }
@@ -409,7 +409,7 @@ Plan choose_plan(const NrGemmParams& p) {
     const long long tiles = nblk(pl.bm, pl.bn);
     const int cap_m = p.M >= 8192 ? 2 : (p.M >= 2048 ? 4 : 8);      // bounds the fp32 slab traffic (8*M*N*split bytes)
     const int min_tiles = p.M <= 1024 ? 8 : 16;                      // k-tiles each slice keeps
-    if (tiles < 1024 && nk >= 4 * min_tiles) {
+    if (tiles < 512 && nk >= 4 * min_tiles) {
       int s_ = (int)((1280 + tiles - 1) / tiles);
       if (s_ > nk / min_tiles) s_ = nk / min_tiles;
       if (s_ > cap_m) s_ = cap_m;
