@@ -433,6 +433,86 @@ def gen_sgm(out_dir):
     print("sgm_tiny:", {k: v.shape for k, v in out.items()}, "final abs mean", final.abs().mean().item())
 
 
+# --------------------------------------------------------------------------------------------------
+# weight ingestion: run the reference's own converter / LoRA-merge functions on synthetic checkpoints
+# --------------------------------------------------------------------------------------------------
+def _load_ref_module(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@torch.no_grad()
+def gen_weights(out_dir):
+    import json
+    from neurons_amd import _lib
+    from neurons_amd.synth import randn
+    from neurons_amd.unet3d import random_state_dict, state_dict_schema
+    from neurons_amd.weights import LDM_UNET_PREFIX, ldm_unet_key_map
+    install_scaffolding()
+    # stand-ins for names the converter module only imports (never calls on this path)
+    dm = sys.modules["diffusers.models"]
+    for n in ("AutoencoderKL", "PriorTransformer", "UNet2DConditionModel", "ControlNetModel"):
+        setattr(dm, n, type(n, (), {}))
+    names = ("DDIMScheduler DDPMScheduler DPMSolverMultistepScheduler EulerAncestralDiscreteScheduler EulerDiscreteScheduler "
+             "HeunDiscreteScheduler LMSDiscreteScheduler PNDMScheduler UnCLIPScheduler").split()
+    _mod("diffusers.schedulers", **{n: type(n, (), {}) for n in names})
+    sys.modules["diffusers.utils.import_utils"].BACKENDS_MAPPING = {}
+    sys.modules["diffusers"].StableDiffusionPipeline = type("StableDiffusionPipeline", (), {})
+    tv_stub = sys.modules.pop("torchvision", None)     # transformers probes torchvision with find_spec(): hide the stub meanwhile
+    try:
+        conv = _load_ref_module("ref_convert_from_ckpt", f"{REF}/animatediff/utils/convert_from_ckpt.py")
+    finally:
+        if tv_stub is not None:
+            sys.modules["torchvision"] = tv_stub
+    lora = _load_ref_module("ref_convert_lora", f"{REF}/animatediff/utils/convert_lora_safetensor_to_diffusers.py")
+
+    # (1) LDM -> diffusers key map of the SD-1.5 topology: feed a checkpoint of 1-element tensors carrying an id
+    cfg = tiny_unet_config()
+    km = ldm_unet_key_map(cfg)                       # our claim; the reference decides
+    ckpt = {LDM_UNET_PREFIX + k: torch.tensor([float(i)]) for i, k in enumerate(sorted(km))}
+    ids = {float(i): k for i, k in enumerate(sorted(km))}
+    converted = conv.convert_ldm_unet_checkpoint(dict(ckpt), {"layers_per_block": cfg.layers_per_block, "class_embed_type": None})
+    ref_map = {ids[float(v)]: k for k, v in converted.items()}
+
+    # (2) LoRA merges on the reference U-Net (torch modules)
+    sd = random_state_dict(cfg, _lib.NR_KIND_UNET3D, seed=11)
+    unet = build_reference_unet(cfg, sd)
+    pipe = types.SimpleNamespace(unet=unet, text_encoder=None)
+    targets = ["down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q", "up_blocks.1.attentions.2.transformer_blocks.0.attn2.to_k",
+               "mid_block.attentions.0.transformer_blocks.0.ff.net.2", "down_blocks.1.attentions.1.proj_in",
+               "up_blocks.3.attentions.0.transformer_blocks.0.attn2.to_out.0"]
+    shapes = state_dict_schema(cfg)
+    kohya = {}
+    for t in targets:
+        w = shapes[t + ".weight"]
+        r = 4
+        name = "lora_unet_" + t.replace(".", "_")
+        if len(w) == 4:
+            kohya[name + ".lora_down.weight"] = randn(name + ".d", (r, w[1], 1, 1), 81)
+            kohya[name + ".lora_up.weight"] = randn(name + ".u", (w[0], r, 1, 1), 82)
+        else:
+            kohya[name + ".lora_down.weight"] = randn(name + ".d", (r, w[1]), 81)
+            kohya[name + ".lora_up.weight"] = randn(name + ".u", (w[0], r), 82)
+        kohya[name + ".alpha"] = torch.tensor(4.0)
+    lora.convert_lora(pipe, kohya, alpha=0.8)
+    dl = {}
+    for t in ("down_blocks.0.attentions.0.transformer_blocks.0.attn1.processor.to_q_lora", "up_blocks.2.attentions.1.transformer_blocks.0.attn2.processor.to_out_lora",
+              "down_blocks.2.motion_modules.0.temporal_transformer.transformer_blocks.0.attention_blocks.0.processor.to_v_lora"):
+        base = t.replace("processor.", "").replace("_lora", "").replace("to_out", "to_out.0") + ".weight"
+        w = shapes[base]
+        dl[t + ".down.weight"] = randn(t + ".d", (4, w[1]), 83)
+        dl[t + ".up.weight"] = randn(t + ".u", (w[0], 4), 84)
+    lora.load_diffusers_lora(pipe, dl, alpha=0.7)
+    merged = unet.state_dict()
+    changed = {k: [float(merged[k].double().sum()), float(merged[k].double().abs().sum())] for k in merged
+               if not k.endswith("pos_encoder.pe") and not torch.equal(merged[k], sd[k])}
+    with open(os.path.join(out_dir, "weights.json"), "w") as f:
+        json.dump({"ldm_to_diffusers": ref_map, "lora_changed_checksums": changed, "kohya_targets": targets}, f, indent=0, sort_keys=True)
+    print("weights.json:", len(ref_map), "mapped keys;", len(changed), "tensors changed by LoRA; map equal to ours:", ref_map == km)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -442,5 +522,6 @@ if __name__ == "__main__":
     gen_loop(out_dir, unet, ctrl)
     gen_leaf_ops(out_dir)
     gen_sgm(out_dir)
+    gen_weights(out_dir)
     for f in sorted(os.listdir(out_dir)):
         print(f, os.path.getsize(os.path.join(out_dir, f)) // 1024, "KiB")
