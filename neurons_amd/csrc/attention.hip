@@ -256,28 +256,38 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p, in
         s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
       }
     }
+    // softmax in the log2 domain: exp(scale*s - m) = exp2(s*scale*log2(e) - m2); one v_exp per score, no extra mul.
+    // Full tiles (all 64 keys valid) skip the key-mask selects.
+    const float sl2 = p.scale * 1.4426950408889634f;
+    const bool full = k0 + KT2 <= p.Lk;
     float mx = -1e30f;
+    if (full) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = k0 + 16 * t + 4 * g + r;
-        const float v = key < p.Lk ? s[t][r] * p.scale : -1e30f;
-        s[t][r] = v;
-        mx = fmaxf(mx, v);
-      }
+        for (int r = 0; r < 4; ++r) { s[t][r] *= sl2; mx = fmaxf(mx, s[t][r]); }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = k0 + 16 * t + 4 * g + r;
+          const float v = key < p.Lk ? s[t][r] * sl2 : -1e30f;
+          s[t][r] = v;
+          mx = fmaxf(mx, v);
+        }
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_i, mx);
-    const float alpha = __expf(m_i - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
     float rs = 0.f;
     bf16x8 pf[2];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int key = k0 + 16 * t + 4 * g + r;
-        const float e = key < p.Lk ? __expf(s[t][r] - m_new) : 0.f;
+        const float e = __builtin_amdgcn_exp2f(s[t][r] - m_new);   // masked keys: exp2(-1e30 - m) = 0
         rs += e;
         pf[t >> 1][(t & 1) * 4 + r] = (bf16)e;
       }

@@ -17,19 +17,20 @@ namespace {
 // (CFG halves share one latent; SparseCtrl condition has batch B while the net runs 2B).
 // grid (H, nimg), block 256; LDS patch [Cin][3][W+2]
 // ---------------------------------------------------------------------------------------------
+template <int CIN>
 __global__ __launch_bounds__(256) void conv_in_small_kernel(const float* __restrict__ s0, const float* __restrict__ s1,
                                                             int c0, int c1, int src_batch, int F, int H, int W,
                                                             const float* __restrict__ wT, const float* __restrict__ bias,
                                                             const float* __restrict__ addend, int Cout,
                                                             bf16* __restrict__ out, float in_scale) {
-  // thread = one output channel (coalesced weight reads and output stores), register-blocked over 8 pixels of the
-  // row; the 3-row input patch sits in LDS and is read as wave-uniform broadcasts.
+  // thread = one output channel (coalesced weight reads and output stores) with its 9*CIN weights in registers,
+  // register-blocked over 8 pixels of the row; the 3-row input patch sits in LDS (wave-uniform broadcast reads).
   extern __shared__ float patch[];
-  const int Cin = c0 + c1;
+  constexpr int K = CIN * 9;
   const int y = blockIdx.x, n = blockIdx.y;
   const int b = (n / F) % src_batch, f = n % F;
   const int PW = W + 2;
-  for (int i = threadIdx.x; i < Cin * 3 * PW; i += 256) {
+  for (int i = threadIdx.x; i < CIN * 3 * PW; i += 256) {
     const int ci = i / (3 * PW);
     const int r = i - ci * 3 * PW;
     const int ky = r / PW, px = r - ky * PW;
@@ -43,20 +44,22 @@ __global__ __launch_bounds__(256) void conv_in_small_kernel(const float* __restr
     patch[i] = v;
   }
   __syncthreads();
-  const int K = Cin * 9;
   for (int co = threadIdx.x; co < Cout; co += 256) {
+    float w[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) w[k] = wT[(size_t)k * Cout + co];
     const float b0 = bias[co] + (addend ? addend[co] : 0.f);
     for (int x0 = 0; x0 < W; x0 += 8) {
       float acc[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] = b0;
+#pragma unroll
       for (int k = 0; k < K; ++k) {
         const int ci = k / 9, t = k - ci * 9;
         const int ky = t / 3, kx = t - ky * 3;
-        const float w = wT[(size_t)k * Cout + co];
         const float* pr = patch + (ci * 3 + ky) * PW + x0 + kx;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += w * pr[e];   // pr[e] beyond W+1 only when x0+e >= W (masked at the store)
+        for (int e = 0; e < 8; ++e) acc[e] += w[k] * pr[e];   // pr[e] beyond W+1 only when x0+e >= W (masked at the store)
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e)
@@ -138,11 +141,12 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
       if (m < M) {
+        const f32x4 x0 = *(const f32x4*)(x + (size_t)m * K + k0), x1 = *(const f32x4*)(x + (size_t)m * K + k0 + 4);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float xv = x[(size_t)m * K + k0 + e];
-          if (in_act) xv = silu_f(xv);
-          acc[m] += xv * wf[e];
+        for (int e = 0; e < 4; ++e) {
+          float a = x0[e], b2 = x1[e];
+          if (in_act) { a = silu_f(a); b2 = silu_f(b2); }
+          acc[m] += a * wf[e] + b2 * wf[4 + e];
         }
       }
     }
@@ -218,8 +222,14 @@ extern "C" int nr_launch_conv_in_small(const float* s0, const float* s1, int c0,
                                        bf16* out, float in_scale, hipStream_t stream) {
   const size_t shm = ((size_t)(c0 + c1) * 3 * (W + 2) + 16) * sizeof(float);   // +16: masked over-read of the last row
   if (shm > 60000) return 1;
-  hipLaunchKernelGGL(conv_in_small_kernel, dim3(H, nimg), dim3(256), shm, stream, s0, s1, c0, c1, src_batch, F, H, W, wT,
-                     bias, addend, Cout, out, in_scale);
+  if (c0 + c1 == 4)
+    hipLaunchKernelGGL((conv_in_small_kernel<4>), dim3(H, nimg), dim3(256), shm, stream, s0, s1, c0, c1, src_batch, F, H, W, wT,
+                       bias, addend, Cout, out, in_scale);
+  else if (c0 + c1 == 5)
+    hipLaunchKernelGGL((conv_in_small_kernel<5>), dim3(H, nimg), dim3(256), shm, stream, s0, s1, c0, c1, src_batch, F, H, W, wT,
+                       bias, addend, Cout, out, in_scale);
+  else
+    return 2;
   return 0;
 }
 

@@ -776,8 +776,8 @@ struct nr_net {
         LAUNCH_OK(nr_launch_linear_small(sincos, b2n, C0, w1, b1, temb_dim, 0, 1, e1, nullptr, s));
         LAUNCH_OK(nr_launch_linear_small(e1, b2n, temb_dim, w2, b2, temb_dim, 0, 0, et, nullptr, s));
         LAUNCH_OK(nr_launch_linear_small(io.y, b2n, adm, wy1, by1, temb_dim, 0, 1, y1, nullptr, s));
-        LAUNCH_OK(nr_launch_linear_small(y1, b2n, temb_dim, wy2, by2, temb_dim, 0, 0, emb, et, s));   // emb = time + label
-        LAUNCH_OK(nr_launch_linear_small(emb, b2n, temb_dim, wp, bp, tt, 1, 0, ta, nullptr, s));
+        LAUNCH_OK(nr_launch_linear_small(y1, b2n, temb_dim, wy2, by2, temb_dim, 0, 1, emb, et, s));   // SiLU(time + label)
+        LAUNCH_OK(nr_launch_linear_small(emb, b2n, temb_dim, wp, bp, tt, 0, 0, ta, nullptr, s));
       });
     }
     // ---- context fp32 -> bf16 ----
@@ -897,8 +897,10 @@ struct nr_net {
       emit([=](hipStream_t s) {
         LAUNCH_OK(nr_launch_timestep_sincos(td, b2n, C0, sincos, s));
         LAUNCH_OK(nr_launch_linear_small(sincos, b2n, C0, w1, b1, temb_dim, 0, 1, emb1, nullptr, s));   // Linear + SiLU
-        LAUNCH_OK(nr_launch_linear_small(emb1, b2n, temb_dim, w2, b2, temb_dim, 0, 0, emb, nullptr, s)); // emb
-        LAUNCH_OK(nr_launch_linear_small(emb, b2n, temb_dim, wp, bp, tt, 1, 0, ta, nullptr, s));         // Linear(SiLU(emb)) for all resnets
+        // every consumer of emb applies SiLU first (resnet.py:191), so store SiLU(emb) once instead of re-evaluating it
+        // in each of the ~22k output rows of the batched projection
+        LAUNCH_OK(nr_launch_linear_small(emb1, b2n, temb_dim, w2, b2, temb_dim, 0, 1, emb, nullptr, s)); // SiLU(emb)
+        LAUNCH_OK(nr_launch_linear_small(emb, b2n, temb_dim, wp, bp, tt, 0, 0, ta, nullptr, s));         // Linear(SiLU(emb)) for all resnets
       });
     }
 
