@@ -41,6 +41,9 @@ typedef struct nr_net nr_net;
 #define NR_KIND_SPARSECTRL 1 /* animatediff/models/sparse_controlnet.py:85 SparseControlNetModel */
 #define NR_KIND_SGM_UNET 2   /* generative_models/sgm/modules/diffusionmodules/openaimodel.py:472 UNetModel (unCLIP keyframes) */
 
+#define NR_KIND_VAE_DECODER 3 /* generative_models/sgm/modules/diffusionmodules/model.py:612 Decoder behind
+                                 sgm/models/autoencoder.py:490 decode (= diffusers AutoencoderKL.decode)     */
+
 #define NR_MAX_LEVELS 4
 
 /* Mirrors the constructor arguments that reach the hot path (unet.py:42-90; SD-1.5 unet/config.json +
@@ -154,6 +157,16 @@ nr_status nr_denoise_step_forward(nr_net* unet, nr_net* ctrl, nr_stream stream, 
  * ("crossattn"); y_dev fp32 [batch][adm_in_channels] ("vector"); out_dev fp32 [batch][4][h][w].               */
 nr_status nr_sgm_unet_forward(nr_net* h, nr_stream stream, const float* x_dev, float in_scale, const float* timesteps,
                               const float* ctx_dev, int32_t ctx_len, const float* y_dev, float* out_dev);
+
+/* replaces DiffusionEngine.decode_first_stage (sgm/models/diffusion.py:118-135: z / scale_factor ->
+ * AutoencodingEngineLegacy.decode, autoencoder.py:490-494 = post_quant_conv -> Decoder.forward, model.py:723-757) and
+ * the per-frame vae.decode of AnimationPipeline.decode_latents (pipeline_animation.py:243-256; same network under
+ * diffusers parameter names, see neurons_amd/vae.py for the key map).  Config: kind NR_KIND_VAE_DECODER,
+ * in_channels = z_channels (= embed_dim), out_channels = 3, block_out_channels = ch * ch_mult, layers_per_block =
+ * num_res_blocks, norm_num_groups 32, norm_eps 1e-6; plan with (batch = images, frames = 1, h, w, ctx_len = 0).
+ *   z_dev fp32 [batch][z][h][w]; z_scale = 1 / scale_factor; out_dev fp32 [batch][3][8h][8w];
+ *   unit_range != 0 fuses the callers' (x / 2 + 0.5).clamp(0, 1) (pipeline_animation.py:252) into the last kernel.  */
+nr_status nr_vae_decode(nr_net* h, nr_stream stream, const float* z_dev, float z_scale, int32_t unit_range, float* out_dev);
 
 /* replaces Denoiser.forward's output scaling + VanillaCFG + EulerEDMSampler.sampler_step with s_churn = 0
  * (denoiser.py:36-39, denoiser_scaling.py:29-37, guiders.py:28-31, sampling_utils.py:34-35, sampling.py:98-112):

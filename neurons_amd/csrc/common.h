@@ -84,6 +84,7 @@ struct NrGemmParams {
   int ldo;
   float out_scale;     // (acc + bias + rowvec) * out_scale + res
   int geglu;           // 1: W rows are (value16|gate16)-interleaved; out has N/2 columns
+  float* out_f32;      // non-null: write the raw fp32 accumulators to out_f32[M][N] and skip the epilogue (attention scores)
 };
 
 struct NrAttnParams {

@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void conv_in_small_kernel(const float* __restr
 template <int COUT>
 __global__ __launch_bounds__(256) void conv_out_small_kernel(const bf16* __restrict__ x, int Cin, int nimg, int F, int H,
                                                              int W, const bf16* __restrict__ w,
-                                                             const float* __restrict__ bias, float* __restrict__ out) {
+                                                             const float* __restrict__ bias, float* __restrict__ out,
+                                                             int unit_range) {
   const int lane = threadIdx.x & 63;
   const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long npix = (long long)nimg * H * W;
@@ -104,8 +105,62 @@ __global__ __launch_bounds__(256) void conv_out_small_kernel(const bf16* __restr
   if (lane == 0) {
     const int b = n / F, f = n - b * F;
 #pragma unroll
-    for (int o = 0; o < COUT; ++o)
-      out[((((size_t)b * COUT + o) * F + f) * H + y) * W + xx] = acc[o] + bias[o];
+    for (int o = 0; o < COUT; ++o) {
+      float v = acc[o] + bias[o];
+      if (unit_range) v = fminf(fmaxf(v * 0.5f + 0.5f, 0.f), 1.f);   // (x / 2 + 0.5).clamp(0, 1)  pipeline_animation.py:252
+      out[((((size_t)b * COUT + o) * F + f) * H + y) * W + xx] = v;
+    }
+  }
+}
+
+// post_quant_conv (1x1, C <= 8) on the fp32 NCHW latent: out[n][co][p] = qb[co] + sum_ci Q[co][ci] * (z[n][ci][p] * scale)
+// (sgm/models/autoencoder.py:459,492; the 1/scale_factor of diffusion.py:119 / pipeline_animation.py:245 is `scale`)
+__global__ void post_quant_kernel(const float* __restrict__ z, float scale, const float* __restrict__ Q,
+                                  const float* __restrict__ qb, float* __restrict__ out, int nimg, int C, int hw) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)nimg * hw) return;
+  const int n = (int)(idx / hw), p = (int)(idx - (long long)n * hw);
+  float v[8];
+  for (int c = 0; c < C; ++c) v[c] = z[((size_t)n * C + c) * hw + p] * scale;
+  for (int co = 0; co < C; ++co) {
+    float a = qb[co];
+    for (int c = 0; c < C; ++c) a += Q[co * C + c] * v[c];
+    out[((size_t)n * C + co) * hw + p] = a;
+  }
+}
+
+// row softmax of fp32 scores -> bf16 probabilities: P[r][:] = softmax(S[r][:] * scale).  One 256-thread block per row.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, bf16* __restrict__ P, int L, float scale_log2e) {
+  __shared__ float red[4];
+  const float* s = S + (size_t)blockIdx.x * L;
+  bf16* o = P + (size_t)blockIdx.x * L;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float m = -INFINITY;
+  for (int i = threadIdx.x * 4; i < L; i += 1024) {
+    const f32x4 v = *(const f32x4*)(s + i);
+    m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+  }
+  m = wave_max(m);
+  if (lane == 0) red[wv] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale_log2e;
+  __syncthreads();
+  float l = 0.f;
+  for (int i = threadIdx.x * 4; i < L; i += 1024) {
+    const f32x4 v = *(const f32x4*)(s + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) l += exp2f(v[e] * scale_log2e - m);
+  }
+  l = wave_sum(l);
+  if (lane == 0) red[wv] = l;
+  __syncthreads();
+  const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
+  for (int i = threadIdx.x * 4; i < L; i += 1024) {
+    const f32x4 v = *(const f32x4*)(s + i);
+    bf16x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = (bf16)(exp2f(v[e] * scale_log2e - m) * inv);
+    *(bf16x4*)(o + i) = r;
   }
 }
 
@@ -234,14 +289,30 @@ extern "C" int nr_launch_conv_in_small(const float* s0, const float* s1, int c0,
 }
 
 extern "C" int nr_launch_conv_out_small(const bf16* x, int Cin, int nimg, int F, int H, int W, const bf16* w,
-                                        const float* bias, int Cout, float* out, hipStream_t stream) {
+                                        const float* bias, int Cout, float* out, int unit_range, hipStream_t stream) {
   if (Cin % 8 != 0) return 1;
   const long long npix = (long long)nimg * H * W;
   const unsigned blocks = (unsigned)((npix + 3) / 4);
   if (Cout == 4)
-    hipLaunchKernelGGL((conv_out_small_kernel<4>), dim3(blocks), dim3(256), 0, stream, x, Cin, nimg, F, H, W, w, bias, out);
+    hipLaunchKernelGGL((conv_out_small_kernel<4>), dim3(blocks), dim3(256), 0, stream, x, Cin, nimg, F, H, W, w, bias, out, unit_range);
+  else if (Cout == 3)
+    hipLaunchKernelGGL((conv_out_small_kernel<3>), dim3(blocks), dim3(256), 0, stream, x, Cin, nimg, F, H, W, w, bias, out, unit_range);
   else
     return 2;
+  return 0;
+}
+
+extern "C" int nr_launch_post_quant(const float* z, float scale, const float* Q, const float* qb, float* out, int nimg, int C,
+                                    int hw, hipStream_t stream) {
+  if (C > 8) return 1;
+  const long long total = (long long)nimg * hw;
+  hipLaunchKernelGGL(post_quant_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, z, scale, Q, qb, out, nimg, C, hw);
+  return 0;
+}
+
+extern "C" int nr_launch_softmax_rows(const float* S, bf16* P, int rows, int L, float scale, hipStream_t stream) {
+  if (L % 4 != 0) return 1;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, stream, S, P, L, scale * 1.4426950408889634f);
   return 0;
 }
 

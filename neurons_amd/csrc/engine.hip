@@ -38,8 +38,11 @@ int nr_launch_attention(const NrAttnParams* pp, hipStream_t stream);
 int nr_launch_conv_in_small(const float* s0, const float* s1, int c0, int c1, int src_batch, int nimg, int F, int H, int W,
                             const float* wT, const float* bias, const float* addend, int Cout, bf16* out, float in_scale,
                             hipStream_t stream);
+int nr_launch_post_quant(const float* z, float scale, const float* Q, const float* qb, float* out, int nimg, int C, int hw,
+                         hipStream_t stream);
+int nr_launch_softmax_rows(const float* S, bf16* P, int rows, int L, float scale, hipStream_t stream);
 int nr_launch_conv_out_small(const bf16* x, int Cin, int nimg, int F, int H, int W, const bf16* w, const float* bias,
-                             int Cout, float* out, hipStream_t stream);
+                             int Cout, float* out, int unit_range, hipStream_t stream);
 int nr_launch_timestep_sincos(const float* t, int M, int dim, float* out, hipStream_t stream);
 int nr_launch_linear_small(const float* x, int M, int K, const bf16* W, const float* b, int N, int in_act, int out_act,
                            float* y, const float* addend, hipStream_t stream);
@@ -159,7 +162,8 @@ struct IO {
   void* out_down[16] = {nullptr};
   void* out_mid = nullptr;
   const float* y = nullptr;     // sgm "vector" conditioning
-  float in_scale = 1.f;         // sgm c_in
+  float in_scale = 1.f;         // sgm c_in; VAE: 1 / scale_factor
+  int unit_range = 0;           // VAE: fuse (x / 2 + 0.5).clamp(0, 1) into conv_out
   bool operator==(const IO& o) const { return std::memcmp(this, &o, sizeof(IO)) == 0; }
 };
 
@@ -541,6 +545,8 @@ struct nr_net {
   ResKeys res_keys(const std::string& pre) const {
     if (cfg.kind == NR_KIND_SGM_UNET)
       return ResKeys{pre + ".in_layers.0", pre + ".in_layers.2", pre + ".out_layers.0", pre + ".out_layers.3", pre + ".skip_connection"};
+    if (cfg.kind == NR_KIND_VAE_DECODER)   // sgm/modules/diffusionmodules/model.py:94-151
+      return ResKeys{pre + ".norm1", pre + ".conv1", pre + ".norm2", pre + ".conv2", pre + ".nin_shortcut"};
     return ResKeys{pre + ".norm1", pre + ".conv1", pre + ".norm2", pre + ".conv2", pre + ".conv_shortcut"};
   }
 
@@ -554,7 +560,9 @@ struct nr_net {
     Act h = groupnorm(x0, x1, k.norm1, cfg.norm_eps, 1);
     GemmOpt o1;
     o1.bias = w_f32(k.conv1 + ".bias", Cout);
-    o1.rowvec = temb_for(pre, Cout); o1.rowvec_div = F * hw; o1.rowvec_ld = temb_total;
+    if (cfg.kind != NR_KIND_VAE_DECODER) {   // the VAE's ResnetBlock runs with temb = None (model.py:138-139,727)
+      o1.rowvec = temb_for(pre, Cout); o1.rowvec_div = F * hw; o1.rowvec_ld = temb_total;
+    }
     Act h1 = conv(h, nullptr, w_conv3(k.conv1 + ".weight", Cout, Cin), Cout, 3, 1, 0, o1);
     h = Act();
     Act h2 = groupnorm(h1, nullptr, k.norm2, cfg.norm_eps, 1);
@@ -842,7 +850,120 @@ struct nr_net {
       const bf16* wo = w_conv3("out.2.weight", cfg.out_channels, C0);
       const float* bo = w_f32("out.2.bias", cfg.out_channels);
       const bf16* hp = hn.ptr; const int Hn = H, Wn = W, oc = cfg.out_channels;
-      emit([=, this](hipStream_t s) { LAUNCH_OK(nr_launch_conv_out_small(hp, C0, nimg, 1, Hn, Wn, wo, bo, oc, io.out, s)); });
+      emit([=, this](hipStream_t s) { LAUNCH_OK(nr_launch_conv_out_small(hp, C0, nimg, 1, Hn, Wn, wo, bo, oc, io.out, 0, s)); });
+    }
+    n_res = 0;
+    res_shapes.clear();
+  }
+
+
+  // ------------------------------------------------------------------ VAE decoder (sgm first stage)
+  // plain GEMM on raw pointers: out = A[M][K] . W[N][K]^T (+bias) -> bf16 [M][ldo], or raw fp32 [M][N] when out32
+  void gemm_raw(const bf16* a, int lda, const bf16* w, int M, int N, int K, const float* bias, bf16* out, int ldo, float* out32,
+                const char* what) {
+    NrGemmParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.a0 = a; p.c0 = K; p.lda0 = lda; p.H = p.W = p.OH = p.OW = 1; p.ksize = 1; p.stride = 1;
+    p.w = w; p.M = M; p.N = N; p.K = K; p.bias = bias; p.out = out; p.ldo = ldo; p.out_scale = 1.f; p.out_f32 = out32;
+    const size_t wsb = nr_igemm_workspace_bytes(&p);
+    float* ws = nullptr;
+    std::shared_ptr<Buf> wsbuf;
+    if (wsb) { wsbuf = new_tmp(wsb); ws = at<float>(wsbuf->off); }
+    char d[160];
+    snprintf(d, sizeof(d), "igemm %s M=%d N=%d K=%d", what, M, N, K);
+    emit([p, ws](hipStream_t s) { LAUNCH_OK(nr_launch_igemm(&p, ws, s)); }, NR_PROF_IGEMM, 2.0 * M * (double)N * K,
+         2.0 * ((double)M * K + (double)N * K) + (out32 ? 4.0 : 2.0) * (double)M * N, d);
+  }
+
+  // AttnBlock (model.py:161-201): GroupNorm -> q,k,v 1x1 convs -> single-head softmax(q k^T / sqrt(C)) v -> proj_out
+  // + x.  The head dimension is the full channel count (512), beyond the flash kernels' register budget, so the
+  // block is expressed as MFMA GEMMs per image: S = Q K^T (fp32 scores), row softmax -> bf16 P, O = P V.  V is
+  // produced already transposed (V^T = Wv . Xn^T, i.e. the igemm with the weight as the "activation" operand); its
+  // bias moves to the P V epilogue because every softmax row sums to one.
+  Act vae_attn(const Act& x, const std::string& pre) {
+    const int C = x.C, hw = x.H * x.W;
+    if (hw % 64 != 0) throw NrError(NR_ERR_UNSUPPORTED, "VAE attention: latent h*w must be a multiple of 64");
+    Act hn = groupnorm(x, nullptr, pre + ".norm", cfg.norm_eps, 0);
+    GemmOpt oq; oq.bias = w_f32(pre + ".q.bias", C);
+    Act q = linear(hn, w_linear(pre + ".q.weight", C, C), C, oq);
+    GemmOpt ok; ok.bias = w_f32(pre + ".k.bias", C);
+    Act k = linear(hn, w_linear(pre + ".k.weight", C, C), C, ok);
+    const bf16* wv = w_linear(pre + ".v.weight", C, C);
+    const float* bv = w_f32(pre + ".v.bias", C);
+    Act o = new_act(x.nimg, x.H, x.W, C);
+    {
+      auto vt = new_tmp((size_t)C * hw * sizeof(bf16));
+      auto sc = new_tmp((size_t)hw * hw * sizeof(float));
+      auto pr = new_tmp((size_t)hw * hw * sizeof(bf16));
+      bf16* vtp = at<bf16>(vt->off); float* scp = at<float>(sc->off); bf16* prp = at<bf16>(pr->off);
+      const float scale = 1.0f / std::sqrt((float)C);
+      for (int n = 0; n < x.nimg; ++n) {
+        const size_t off = (size_t)n * hw * C;
+        gemm_raw(wv, C, hn.ptr + off, C, hw, C, nullptr, vtp, hw, nullptr, "vae V^T");
+        gemm_raw(q.ptr + off, C, k.ptr + off, hw, hw, C, nullptr, nullptr, 0, scp, "vae QK^T");
+        emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_softmax_rows(scp, prp, hw, hw, scale, s)); }, NR_PROF_ATTENTION,
+             5.0 * (double)hw * hw, 6.0 * (double)hw * hw, "softmax rows L=" + std::to_string(hw));
+        gemm_raw(prp, hw, vtp, hw, C, hw, bv, o.ptr + off, C, nullptr, "vae PV");
+      }
+    }
+    hn = Act(); q = Act(); k = Act();
+    GemmOpt op; op.bias = w_f32(pre + ".proj_out.bias", C); op.res = &x;
+    Act out = linear(o, w_linear(pre + ".proj_out.weight", C, C), C, op);
+    tap(pre, out);
+    return out;
+  }
+
+  // AutoencodingEngineLegacy.decode (sgm/models/autoencoder.py:490-494) = post_quant_conv -> Decoder.forward
+  // (sgm/modules/diffusionmodules/model.py:723-757).  Same network as diffusers AutoencoderKL.decode used by
+  // decode_latents (pipeline_animation.py:243-256) under different parameter names.
+  void build_vae() {
+    const int L = cfg.num_levels, zc = cfg.in_channels, nimg = B2;
+    if (F != 1) throw NrError(NR_ERR_ARG, "the VAE decoder is a 2-D network: plan with frames = 1");
+    ctx_persist.clear(); ops.clear(); ctx_ops.clear(); op_meta.clear(); taps.clear(); arena.reset(); parena.reset();
+    temb_slots.clear(); temb_total = 0; temb_all = nullptr;
+    t_dev = new_scratch<float>(16);
+    const int Cm = cfg.block_out_channels[L - 1];
+    float* zq = new_scratch<float>((size_t)nimg * zc * H * W);
+    {
+      check_shape("post_quant_conv.weight", need("post_quant_conv.weight"), {zc, zc});
+      const float* Q = (const float*)cached("f32:post_quant_conv.weight", [&]() {
+        const HostTensor& t = data_of("post_quant_conv.weight");
+        return upload("f32:post_quant_conv.weight", t.data.data(), t.data.size() * 4);
+      });
+      const float* qb = w_f32("post_quant_conv.bias", zc);
+      const int hw = H * W;
+      emit([=, this](hipStream_t s) { LAUNCH_OK(nr_launch_post_quant(io.sample, io.in_scale, Q, qb, zq, nimg, zc, hw, s)); });
+    }
+    Act x = new_act(nimg, H, W, Cm);
+    {
+      const float* wT = w_conv_in("decoder.conv_in.weight", Cm, zc);
+      const float* bi = w_f32("decoder.conv_in.bias", Cm);
+      bf16* xp = x.ptr; const int Hn = H, Wn = W;
+      emit([=](hipStream_t s) {
+        LAUNCH_OK(nr_launch_conv_in_small(zq, nullptr, zc, 0, nimg, nimg, 1, Hn, Wn, wT, bi, nullptr, Cm, xp, 1.f, s));
+      });
+      tap("decoder.conv_in", x);
+    }
+    x = resnet(x, nullptr, "decoder.mid.block_1", Cm);
+    x = vae_attn(x, "decoder.mid.attn_1");
+    x = resnet(x, nullptr, "decoder.mid.block_2", Cm);
+    for (int lev = L - 1; lev >= 0; --lev) {
+      const int Co = cfg.block_out_channels[lev];
+      const std::string up = "decoder.up." + std::to_string(lev);
+      for (int j = 0; j < cfg.layers_per_block + 1; ++j) x = resnet(x, nullptr, up + ".block." + std::to_string(j), Co);
+      if (lev != 0) {
+        GemmOpt o; o.bias = w_f32(up + ".upsample.conv.bias", Co);
+        x = conv(x, nullptr, w_conv3(up + ".upsample.conv.weight", Co, Co), Co, 3, 1, 1, o);   // nearest 2x + conv (model.py:67-71)
+        tap(up + ".upsample", x);
+      }
+    }
+    Act hn = groupnorm(x, nullptr, "decoder.norm_out", cfg.norm_eps, 1);
+    {
+      const int C0 = cfg.block_out_channels[0], oc = cfg.out_channels;
+      const bf16* wo = w_conv3("decoder.conv_out.weight", oc, C0);
+      const float* bo = w_f32("decoder.conv_out.bias", oc);
+      const bf16* hp = hn.ptr; const int Hn = x.H, Wn = x.W;
+      emit([=, this](hipStream_t s) { LAUNCH_OK(nr_launch_conv_out_small(hp, C0, nimg, 1, Hn, Wn, wo, bo, oc, io.out, io.unit_range, s)); });
     }
     n_res = 0;
     res_shapes.clear();
@@ -850,6 +971,7 @@ struct nr_net {
 
   void build() {
     if (cfg.kind == NR_KIND_SGM_UNET) { build_sgm(); return; }
+    if (cfg.kind == NR_KIND_VAE_DECODER) { build_vae(); return; }
     const int L = cfg.num_levels;
     const int C0 = cfg.block_out_channels[0];
     const int temb_dim = 4 * C0;
@@ -1058,13 +1180,14 @@ struct nr_net {
       const bf16* wo = w_conv3("conv_out.weight", cfg.out_channels, C0);
       const float* bo = w_f32("conv_out.bias", cfg.out_channels);
       const bf16* hp = hn.ptr; const int Fn = F, Hn = H, Wn = W, oc = cfg.out_channels;
-      emit([=, this](hipStream_t s) { LAUNCH_OK(nr_launch_conv_out_small(hp, C0, nimg, Fn, Hn, Wn, wo, bo, oc, io.out, s)); });
+      emit([=, this](hipStream_t s) { LAUNCH_OK(nr_launch_conv_out_small(hp, C0, nimg, Fn, Hn, Wn, wo, bo, oc, io.out, 0, s)); });
     }
   }
 
   void plan(int batch, int frames, int h, int w, int ctxl) {
-    if (batch <= 0 || batch > 16 || frames <= 0 || h <= 0 || w <= 0 || ctxl <= 0) throw NrError(NR_ERR_ARG, "plan: bad shape");
-    const int down = 1 << (cfg.num_levels - 1);
+    const bool vae = cfg.kind == NR_KIND_VAE_DECODER;
+    if (batch <= 0 || batch > 16 || frames <= 0 || h <= 0 || w <= 0 || (ctxl <= 0 && !vae)) throw NrError(NR_ERR_ARG, "plan: bad shape");
+    const int down = vae ? 1 : 1 << (cfg.num_levels - 1);
     if (h % down != 0 || w % down != 0)
       throw NrError(NR_ERR_ARG, "plan: latent h,w must be multiples of " + std::to_string(down));
     HIP_OK(hipDeviceSynchronize());
@@ -1196,16 +1319,20 @@ extern "C" nr_status nr_net_create(const nr_net_config* cfg, nr_net** out) {
   NR_TRY
   if (!cfg || !out) throw NrError(NR_ERR_ARG, "null argument");
   if (cfg->num_levels < 2 || cfg->num_levels > NR_MAX_LEVELS) throw NrError(NR_ERR_ARG, "num_levels must be 2..4");
-  if (cfg->kind != NR_KIND_UNET3D && cfg->kind != NR_KIND_SPARSECTRL && cfg->kind != NR_KIND_SGM_UNET) throw NrError(NR_ERR_ARG, "bad kind");
+  if (cfg->kind != NR_KIND_UNET3D && cfg->kind != NR_KIND_SPARSECTRL && cfg->kind != NR_KIND_SGM_UNET && cfg->kind != NR_KIND_VAE_DECODER)
+    throw NrError(NR_ERR_ARG, "bad kind");
+  const bool vae = cfg->kind == NR_KIND_VAE_DECODER;
+  if (vae && (cfg->in_channels != 4 || cfg->out_channels != 3))
+    throw NrError(NR_ERR_UNSUPPORTED, "VAE decoder: z_channels must be 4 and out_ch 3");
   for (int i = 0; i < cfg->num_levels; ++i) {
     const int C = cfg->block_out_channels[i];
     if (C % 64 != 0) throw NrError(NR_ERR_UNSUPPORTED, "block_out_channels must be multiples of 64");
     if (C % cfg->norm_num_groups != 0) throw NrError(NR_ERR_ARG, "channels not divisible by norm_num_groups");
     const int hd = cfg->num_head_channels > 0 ? cfg->num_head_channels : (cfg->num_heads > 0 ? C / cfg->num_heads : 0);
-    if (hd <= 0 || C % hd != 0 || hd % 8 != 0 || hd > 160)
+    if (!vae && (hd <= 0 || C % hd != 0 || hd % 8 != 0 || hd > 160))
       throw NrError(NR_ERR_UNSUPPORTED, "head dim must divide the channels, be a multiple of 8 and <= 160");
   }
-  if (cfg->cross_attention_dim % 64 != 0) throw NrError(NR_ERR_UNSUPPORTED, "cross_attention_dim must be a multiple of 64");
+  if (!vae && cfg->cross_attention_dim % 64 != 0) throw NrError(NR_ERR_UNSUPPORTED, "cross_attention_dim must be a multiple of 64");
   if (cfg->norm_num_groups > 64) throw NrError(NR_ERR_UNSUPPORTED, "norm_num_groups > 64");
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess) throw NrError(NR_ERR_HIP, "no HIP device available: libneurons_amd requires an MI355X (gfx950) GPU");
@@ -1406,6 +1533,20 @@ extern "C" nr_status nr_sgm_unet_forward(nr_net* h, nr_stream stream, const floa
   NR_CATCH
 }
 
+extern "C" nr_status nr_vae_decode(nr_net* h, nr_stream stream, const float* z_dev, float z_scale, int32_t unit_range, float* out_dev) {
+  NR_TRY
+  if (!h || h->cfg.kind != NR_KIND_VAE_DECODER) throw NrError(NR_ERR_ARG, "handle is not a VAE decoder");
+  if (!h->planned) throw NrError(NR_ERR_STATE, "nr_net_plan() has not been called (or weights changed since)");
+  if (!z_dev || !out_dev) throw NrError(NR_ERR_ARG, "null tensor argument");
+  IO io;
+  std::memset(&io, 0, sizeof(io));
+  io.sample = z_dev; io.out = out_dev; io.in_scale = z_scale; io.unit_range = unit_range ? 1 : 0; io.scale = 1.f; io.cond_batch = 1;
+  h->io = io;
+  const float zeros[16] = {0};
+  h->run((hipStream_t)stream, zeros);
+  NR_CATCH
+}
+
 extern "C" nr_status nr_edm_cfg_euler_step(nr_stream stream, const float* net_dev, const float* x_dev, float* x_out_dev,
                                            int64_t n, float cfg_scale, float sigma_quantized, float sigma, float sigma_next) {
   NR_TRY
@@ -1427,7 +1568,7 @@ extern "C" nr_status nr_cfg_ddim_step(nr_stream stream, const float* eps_dev, co
 extern "C" nr_status nr_net_profile_last(nr_net* h, nr_stream stream, nr_profile* out) {
   NR_TRY
   if (!h || !out) throw NrError(NR_ERR_ARG, "null argument");
-  if (!h->planned || !h->io.ctx) throw NrError(NR_ERR_STATE, "run a forward first");
+  if (!h->planned || !h->io.sample) throw NrError(NR_ERR_STATE, "run a forward first");
   profile_last(h, (hipStream_t)stream, out, getenv("NR_PROFILE_CSV"));
   NR_CATCH
 }

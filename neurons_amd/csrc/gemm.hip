@@ -460,6 +460,7 @@ void apply_override(const NrGemmParams& p, Plan& pl, int& m_fast) {
 
 // fp32 scratch (bytes) a launch of this shape needs for split-K slabs (0 if none)
 extern "C" size_t nr_igemm_workspace_bytes(const NrGemmParams* pp) {
+  if (pp->out_f32) return 0;
   Plan pl = choose_plan(*pp);
   int mf = 0;
   apply_override(*pp, pl, mf);
@@ -480,8 +481,12 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
   const double a_elems = (double)p.M * Cin * (p.ksize == 3 ? (p.stride == 2 ? 4.0 : (p.ups ? 0.25 : 1.0)) : 1.0);
   int m_fast = w_elems > a_elems ? 1 : 0;
   apply_override(p, pl, m_fast);
+  if (p.out_f32) {   // raw fp32 result: the kernel's slab path with a single K slice, no reduce pass
+    if (p.geglu) return 7;
+    pl.splitk = 1;
+  }
   if (pl.splitk > 1 && !workspace) return 6;
-  float* partial = pl.splitk > 1 ? workspace : nullptr;
+  float* partial = p.out_f32 ? p.out_f32 : (pl.splitk > 1 ? workspace : nullptr);
   const unsigned grid = (unsigned)(((p.M + pl.bm - 1) / pl.bm) * ((p.N + pl.bn - 1) / pl.bn) * pl.splitk);
   if (pl.bm == 256) launch_tile<256, 128, 4, 2>(p, grid, pl, partial, m_fast, stream);
   else if (pl.bm == 128 && pl.bn == 160) launch_tile<128, 160, 2, 2>(p, grid, pl, partial, m_fast, stream);

@@ -17,6 +17,7 @@ Usage:  python oracle/gen_golden.py            (writes tests/golden/*.npz, a few
 """
 import functools
 import importlib.util
+import json
 import inspect
 import logging
 import os
@@ -434,6 +435,70 @@ def gen_sgm(out_dir):
 
 
 # --------------------------------------------------------------------------------------------------
+# first-stage decoder: the reference's own sgm Decoder (+ post_quant_conv as AutoencodingEngineLegacy.decode applies
+# it, autoencoder.py:459,490-494; that class itself needs Lightning) and the diffusers<->LDM VAE key map from the
+# reference's convert_ldm_vae_checkpoint
+# --------------------------------------------------------------------------------------------------
+def tiny_vae_config():
+    from neurons_amd.vae import VAEDecoderConfig
+    return VAEDecoderConfig(ch=64, ch_mult=(1, 1, 2, 2), num_res_blocks=2)
+
+
+@torch.no_grad()
+def gen_vae(out_dir):
+    from neurons_amd.vae import vae_random_state_dict, diffusers_vae_key_map, VAEDecoderConfig
+    from neurons_amd.synth import randn
+    install_sgm_scaffolding()
+    from sgm.modules.diffusionmodules.model import Decoder
+    cfg = tiny_vae_config()
+    sd = vae_random_state_dict(cfg, seed=91)
+    dec = Decoder(ch=cfg.ch, out_ch=cfg.out_ch, ch_mult=cfg.ch_mult, num_res_blocks=cfg.num_res_blocks, attn_resolutions=[],
+                  in_channels=3, resolution=64, z_channels=cfg.z_channels, attn_type="vanilla", double_z=True)
+    dsd = {k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")}
+    assert set(dec.state_dict().keys()) == set(dsd.keys()), set(dec.state_dict().keys()) ^ set(dsd.keys())
+    dec.load_state_dict(dsd, strict=True)
+    dec.eval()
+    pq = torch.nn.Conv2d(cfg.embed_dim, cfg.z_channels, 1)
+    pq.load_state_dict({"weight": sd["post_quant_conv.weight"], "bias": sd["post_quant_conv.bias"]})
+    z = randn("vae.z", (2, 4, 8, 8), 92)
+    out = dict(z=z.numpy())
+    out["image"] = dec(pq(z / 0.18215)).numpy()          # decode_first_stage (diffusion.py:118-135)
+    # decode_latents (pipeline_animation.py:243-256) on a (1, 4, 2, 8, 16) clip: per-frame decode, /2+.5, clamp
+    lat = randn("vae.lat", (1, 4, 2, 8, 16), 93) * 0.5
+    fr = (lat / 0.18215).permute(0, 2, 1, 3, 4).reshape(2, 4, 8, 16)
+    vid = torch.cat([dec(pq(fr[i:i + 1])) for i in range(2)])
+    out["lat"] = lat.numpy()
+    out["video"] = (vid.reshape(1, 2, 3, 64, 128).permute(0, 2, 1, 3, 4) / 2 + 0.5).clamp(0, 1).numpy()
+    np.savez_compressed(os.path.join(out_dir, "vae_tiny.npz"), **out)
+    print("vae_tiny:", {k: v.shape for k, v in out.items()}, "image abs mean", float(np.abs(out["image"]).mean()),
+          "video mean", float(out["video"].mean()), "clamped frac", float(((out["video"] == 0) | (out["video"] == 1)).mean()))
+    # key map: run the reference converter on an LDM-named VAE checkpoint whose tensors encode their own names
+    conv = load_ref_converter()
+    full = VAEDecoderConfig()
+    from neurons_amd.vae import vae_decoder_state_dict_schema
+    names = list(vae_decoder_state_dict_schema(full).keys())
+    ck = {"first_stage_model." + k: torch.full((1,), float(i)) for i, k in enumerate(names)}
+    # the converter also reads encoder / quant_conv entries: give it the ones it indexes unconditionally
+    for k in ("encoder.conv_in", "encoder.conv_out", "encoder.norm_out", "quant_conv"):
+        ck[f"first_stage_model.{k}.weight"] = torch.zeros(1)
+        ck[f"first_stage_model.{k}.bias"] = torch.zeros(1)
+    for k in ("q", "k", "v", "proj_out"):      # the converter squeezes these 1x1-conv weights ([:, :, 0, 0] / [:, :, 0])
+        n = f"first_stage_model.decoder.mid.attn_1.{k}.weight"
+        ck[n] = ck[n].reshape(1, 1, 1, 1)
+    class _Cfg(dict):
+        __getattr__ = dict.__getitem__
+    vcfg = _Cfg(down_block_types=["DownEncoderBlock2D"] * 4, up_block_types=["UpDecoderBlock2D"] * 4, layers_per_block=2)
+    conv_sd = conv.convert_ldm_vae_checkpoint(ck, vcfg)
+    ref_map = {k: names[int(v.reshape(-1)[0])] for k, v in conv_sd.items() if k.startswith(("decoder.", "post_quant_conv."))}
+    ours = diffusers_vae_key_map(full)
+    with open(os.path.join(out_dir, "vae_keys.json"), "w") as f:
+        json.dump({"diffusers_to_ldm": ref_map}, f, indent=0, sort_keys=True)
+    print("vae_keys.json:", len(ref_map), "decoder keys; map equal to ours:", ref_map == ours)
+    if ref_map != ours:
+        print(sorted(set(ref_map.items()) ^ set(ours.items()))[:10])
+
+
+# --------------------------------------------------------------------------------------------------
 # weight ingestion: run the reference's own converter / LoRA-merge functions on synthetic checkpoints
 # --------------------------------------------------------------------------------------------------
 def _load_ref_module(name, path):
@@ -443,13 +508,8 @@ def _load_ref_module(name, path):
     return m
 
 
-@torch.no_grad()
-def gen_weights(out_dir):
-    import json
-    from neurons_amd import _lib
-    from neurons_amd.synth import randn
-    from neurons_amd.unet3d import random_state_dict, state_dict_schema
-    from neurons_amd.weights import LDM_UNET_PREFIX, ldm_unet_key_map
+def load_ref_converter():
+    """Import the reference's animatediff/utils/convert_from_ckpt.py under the in-memory diffusers scaffolding."""
     install_scaffolding()
     # stand-ins for names the converter module only imports (never calls on this path)
     dm = sys.modules["diffusers.models"]
@@ -466,6 +526,16 @@ def gen_weights(out_dir):
     finally:
         if tv_stub is not None:
             sys.modules["torchvision"] = tv_stub
+    return conv
+
+
+@torch.no_grad()
+def gen_weights(out_dir):
+    from neurons_amd import _lib
+    from neurons_amd.synth import randn
+    from neurons_amd.unet3d import random_state_dict, state_dict_schema
+    from neurons_amd.weights import LDM_UNET_PREFIX, ldm_unet_key_map
+    conv = load_ref_converter()
     lora = _load_ref_module("ref_convert_lora", f"{REF}/animatediff/utils/convert_lora_safetensor_to_diffusers.py")
 
     # (1) LDM -> diffusers key map of the SD-1.5 topology: feed a checkpoint of 1-element tensors carrying an id
@@ -522,6 +592,7 @@ if __name__ == "__main__":
     gen_loop(out_dir, unet, ctrl)
     gen_leaf_ops(out_dir)
     gen_sgm(out_dir)
+    gen_vae(out_dir)
     gen_weights(out_dir)
     for f in sorted(os.listdir(out_dir)):
         print(f, os.path.getsize(os.path.join(out_dir, f)) // 1024, "KiB")
