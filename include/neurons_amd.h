@@ -164,9 +164,12 @@ nr_status nr_sgm_unet_forward(nr_net* h, nr_stream stream, const float* x_dev, f
  * diffusers parameter names, see neurons_amd/vae.py for the key map).  Config: kind NR_KIND_VAE_DECODER,
  * in_channels = z_channels (= embed_dim), out_channels = 3, block_out_channels = ch * ch_mult, layers_per_block =
  * num_res_blocks, norm_num_groups 32, norm_eps 1e-6; plan with (batch = images, frames = 1, h, w, ctx_len = 0).
- *   z_dev fp32 [batch][z][h][w]; z_scale = 1 / scale_factor; out_dev fp32 [batch][3][8h][8w];
- *   unit_range != 0 fuses the callers' (x / 2 + 0.5).clamp(0, 1) (pipeline_animation.py:252) into the last kernel.  */
-nr_status nr_vae_decode(nr_net* h, nr_stream stream, const float* z_dev, float z_scale, int32_t unit_range, float* out_dev);
+ *   z_dev fp32 [batch][z][h][w]; z_scale = 1 / scale_factor; out_dev fp32 [batch][3][8h][8w] =
+ *   decoder(z) * out_mul + out_add, clamped to [0, 1] when clamp01 != 0: the callers' image post-scaling fused into
+ *   the last kernel ((x / 2 + 0.5).clamp(0, 1) pipeline_animation.py:252; clamp(x * .8 + .2, 0, 1) utils.py:348);
+ *   (1, 0, 0) returns the raw decoder output.                                                                     */
+nr_status nr_vae_decode(nr_net* h, nr_stream stream, const float* z_dev, float z_scale, float out_mul, float out_add,
+                        int32_t clamp01, float* out_dev);
 
 /* replaces Denoiser.forward's output scaling + VanillaCFG + EulerEDMSampler.sampler_step with s_churn = 0
  * (denoiser.py:36-39, denoiser_scaling.py:29-37, guiders.py:28-31, sampling_utils.py:34-35, sampling.py:98-112):

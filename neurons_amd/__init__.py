@@ -5,6 +5,8 @@ Host side mirrors the reference's Python interface for this path (same names, ar
   NativeSparseCtrl    ~ animatediff/models/sparse_controlnet.py:85  SparseControlNetModel
   DDIMScheduler       ~ diffusers==0.11.1 DDIMScheduler (call sites pipeline_neuroclips.py:378-483)
   NeuroclipsPipeline  ~ animatediff/pipelines/pipeline_neuroclips.py:43
+  sgm.NativeSGMUNet   ~ generative_models/sgm/modules/diffusionmodules/openaimodel.py:472 (unCLIP keyframes)
+  vae.NativeVAEDecoder ~ generative_models/sgm/modules/diffusionmodules/model.py:612 Decoder (= AutoencoderKL.decode)
 All arithmetic of the two networks runs in libneurons_amd.so (hand-written HIP for gfx950) behind the
 C ABI in include/neurons_amd.h; PyTorch supplies device memory, streams and torch.distributed only.
 """

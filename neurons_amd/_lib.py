@@ -75,7 +75,7 @@ SYMBOLS = {
     "nr_sparsectrl_forward": (_I32, [_VP, _VP, _VP, _FP, _VP, _I32, _VP, _VP, _I32, C.c_float, C.POINTER(_VP), _VP]),
     "nr_denoise_step_forward": (_I32, [_VP, _VP, _VP, _VP, _FP, _VP, _I32, _VP, _VP, _I32, C.c_float, C.POINTER(_VP), _VP, _VP]),
     "nr_sgm_unet_forward": (_I32, [_VP, _VP, _VP, C.c_float, _FP, _VP, _I32, _VP, _VP]),
-    "nr_vae_decode": (_I32, [_VP, _VP, _VP, C.c_float, _I32, _VP]),
+    "nr_vae_decode": (_I32, [_VP, _VP, _VP, C.c_float, C.c_float, C.c_float, _I32, _VP]),
     "nr_edm_cfg_euler_step": (_I32, [_VP, _VP, _VP, _VP, _I64, C.c_float, C.c_float, C.c_float, C.c_float]),
     "nr_cfg_ddim_step": (_I32, [_VP, _VP, _VP, _VP, _I64, C.c_float, _I32, C.c_double, C.c_double]),
     "nr_net_profile_last": (_I32, [_VP, _VP, C.POINTER(NrProfile)]),

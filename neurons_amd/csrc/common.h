@@ -108,7 +108,8 @@ struct NrGnParams {
   int nimg, hw;                     // images, pixels per image
   int groups;
   int pix_per_blk, nchunk;          // pixel chunking: nchunk = ceil(hw / pix_per_blk)
-  float* partial;                   // [nimg][nchunk][groups][2]
+  float* partial;                   // [nimg][nchunk][groups][2], then (large images) [nimg][groups][2] mean/rstd
+  int finalized;                    // 1: gn_apply reads mean/rstd written by gn_finalize instead of re-reducing
   const float* gamma; const float* beta;  // [C]
   float eps;
   int silu;

@@ -75,7 +75,7 @@ template <int COUT>
 __global__ __launch_bounds__(256) void conv_out_small_kernel(const bf16* __restrict__ x, int Cin, int nimg, int F, int H,
                                                              int W, const bf16* __restrict__ w,
                                                              const float* __restrict__ bias, float* __restrict__ out,
-                                                             int unit_range) {
+                                                             float out_mul, float out_add, int clamp01) {
   const int lane = threadIdx.x & 63;
   const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long npix = (long long)nimg * H * W;
@@ -106,8 +106,9 @@ __global__ __launch_bounds__(256) void conv_out_small_kernel(const bf16* __restr
     const int b = n / F, f = n - b * F;
 #pragma unroll
     for (int o = 0; o < COUT; ++o) {
-      float v = acc[o] + bias[o];
-      if (unit_range) v = fminf(fmaxf(v * 0.5f + 0.5f, 0.f), 1.f);   // (x / 2 + 0.5).clamp(0, 1)  pipeline_animation.py:252
+      // image post-scaling of the callers: (x / 2 + 0.5).clamp(0, 1) pipeline_animation.py:252; clamp(x*.8+.2) utils.py:348
+      float v = (acc[o] + bias[o]) * out_mul + out_add;
+      if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
       out[((((size_t)b * COUT + o) * F + f) * H + y) * W + xx] = v;
     }
   }
@@ -289,14 +290,14 @@ extern "C" int nr_launch_conv_in_small(const float* s0, const float* s1, int c0,
 }
 
 extern "C" int nr_launch_conv_out_small(const bf16* x, int Cin, int nimg, int F, int H, int W, const bf16* w,
-                                        const float* bias, int Cout, float* out, int unit_range, hipStream_t stream) {
+                                        const float* bias, int Cout, float* out, float out_mul, float out_add, int clamp01, hipStream_t stream) {
   if (Cin % 8 != 0) return 1;
   const long long npix = (long long)nimg * H * W;
   const unsigned blocks = (unsigned)((npix + 3) / 4);
   if (Cout == 4)
-    hipLaunchKernelGGL((conv_out_small_kernel<4>), dim3(blocks), dim3(256), 0, stream, x, Cin, nimg, F, H, W, w, bias, out, unit_range);
+    hipLaunchKernelGGL((conv_out_small_kernel<4>), dim3(blocks), dim3(256), 0, stream, x, Cin, nimg, F, H, W, w, bias, out, out_mul, out_add, clamp01);
   else if (Cout == 3)
-    hipLaunchKernelGGL((conv_out_small_kernel<3>), dim3(blocks), dim3(256), 0, stream, x, Cin, nimg, F, H, W, w, bias, out, unit_range);
+    hipLaunchKernelGGL((conv_out_small_kernel<3>), dim3(blocks), dim3(256), 0, stream, x, Cin, nimg, F, H, W, w, bias, out, out_mul, out_add, clamp01);
   else
     return 2;
   return 0;

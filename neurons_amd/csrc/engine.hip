@@ -42,7 +42,7 @@ int nr_launch_post_quant(const float* z, float scale, const float* Q, const floa
                          hipStream_t stream);
 int nr_launch_softmax_rows(const float* S, bf16* P, int rows, int L, float scale, hipStream_t stream);
 int nr_launch_conv_out_small(const bf16* x, int Cin, int nimg, int F, int H, int W, const bf16* w, const float* bias,
-                             int Cout, float* out, int unit_range, hipStream_t stream);
+                             int Cout, float* out, float out_mul, float out_add, int clamp01, hipStream_t stream);
 int nr_launch_timestep_sincos(const float* t, int M, int dim, float* out, hipStream_t stream);
 int nr_launch_linear_small(const float* x, int M, int K, const bf16* W, const float* b, int N, int in_act, int out_act,
                            float* y, const float* addend, hipStream_t stream);
@@ -163,7 +163,8 @@ struct IO {
   void* out_mid = nullptr;
   const float* y = nullptr;     // sgm "vector" conditioning
   float in_scale = 1.f;         // sgm c_in; VAE: 1 / scale_factor
-  int unit_range = 0;           // VAE: fuse (x / 2 + 0.5).clamp(0, 1) into conv_out
+  float out_mul = 1.f, out_add = 0.f;   // VAE: image post-scaling fused into conv_out
+  int clamp01 = 0;
   bool operator==(const IO& o) const { return std::memcmp(this, &o, sizeof(IO)) == 0; }
 };
 
@@ -850,7 +851,7 @@ struct nr_net {
       const bf16* wo = w_conv3("out.2.weight", cfg.out_channels, C0);
       const float* bo = w_f32("out.2.bias", cfg.out_channels);
       const bf16* hp = hn.ptr; const int Hn = H, Wn = W, oc = cfg.out_channels;
-      emit([=, this](hipStream_t s) { LAUNCH_OK(nr_launch_conv_out_small(hp, C0, nimg, 1, Hn, Wn, wo, bo, oc, io.out, 0, s)); });
+      emit([=, this](hipStream_t s) { LAUNCH_OK(nr_launch_conv_out_small(hp, C0, nimg, 1, Hn, Wn, wo, bo, oc, io.out, 1.f, 0.f, 0, s)); });
     }
     n_res = 0;
     res_shapes.clear();
@@ -963,7 +964,7 @@ struct nr_net {
       const bf16* wo = w_conv3("decoder.conv_out.weight", oc, C0);
       const float* bo = w_f32("decoder.conv_out.bias", oc);
       const bf16* hp = hn.ptr; const int Hn = x.H, Wn = x.W;
-      emit([=, this](hipStream_t s) { LAUNCH_OK(nr_launch_conv_out_small(hp, C0, nimg, 1, Hn, Wn, wo, bo, oc, io.out, io.unit_range, s)); });
+      emit([=, this](hipStream_t s) { LAUNCH_OK(nr_launch_conv_out_small(hp, C0, nimg, 1, Hn, Wn, wo, bo, oc, io.out, io.out_mul, io.out_add, io.clamp01, s)); });
     }
     n_res = 0;
     res_shapes.clear();
@@ -1180,7 +1181,7 @@ struct nr_net {
       const bf16* wo = w_conv3("conv_out.weight", cfg.out_channels, C0);
       const float* bo = w_f32("conv_out.bias", cfg.out_channels);
       const bf16* hp = hn.ptr; const int Fn = F, Hn = H, Wn = W, oc = cfg.out_channels;
-      emit([=, this](hipStream_t s) { LAUNCH_OK(nr_launch_conv_out_small(hp, C0, nimg, Fn, Hn, Wn, wo, bo, oc, io.out, 0, s)); });
+      emit([=, this](hipStream_t s) { LAUNCH_OK(nr_launch_conv_out_small(hp, C0, nimg, Fn, Hn, Wn, wo, bo, oc, io.out, 1.f, 0.f, 0, s)); });
     }
   }
 
@@ -1533,14 +1534,15 @@ extern "C" nr_status nr_sgm_unet_forward(nr_net* h, nr_stream stream, const floa
   NR_CATCH
 }
 
-extern "C" nr_status nr_vae_decode(nr_net* h, nr_stream stream, const float* z_dev, float z_scale, int32_t unit_range, float* out_dev) {
+extern "C" nr_status nr_vae_decode(nr_net* h, nr_stream stream, const float* z_dev, float z_scale, float out_mul, float out_add,
+                                   int32_t clamp01, float* out_dev) {
   NR_TRY
   if (!h || h->cfg.kind != NR_KIND_VAE_DECODER) throw NrError(NR_ERR_ARG, "handle is not a VAE decoder");
   if (!h->planned) throw NrError(NR_ERR_STATE, "nr_net_plan() has not been called (or weights changed since)");
   if (!z_dev || !out_dev) throw NrError(NR_ERR_ARG, "null tensor argument");
   IO io;
   std::memset(&io, 0, sizeof(io));
-  io.sample = z_dev; io.out = out_dev; io.in_scale = z_scale; io.unit_range = unit_range ? 1 : 0; io.scale = 1.f; io.cond_batch = 1;
+  io.sample = z_dev; io.out = out_dev; io.in_scale = z_scale; io.out_mul = out_mul; io.out_add = out_add; io.clamp01 = clamp01 ? 1 : 0; io.scale = 1.f; io.cond_batch = 1;
   h->io = io;
   const float zeros[16] = {0};
   h->run((hipStream_t)stream, zeros);

@@ -77,7 +77,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(NrGnParams p) {
   const int img = blockIdx.y, chunk = blockIdx.x;
   const int tid = threadIdx.x;
   const int cg = C / p.groups;
-  if (tid < p.groups) {
+  if (p.finalized) {
+    if (tid < p.groups) {
+      const float* o = p.partial + (size_t)p.nimg * p.nchunk * p.groups * 2 + ((size_t)img * p.groups + tid) * 2;
+      gmean[tid] = o[0];
+      grstd[tid] = o[1];
+    }
+  } else if (tid < p.groups) {
     float s = 0.f, q = 0.f;
     for (int k = 0; k < p.nchunk; ++k) {
       const float* o = p.partial + (((size_t)img * p.nchunk + k) * p.groups + tid) * 2;
@@ -116,6 +122,32 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(NrGnParams p) {
       o[e] = (bf16)f;
     }
     *(bf16x8*)(p.out + row * p.ldo + c) = o;
+  }
+}
+
+// Large images (VAE decoder levels: 10^4..10^6 pixels per image) use many small pixel chunks so the streaming
+// kernels fill the chip; this kernel folds the per-chunk partials to mean / rstd once per (image, group) in a fixed
+// order (deterministic) instead of every apply block re-reducing thousands of partials.  grid (groups, nimg).
+__global__ __launch_bounds__(256) void gn_finalize_kernel(NrGnParams p) {
+  __shared__ float red[2][4];
+  const int g = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+  float s = 0.f, q = 0.f;
+  for (int k = tid; k < p.nchunk; k += 256) {
+    const float* o = p.partial + (((size_t)img * p.nchunk + k) * p.groups + g) * 2;
+    s += o[0]; q += o[1];
+  }
+  s = wave_sum(s); q = wave_sum(q);
+  if ((tid & 63) == 0) { red[0][tid >> 6] = s; red[1][tid >> 6] = q; }
+  __syncthreads();
+  if (tid == 0) {
+    s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const int cg = (p.c0 + p.c1) / p.groups;
+    const float inv = 1.0f / ((float)cg * (float)p.hw);
+    const float mean = s * inv;
+    float* o = p.partial + (size_t)p.nimg * p.nchunk * p.groups * 2 + ((size_t)img * p.groups + g) * 2;
+    o[0] = mean;
+    o[1] = rsqrtf(fmaxf(q * inv - mean * mean, 0.f) + p.eps);
   }
 }
 
@@ -250,14 +282,16 @@ void launch_ln(const bf16* x, int ldx, bf16* out, int ldo, int M, int C, const f
 }  // namespace
 
 extern "C" int nr_gn_workspace_floats(int nimg, int hw, int groups, int* pix_per_blk_out, int* nchunk_out) {
-  // aim for >= ~16 chunks per image but at least 8 pixels per block
+  // aim for >= ~16 chunks per image but at least 8 and at most 128 pixels per block (large images: many chunks,
+  // folded by gn_finalize)
   int ppb = (hw + 15) / 16;
   if (ppb < 8) ppb = 8;
+  if (ppb > 128) ppb = 128;
   if (ppb > hw) ppb = hw;
   const int nchunk = (hw + ppb - 1) / ppb;
   if (pix_per_blk_out) *pix_per_blk_out = ppb;
   if (nchunk_out) *nchunk_out = nchunk;
-  return nimg * nchunk * groups * 2;
+  return nimg * nchunk * groups * 2 + nimg * groups * 2;
 }
 
 extern "C" int nr_launch_groupnorm(NrGnParams* pp, hipStream_t stream) {
@@ -284,7 +318,9 @@ extern "C" int nr_launch_groupnorm(NrGnParams* pp, hipStream_t stream) {
   const size_t shm_apply = (size_t)2 * C * sizeof(float);
   if (shm_stats > 60000 || shm_apply > 60000) return 3;
   dim3 grid(p.nchunk, p.nimg);
+  p.finalized = p.nchunk > 16 ? 1 : 0;
   hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), shm_stats, stream, p);
+  if (p.finalized) hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.groups, p.nimg), dim3(256), 0, stream, p);
   hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), shm_apply, stream, p);
   return 0;
 }

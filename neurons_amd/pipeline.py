@@ -10,7 +10,8 @@ Kept identical to the reference (so ``scripts/neuroclips_video*.py`` can call it
   * SparseCtrl cond/mask construction (:447-458) — built once, they are step-invariant
 Additive extensions (defaults keep reference behaviour): ``text_embeddings=`` (skip the CLIP encoder),
 ``noise=`` (explicit noise instead of the in-call draw), ``output_type="latent"`` (skip the VAE).
-VAE and CLIP stay PyTorch modules supplied by the caller (north-star: out of the HIP scope).
+``vae`` may be a ``neurons_amd.vae.NativeVAEDecoder`` (the decode then also runs in HIP) or the
+caller's PyTorch ``AutoencoderKL``; CLIP stays a PyTorch module supplied by the caller.
 """
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Union
@@ -52,7 +53,7 @@ class NeuroclipsPipeline:
             scheduler.config.clip_sample = False
         self.register_modules(vae=vae, text_encoder=text_encoder, tokenizer=tokenizer, unet=unet, scheduler=scheduler,
                               controlnet=controlnet)
-        if vae is not None and hasattr(vae, "config"):
+        if vae is not None and hasattr(vae, "config") and hasattr(vae.config, "block_out_channels"):
             self.vae_scale_factor = 2 ** (len(vae.config.block_out_channels) - 1)
         else:
             self.vae_scale_factor = 8
@@ -132,8 +133,13 @@ class NeuroclipsPipeline:
             text_embeddings = torch.cat([uncond_embeddings, text_embeddings])
         return text_embeddings
 
-    # ---- VAE decode, frame by frame (pipeline_neuroclips.py:242-255); VAE stays PyTorch ----
+    # ---- VAE decode (pipeline_neuroclips.py:242-255).  A NativeVAEDecoder as ``vae`` decodes all frames in one engine
+    # launch with the /2+0.5 clamp fused; any other ``vae`` (the caller's PyTorch AutoencoderKL) goes frame by frame
+    # exactly as the reference does ----
     def decode_latents(self, latents):
+        from .vae import NativeVAEDecoder
+        if isinstance(self.vae, NativeVAEDecoder):
+            return self.vae.decode_latents(latents).cpu().float().numpy()
         video_length = latents.shape[2]
         latents = 1 / 0.18215 * latents
         b, c, f, h, w = latents.shape

@@ -173,10 +173,14 @@ class NativeVAEDecoder(_NativeNet):
         self._io_z = torch.empty(b, self.config.z_channels, h, w, dtype=torch.float32, device=dev)
         self._out_shape = (self.config.out_ch, h * up, w * up)
 
-    def decode(self, z, z_scale: float = 1.0, unit_range: bool = False, chunk: int = None):
+    def decode(self, z, z_scale: float = 1.0, unit_range: bool = False, chunk: int = None, post=None):
         """z [n][4][h][w] (any float dtype, on the GPU) -> fp32 [n][3][8h][8w].  ``z_scale`` multiplies the latent
-        first (1 / scale_factor); ``unit_range`` fuses ``(x / 2 + 0.5).clamp(0, 1)``.  Images are independent
-        (GroupNorm is per sample), so ``chunk`` only bounds the activation arena."""
+        first (1 / scale_factor); ``post=(mul, add)`` fuses ``clamp(x * mul + add, 0, 1)`` into the last kernel
+        (``unit_range`` = (0.5, 0.5)).  Images are independent (GroupNorm is per sample), so ``chunk`` only bounds
+        the activation arena."""
+        if unit_range:
+            post = (0.5, 0.5)
+        mul, add, clamp = (float(post[0]), float(post[1]), 1) if post is not None else (1.0, 0.0, 0)
         if not z.is_cuda:
             raise RuntimeError("NativeVAEDecoder.decode: CUDA (ROCm) tensors required; there is no CPU fallback")
         if z.dim() != 4 or z.shape[1] != self.config.z_channels:
@@ -191,7 +195,7 @@ class NativeVAEDecoder(_NativeNet):
             self._ensure_plan(zc.shape[0], 1, h, w, 0)
             self._io_z.copy_(zc)
             out = torch.empty((zc.shape[0],) + self._out_shape, dtype=torch.float32, device=z.device)
-            _lib.check(lib.nr_vae_decode(self._handle(), stream, self._io_z.data_ptr(), float(z_scale), 1 if unit_range else 0,
+            _lib.check(lib.nr_vae_decode(self._handle(), stream, self._io_z.data_ptr(), float(z_scale), mul, add, clamp,
                                          out.data_ptr()))
             outs.append(out)
         return outs[0] if len(outs) == 1 else torch.cat(outs)
@@ -202,6 +206,10 @@ class NativeVAEDecoder(_NativeNet):
     def decode_first_stage(self, z, scale_factor: float = 0.18215):
         """sgm/models/diffusion.py:118-135."""
         return self.decode(z, z_scale=1.0 / scale_factor)
+
+    def decode_keyframe(self, samples_z, scale_factor: float = 0.18215):
+        """The tail of utils.unclip_recon (:343-349): decode_first_stage then ``clamp(x * .8 + .2, 0, 1)``."""
+        return self.decode(samples_z, z_scale=1.0 / scale_factor, post=(0.8, 0.2))
 
     def decode_latents(self, latents):
         """pipeline_animation.py:243-256: (b, c, f, h, w) latents -> (b, 3, f, 8h, 8w) video in [0, 1] (kept on the GPU;

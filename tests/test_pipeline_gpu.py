@@ -41,3 +41,29 @@ def test_pipeline_input_errors(cuda):
         pipe(3, video_length=8, height=64, width=64)
     with pytest.raises(ValueError, match="Unexpected latents shape"):
         pipe("", video_length=8, height=64, width=64, latents=torch.zeros(1, 4, 8, 4, 4), text_embeddings=torch.zeros(2, 77, 64))
+
+
+def test_c1_loop_to_pixels_with_native_vae(cuda):
+    """Whole video path in HIP: 10-step loop + first-stage decode; pixels against the oracle decode of the REFERENCE's
+    final latents (so the error includes everything the loop accumulated)."""
+    from neurons_amd import DDIMScheduler, NeuroclipsPipeline
+    from neurons_amd.vae import NativeVAEDecoder, vae_random_state_dict
+    from oracle import vae_oracle as V
+    from oracle.gen_golden import tiny_vae_config
+    g = np.load(os.path.join(GOLD, "c1_loop.npz"))
+    unet, ctrl = _tiny()
+    vcfg = tiny_vae_config()
+    vsd = vae_random_state_dict(vcfg, seed=91)
+    vae = NativeVAEDecoder(vcfg).to("cuda")
+    vae.load_state_dict(vsd)
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
+    pipe = NeuroclipsPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, scheduler=sched, controlnet=ctrl).to("cuda")
+    video = pipe("", video_length=8, height=64, width=64, num_inference_steps=int(g["steps"]), guidance_scale=float(g["guidance"]),
+                 latents=torch.from_numpy(g["latents"]).cuda(), noise=torch.from_numpy(g["noise"]),
+                 text_embeddings=torch.from_numpy(g["ctx"]).cuda(), controlnet_images=torch.from_numpy(g["cimg"]).cuda(),
+                 controlnet_image_index=[0], low_strength=0.3, output_type="tensor").videos
+    assert tuple(video.shape) == (1, 3, 8, 64, 64) and video.dtype == torch.float32
+    with torch.no_grad():
+        ref = V.decode_latents(vsd, torch.from_numpy(g["final"]), len(vcfg.ch_mult), vcfg.num_res_blocks)
+    rel, psnr = metrics("C1 loop + native VAE pixels vs oracle decode of reference latents", video, ref)
+    assert psnr >= 35.0

@@ -131,6 +131,9 @@ def test_full_size_clip_decode_properties(cuda):
     assert torch.equal(vid[0].permute(1, 0, 2, 3), (raw / 2 + 0.5).clamp(0, 1))
     _, p2 = metrics("16-frame vs 4x4-frame decode", dec.decode(frames, z_scale=1 / 0.18215, chunk=4), raw)
     assert p2 >= 50.0
+    key = dec.decode_keyframe(frames[:2])                                     # utils.py:343-348 post-scaling
+    raw2 = dec.decode(frames[:2], z_scale=1 / 0.18215)                         # same 2-image plan as `key`
+    assert torch.allclose(key, (raw2 * 0.8 + 0.2).clamp(0, 1), rtol=0, atol=1e-6)        # fma vs mul+add rounding
     with torch.no_grad():
         ref = V.decode(sd, frames[5:6] / 0.18215, 4, 2)
     rel, psnr = metrics("256x256 frame vs oracle", raw[5:6], ref)
