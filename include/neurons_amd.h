@@ -43,6 +43,8 @@ typedef struct nr_net nr_net;
 
 #define NR_KIND_VAE_DECODER 3 /* generative_models/sgm/modules/diffusionmodules/model.py:612 Decoder behind
                                  sgm/models/autoencoder.py:490 decode (= diffusers AutoencoderKL.decode)     */
+#define NR_KIND_VAE_ENCODER 4 /* generative_models/sgm/modules/diffusionmodules/model.py:495 Encoder + quant_conv
+                                 (sgm/models/autoencoder.py:468-488 = diffusers AutoencoderKL.encode)         */
 
 #define NR_MAX_LEVELS 4
 
@@ -170,6 +172,21 @@ nr_status nr_sgm_unet_forward(nr_net* h, nr_stream stream, const float* x_dev, f
  *   (1, 0, 0) returns the raw decoder output.                                                                     */
 nr_status nr_vae_decode(nr_net* h, nr_stream stream, const float* z_dev, float z_scale, float out_mul, float out_add,
                         int32_t clamp01, float* out_dev);
+
+/* replaces vae.encode(2 * x - 1).latent_dist (scripts/neuroclips_video.py:267,282, scripts/neuroclips_video_enhance.py:
+ * 268,283) = AutoencodingEngine.encode up to the moments (sgm/models/autoencoder.py:468-488: Encoder.forward
+ * model.py:584-609 -> quant_conv).  Config: kind NR_KIND_VAE_ENCODER, in_channels 3, out_channels = 2 * z_channels = 8,
+ * block_out_channels = ch * ch_mult, layers_per_block = num_res_blocks, norm eps 1e-6; plan with (batch = images,
+ * frames = 1, IMAGE h, IMAGE w, ctx_len = 0).
+ *   x_dev fp32 [batch][3][h][w]; the network sees x * in_mul + in_add (the callers' 2 * x - 1);
+ *   moments_dev fp32 [batch][8][h/8][w/8] = (mean | logvar), the DiagonalGaussianDistribution parameters.          */
+nr_status nr_vae_encode(nr_net* h, nr_stream stream, const float* x_dev, float in_mul, float in_add, float* moments_dev);
+
+/* DiagonalGaussianDistribution.sample() / .mode() (sgm/modules/distributions/distributions.py:24-42,71-72) times the
+ * callers' latent scale: out[n][z][hw] = (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise) * scale.
+ * noise_dev fp32 [n][z][hw] is drawn by the caller (RNG order is the caller's contract); null = mode().          */
+nr_status nr_gaussian_sample(nr_stream stream, const float* moments_dev, const float* noise_dev, float* out_dev, int32_t n,
+                             int32_t z_channels, int32_t hw, float scale);
 
 /* replaces Denoiser.forward's output scaling + VanillaCFG + EulerEDMSampler.sampler_step with s_churn = 0
  * (denoiser.py:36-39, denoiser_scaling.py:29-37, guiders.py:28-31, sampling_utils.py:34-35, sampling.py:98-112):

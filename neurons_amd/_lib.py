@@ -14,6 +14,7 @@ NR_KIND_UNET3D = 0
 NR_KIND_SPARSECTRL = 1
 NR_KIND_SGM_UNET = 2
 NR_KIND_VAE_DECODER = 3
+NR_KIND_VAE_ENCODER = 4
 NR_MAX_LEVELS = 4
 
 
@@ -76,6 +77,8 @@ SYMBOLS = {
     "nr_denoise_step_forward": (_I32, [_VP, _VP, _VP, _VP, _FP, _VP, _I32, _VP, _VP, _I32, C.c_float, C.POINTER(_VP), _VP, _VP]),
     "nr_sgm_unet_forward": (_I32, [_VP, _VP, _VP, C.c_float, _FP, _VP, _I32, _VP, _VP]),
     "nr_vae_decode": (_I32, [_VP, _VP, _VP, C.c_float, C.c_float, C.c_float, _I32, _VP]),
+    "nr_vae_encode": (_I32, [_VP, _VP, _VP, C.c_float, C.c_float, _VP]),
+    "nr_gaussian_sample": (_I32, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, C.c_float]),
     "nr_edm_cfg_euler_step": (_I32, [_VP, _VP, _VP, _VP, _I64, C.c_float, C.c_float, C.c_float, C.c_float]),
     "nr_cfg_ddim_step": (_I32, [_VP, _VP, _VP, _VP, _I64, C.c_float, _I32, C.c_double, C.c_double]),
     "nr_net_profile_last": (_I32, [_VP, _VP, C.POINTER(NrProfile)]),

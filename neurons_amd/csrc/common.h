@@ -84,6 +84,7 @@ struct NrGemmParams {
   int ldo;
   float out_scale;     // (acc + bias + rowvec) * out_scale + res
   int geglu;           // 1: W rows are (value16|gate16)-interleaved; out has N/2 columns
+  int pad_tl0;         // 3x3 only: 1 = no top/left padding (bottom/right zero) — the VAE Downsample's F.pad (0,1,0,1)
   float* out_f32;      // non-null: write the raw fp32 accumulators to out_f32[M][N] and skip the epilogue (attention scores)
 };
 

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void conv_in_small_kernel(const float* __restr
                                                             int c0, int c1, int src_batch, int F, int H, int W,
                                                             const float* __restrict__ wT, const float* __restrict__ bias,
                                                             const float* __restrict__ addend, int Cout,
-                                                            bf16* __restrict__ out, float in_scale) {
+                                                            bf16* __restrict__ out, float in_scale, float in_shift) {
   // thread = one output channel (coalesced weight reads and output stores) with its 9*CIN weights in registers,
   // register-blocked over 8 pixels of the row; the 3-row input patch sits in LDS (wave-uniform broadcast reads).
   extern __shared__ float patch[];
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void conv_in_small_kernel(const float* __restr
     if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
       const float* s; int cc, cs;
       if (ci < c0) { s = s0; cc = ci; cs = c0; } else { s = s1; cc = ci - c0; cs = c1; }
-      v = s[((((size_t)b * cs + cc) * F + f) * H + iy) * W + ix] * in_scale;
+      v = s[((((size_t)b * cs + cc) * F + f) * H + iy) * W + ix] * in_scale + in_shift;   // padding stays 0
     }
     patch[i] = v;
   }
@@ -128,6 +128,23 @@ __global__ void post_quant_kernel(const float* __restrict__ z, float scale, cons
     for (int c = 0; c < C; ++c) a += Q[co * C + c] * v[c];
     out[((size_t)n * C + co) * hw + p] = a;
   }
+}
+
+// DiagonalGaussianDistribution.sample / .mode (sgm/modules/distributions/distributions.py:24-42; diffusers twin used
+// by scripts/neuroclips_video.py:267): moments [n][2z][hw] -> out[n][z][hw] = (mean + exp(0.5*clamp(logvar,-30,20)) * noise) * scale
+__global__ void gaussian_sample_kernel(const float* __restrict__ moments, const float* __restrict__ noise, float* __restrict__ out,
+                                       long long total, int zc, int hw, float scale) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const long long n = idx / ((long long)zc * hw);
+  const long long r = idx - n * (long long)zc * hw;
+  const float mean = moments[n * 2 * zc * hw + r];
+  float v = mean;
+  if (noise) {
+    const float lv = fminf(fmaxf(moments[n * 2 * zc * hw + (long long)zc * hw + r], -30.f), 20.f);
+    v += expf(0.5f * lv) * noise[idx];
+  }
+  out[idx] = v * scale;
 }
 
 // row softmax of fp32 scores -> bf16 probabilities: P[r][:] = softmax(S[r][:] * scale).  One 256-thread block per row.
@@ -275,15 +292,18 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ a, bf16* __restrict
 
 extern "C" int nr_launch_conv_in_small(const float* s0, const float* s1, int c0, int c1, int src_batch, int nimg, int F,
                                        int H, int W, const float* wT, const float* bias, const float* addend, int Cout,
-                                       bf16* out, float in_scale, hipStream_t stream) {
+                                       bf16* out, float in_scale, float in_shift, hipStream_t stream) {
   const size_t shm = ((size_t)(c0 + c1) * 3 * (W + 2) + 16) * sizeof(float);   // +16: masked over-read of the last row
   if (shm > 60000) return 1;
   if (c0 + c1 == 4)
     hipLaunchKernelGGL((conv_in_small_kernel<4>), dim3(H, nimg), dim3(256), shm, stream, s0, s1, c0, c1, src_batch, F, H, W, wT,
-                       bias, addend, Cout, out, in_scale);
+                       bias, addend, Cout, out, in_scale, in_shift);
   else if (c0 + c1 == 5)
     hipLaunchKernelGGL((conv_in_small_kernel<5>), dim3(H, nimg), dim3(256), shm, stream, s0, s1, c0, c1, src_batch, F, H, W, wT,
-                       bias, addend, Cout, out, in_scale);
+                       bias, addend, Cout, out, in_scale, in_shift);
+  else if (c0 + c1 == 3)
+    hipLaunchKernelGGL((conv_in_small_kernel<3>), dim3(H, nimg), dim3(256), shm, stream, s0, s1, c0, c1, src_batch, F, H, W, wT,
+                       bias, addend, Cout, out, in_scale, in_shift);
   else
     return 2;
   return 0;
@@ -296,6 +316,8 @@ extern "C" int nr_launch_conv_out_small(const bf16* x, int Cin, int nimg, int F,
   const unsigned blocks = (unsigned)((npix + 3) / 4);
   if (Cout == 4)
     hipLaunchKernelGGL((conv_out_small_kernel<4>), dim3(blocks), dim3(256), 0, stream, x, Cin, nimg, F, H, W, w, bias, out, out_mul, out_add, clamp01);
+  else if (Cout == 8)
+    hipLaunchKernelGGL((conv_out_small_kernel<8>), dim3(blocks), dim3(256), 0, stream, x, Cin, nimg, F, H, W, w, bias, out, out_mul, out_add, clamp01);
   else if (Cout == 3)
     hipLaunchKernelGGL((conv_out_small_kernel<3>), dim3(blocks), dim3(256), 0, stream, x, Cin, nimg, F, H, W, w, bias, out, out_mul, out_add, clamp01);
   else
@@ -308,6 +330,14 @@ extern "C" int nr_launch_post_quant(const float* z, float scale, const float* Q,
   if (C > 8) return 1;
   const long long total = (long long)nimg * hw;
   hipLaunchKernelGGL(post_quant_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, z, scale, Q, qb, out, nimg, C, hw);
+  return 0;
+}
+
+extern "C" int nr_launch_gaussian_sample(const float* moments, const float* noise, float* out, int n, int zc, int hw, float scale,
+                                         hipStream_t stream) {
+  const long long total = (long long)n * zc * hw;
+  hipLaunchKernelGGL(gaussian_sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, moments, noise, out,
+                     total, zc, hw, scale);
   return 0;
 }
 

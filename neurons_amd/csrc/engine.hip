@@ -37,7 +37,9 @@ int nr_launch_layernorm(const bf16* x, int ldx, bf16* out, int ldo, int M, int C
 int nr_launch_attention(const NrAttnParams* pp, hipStream_t stream);
 int nr_launch_conv_in_small(const float* s0, const float* s1, int c0, int c1, int src_batch, int nimg, int F, int H, int W,
                             const float* wT, const float* bias, const float* addend, int Cout, bf16* out, float in_scale,
-                            hipStream_t stream);
+                            float in_shift, hipStream_t stream);
+int nr_launch_gaussian_sample(const float* moments, const float* noise, float* out, int n, int zc, int hw, float scale,
+                              hipStream_t stream);
 int nr_launch_post_quant(const float* z, float scale, const float* Q, const float* qb, float* out, int nimg, int C, int hw,
                          hipStream_t stream);
 int nr_launch_softmax_rows(const float* S, bf16* P, int rows, int L, float scale, hipStream_t stream);
@@ -163,6 +165,7 @@ struct IO {
   void* out_mid = nullptr;
   const float* y = nullptr;     // sgm "vector" conditioning
   float in_scale = 1.f;         // sgm c_in; VAE: 1 / scale_factor
+  float in_shift = 0.f;                 // VAE encoder: x * in_scale + in_shift fused into conv_in
   float out_mul = 1.f, out_add = 0.f;   // VAE: image post-scaling fused into conv_out
   int clamp01 = 0;
   bool operator==(const IO& o) const { return std::memcmp(this, &o, sizeof(IO)) == 0; }
@@ -415,6 +418,7 @@ struct nr_net {
     float scale = 1.f;
     int geglu = 0;
     Act* out = nullptr;      // write into this existing activation (may alias res)
+    int pad_tl0 = 0;         // 3x3: no top/left padding (VAE Downsample)
   };
 
   // generic conv / linear.  x1: optional channel-concat second source.
@@ -433,7 +437,7 @@ struct nr_net {
     p.w = w;
     p.M = x0.nimg * OH * OW; p.N = Cout; p.K = ksize * ksize * (p.c0 + p.c1);
     p.bias = o.bias; p.rowvec = o.rowvec; p.rowvec_div = o.rowvec_div; p.rowvec_ld = o.rowvec_ld;
-    p.out_scale = o.scale; p.geglu = o.geglu;
+    p.out_scale = o.scale; p.geglu = o.geglu; p.pad_tl0 = o.pad_tl0;
     const int outC = o.geglu ? Cout / 2 : Cout;
     Act out = o.out ? *o.out : new_act(x0.nimg, OH, OW, outC);
     if (out.C != outC || out.rows() != p.M) throw NrError(NR_ERR_STATE, "conv: output shape mismatch");
@@ -546,7 +550,7 @@ struct nr_net {
   ResKeys res_keys(const std::string& pre) const {
     if (cfg.kind == NR_KIND_SGM_UNET)
       return ResKeys{pre + ".in_layers.0", pre + ".in_layers.2", pre + ".out_layers.0", pre + ".out_layers.3", pre + ".skip_connection"};
-    if (cfg.kind == NR_KIND_VAE_DECODER)   // sgm/modules/diffusionmodules/model.py:94-151
+    if (cfg.kind == NR_KIND_VAE_DECODER || cfg.kind == NR_KIND_VAE_ENCODER)   // sgm/modules/diffusionmodules/model.py:94-151
       return ResKeys{pre + ".norm1", pre + ".conv1", pre + ".norm2", pre + ".conv2", pre + ".nin_shortcut"};
     return ResKeys{pre + ".norm1", pre + ".conv1", pre + ".norm2", pre + ".conv2", pre + ".conv_shortcut"};
   }
@@ -561,7 +565,7 @@ struct nr_net {
     Act h = groupnorm(x0, x1, k.norm1, cfg.norm_eps, 1);
     GemmOpt o1;
     o1.bias = w_f32(k.conv1 + ".bias", Cout);
-    if (cfg.kind != NR_KIND_VAE_DECODER) {   // the VAE's ResnetBlock runs with temb = None (model.py:138-139,727)
+    if (cfg.kind != NR_KIND_VAE_DECODER && cfg.kind != NR_KIND_VAE_ENCODER) {   // the VAE's ResnetBlock runs with temb = None (model.py:138-139,727)
       o1.rowvec = temb_for(pre, Cout); o1.rowvec_div = F * hw; o1.rowvec_ld = temb_total;
     }
     Act h1 = conv(h, nullptr, w_conv3(k.conv1 + ".weight", Cout, Cin), Cout, 3, 1, 0, o1);
@@ -809,7 +813,7 @@ struct nr_net {
         const float* bi = w_f32(bp + ".0.bias", C0);
         bf16* xp = x.ptr; const int ic = cfg.in_channels, b2n = B2, Hn = H, Wn = W;
         emit([=, this](hipStream_t s) {
-          LAUNCH_OK(nr_launch_conv_in_small(io.sample, nullptr, ic, 0, b2n, nimg, 1, Hn, Wn, wT, bi, nullptr, C0, xp, io.in_scale, s));
+          LAUNCH_OK(nr_launch_conv_in_small(io.sample, nullptr, ic, 0, b2n, nimg, 1, Hn, Wn, wT, bi, nullptr, C0, xp, io.in_scale, 0.f, s));
         });
         tap(bp, x);
       } else if (b.kind == 1) {
@@ -941,7 +945,7 @@ struct nr_net {
       const float* bi = w_f32("decoder.conv_in.bias", Cm);
       bf16* xp = x.ptr; const int Hn = H, Wn = W;
       emit([=](hipStream_t s) {
-        LAUNCH_OK(nr_launch_conv_in_small(zq, nullptr, zc, 0, nimg, nimg, 1, Hn, Wn, wT, bi, nullptr, Cm, xp, 1.f, s));
+        LAUNCH_OK(nr_launch_conv_in_small(zq, nullptr, zc, 0, nimg, nimg, 1, Hn, Wn, wT, bi, nullptr, Cm, xp, 1.f, 0.f, s));
       });
       tap("decoder.conv_in", x);
     }
@@ -970,7 +974,67 @@ struct nr_net {
     res_shapes.clear();
   }
 
+
+  // AutoencodingEngine.encode up to the moments (sgm/models/autoencoder.py:468-488): Encoder.forward
+  // (sgm/modules/diffusionmodules/model.py:584-609) -> quant_conv.  == diffusers AutoencoderKL.encode(x).latent_dist
+  // parameters (scripts/neuroclips_video.py:267,282).  Plan h, w are the IMAGE size; moments are [n][2z][h/8][w/8].
+  void build_vae_enc() {
+    const int L = cfg.num_levels, zc2 = cfg.out_channels, nimg = B2, ic = cfg.in_channels;
+    if (F != 1) throw NrError(NR_ERR_ARG, "the VAE encoder is a 2-D network: plan with frames = 1");
+    ctx_persist.clear(); ops.clear(); ctx_ops.clear(); op_meta.clear(); taps.clear(); arena.reset(); parena.reset();
+    temb_slots.clear(); temb_total = 0; temb_all = nullptr;
+    t_dev = new_scratch<float>(16);
+    const int C0 = cfg.block_out_channels[0];
+    Act x = new_act(nimg, H, W, C0);
+    {
+      const float* wT = w_conv_in("encoder.conv_in.weight", C0, ic);
+      const float* bi = w_f32("encoder.conv_in.bias", C0);
+      bf16* xp = x.ptr; const int Hn = H, Wn = W;
+      emit([=, this](hipStream_t s) {
+        LAUNCH_OK(nr_launch_conv_in_small(io.sample, nullptr, ic, 0, nimg, nimg, 1, Hn, Wn, wT, bi, nullptr, C0, xp, io.in_scale,
+                                          io.in_shift, s));
+      });
+      tap("encoder.conv_in", x);
+    }
+    for (int lev = 0; lev < L; ++lev) {
+      const int Co = cfg.block_out_channels[lev];
+      const std::string dn = "encoder.down." + std::to_string(lev);
+      for (int j = 0; j < cfg.layers_per_block; ++j) x = resnet(x, nullptr, dn + ".block." + std::to_string(j), Co);
+      if (lev != L - 1) {
+        // Downsample.forward (model.py:84-91): F.pad (0,1,0,1) then 3x3 stride-2 conv without padding
+        GemmOpt o; o.bias = w_f32(dn + ".downsample.conv.bias", Co); o.pad_tl0 = 1;
+        x = conv(x, nullptr, w_conv3(dn + ".downsample.conv.weight", Co, Co), Co, 3, 2, 0, o);
+        tap(dn + ".downsample", x);
+      }
+    }
+    const int Cm = cfg.block_out_channels[L - 1];
+    x = resnet(x, nullptr, "encoder.mid.block_1", Cm);
+    x = vae_attn(x, "encoder.mid.attn_1");
+    x = resnet(x, nullptr, "encoder.mid.block_2", Cm);
+    Act hn = groupnorm(x, nullptr, "encoder.norm_out", cfg.norm_eps, 1);
+    {
+      const int hw = x.H * x.W;
+      float* mraw = new_scratch<float>((size_t)nimg * zc2 * hw);
+      const bf16* wo = w_conv3("encoder.conv_out.weight", zc2, Cm);
+      const float* bo = w_f32("encoder.conv_out.bias", zc2);
+      check_shape("quant_conv.weight", need("quant_conv.weight"), {zc2, zc2});
+      const float* Q = (const float*)cached("f32:quant_conv.weight", [&]() {
+        const HostTensor& t = data_of("quant_conv.weight");
+        return upload("f32:quant_conv.weight", t.data.data(), t.data.size() * 4);
+      });
+      const float* qb = w_f32("quant_conv.bias", zc2);
+      const bf16* hp = hn.ptr; const int Hn = x.H, Wn = x.W;
+      emit([=, this](hipStream_t s) {
+        LAUNCH_OK(nr_launch_conv_out_small(hp, Cm, nimg, 1, Hn, Wn, wo, bo, zc2, mraw, 1.f, 0.f, 0, s));
+        LAUNCH_OK(nr_launch_post_quant(mraw, 1.f, Q, qb, io.out, nimg, zc2, hw, s));
+      });
+    }
+    n_res = 0;
+    res_shapes.clear();
+  }
+
   void build() {
+    if (cfg.kind == NR_KIND_VAE_ENCODER) { build_vae_enc(); return; }
     if (cfg.kind == NR_KIND_SGM_UNET) { build_sgm(); return; }
     if (cfg.kind == NR_KIND_VAE_DECODER) { build_vae(); return; }
     const int L = cfg.num_levels;
@@ -1044,7 +1108,7 @@ struct nr_net {
       const float* bi = w_f32("conv_in.bias", C0);
       bf16* xp = x.ptr; const int ic = cfg.in_channels, b2n = B2, Fn = F, Hn = H, Wn = W;
       emit([=, this](hipStream_t s) {
-        LAUNCH_OK(nr_launch_conv_in_small(io.sample, nullptr, ic, 0, b2n, nimg, Fn, Hn, Wn, wT, bi, nullptr, C0, xp, 1.f, s));
+        LAUNCH_OK(nr_launch_conv_in_small(io.sample, nullptr, ic, 0, b2n, nimg, Fn, Hn, Wn, wT, bi, nullptr, C0, xp, 1.f, 0.f, s));
       });
     } else {
       // sparse_controlnet.py:467-521: sample := 0 -> conv_in(0) = bias; + cond_embedding(cat[cond, mask])
@@ -1055,7 +1119,7 @@ struct nr_net {
       bf16* xp = x.ptr; const int Fn = F, Hn = H, Wn = W;
       if (cfg.set_noisy_sample_input_to_zero) {
         emit([=, this](hipStream_t s) {
-          LAUNCH_OK(nr_launch_conv_in_small(io.cond, io.mask, cc, 1, io.cond_batch, nimg, Fn, Hn, Wn, wTe, be, bi, C0, xp, 1.f, s));
+          LAUNCH_OK(nr_launch_conv_in_small(io.cond, io.mask, cc, 1, io.cond_batch, nimg, Fn, Hn, Wn, wTe, be, bi, C0, xp, 1.f, 0.f, s));
         });
       } else {
         const float* wT = w_conv_in("conv_in.weight", C0, cfg.in_channels);
@@ -1063,8 +1127,8 @@ struct nr_net {
         bf16* x2p = x2.ptr; const int ic = cfg.in_channels, b2n = B2;
         const long long n = (long long)nimg * H * W * C0;
         emit([=, this](hipStream_t s) {
-          LAUNCH_OK(nr_launch_conv_in_small(io.sample, nullptr, ic, 0, b2n, nimg, Fn, Hn, Wn, wT, bi, nullptr, C0, xp, 1.f, s));
-          LAUNCH_OK(nr_launch_conv_in_small(io.cond, io.mask, cc, 1, io.cond_batch, nimg, Fn, Hn, Wn, wTe, be, nullptr, C0, x2p, 1.f, s));
+          LAUNCH_OK(nr_launch_conv_in_small(io.sample, nullptr, ic, 0, b2n, nimg, Fn, Hn, Wn, wT, bi, nullptr, C0, xp, 1.f, 0.f, s));
+          LAUNCH_OK(nr_launch_conv_in_small(io.cond, io.mask, cc, 1, io.cond_batch, nimg, Fn, Hn, Wn, wTe, be, nullptr, C0, x2p, 1.f, 0.f, s));
           LAUNCH_OK(nr_launch_add_bf16(xp, x2p, xp, n, s));
         });
       }
@@ -1186,9 +1250,9 @@ struct nr_net {
   }
 
   void plan(int batch, int frames, int h, int w, int ctxl) {
-    const bool vae = cfg.kind == NR_KIND_VAE_DECODER;
+    const bool vae = cfg.kind == NR_KIND_VAE_DECODER || cfg.kind == NR_KIND_VAE_ENCODER;
     if (batch <= 0 || batch > 16 || frames <= 0 || h <= 0 || w <= 0 || (ctxl <= 0 && !vae)) throw NrError(NR_ERR_ARG, "plan: bad shape");
-    const int down = vae ? 1 : 1 << (cfg.num_levels - 1);
+    const int down = cfg.kind == NR_KIND_VAE_DECODER ? 1 : 1 << (cfg.num_levels - 1);
     if (h % down != 0 || w % down != 0)
       throw NrError(NR_ERR_ARG, "plan: latent h,w must be multiples of " + std::to_string(down));
     HIP_OK(hipDeviceSynchronize());
@@ -1320,11 +1384,12 @@ extern "C" nr_status nr_net_create(const nr_net_config* cfg, nr_net** out) {
   NR_TRY
   if (!cfg || !out) throw NrError(NR_ERR_ARG, "null argument");
   if (cfg->num_levels < 2 || cfg->num_levels > NR_MAX_LEVELS) throw NrError(NR_ERR_ARG, "num_levels must be 2..4");
-  if (cfg->kind != NR_KIND_UNET3D && cfg->kind != NR_KIND_SPARSECTRL && cfg->kind != NR_KIND_SGM_UNET && cfg->kind != NR_KIND_VAE_DECODER)
-    throw NrError(NR_ERR_ARG, "bad kind");
-  const bool vae = cfg->kind == NR_KIND_VAE_DECODER;
-  if (vae && (cfg->in_channels != 4 || cfg->out_channels != 3))
+  if (cfg->kind < NR_KIND_UNET3D || cfg->kind > NR_KIND_VAE_ENCODER) throw NrError(NR_ERR_ARG, "bad kind");
+  const bool vae = cfg->kind == NR_KIND_VAE_DECODER || cfg->kind == NR_KIND_VAE_ENCODER;
+  if (cfg->kind == NR_KIND_VAE_DECODER && (cfg->in_channels != 4 || cfg->out_channels != 3))
     throw NrError(NR_ERR_UNSUPPORTED, "VAE decoder: z_channels must be 4 and out_ch 3");
+  if (cfg->kind == NR_KIND_VAE_ENCODER && (cfg->in_channels != 3 || cfg->out_channels != 8))
+    throw NrError(NR_ERR_UNSUPPORTED, "VAE encoder: in_channels must be 3 and the moments 2 * z_channels = 8");
   for (int i = 0; i < cfg->num_levels; ++i) {
     const int C = cfg->block_out_channels[i];
     if (C % 64 != 0) throw NrError(NR_ERR_UNSUPPORTED, "block_out_channels must be multiples of 64");
@@ -1546,6 +1611,28 @@ extern "C" nr_status nr_vae_decode(nr_net* h, nr_stream stream, const float* z_d
   h->io = io;
   const float zeros[16] = {0};
   h->run((hipStream_t)stream, zeros);
+  NR_CATCH
+}
+
+extern "C" nr_status nr_vae_encode(nr_net* h, nr_stream stream, const float* x_dev, float in_mul, float in_add, float* moments_dev) {
+  NR_TRY
+  if (!h || h->cfg.kind != NR_KIND_VAE_ENCODER) throw NrError(NR_ERR_ARG, "handle is not a VAE encoder");
+  if (!h->planned) throw NrError(NR_ERR_STATE, "nr_net_plan() has not been called (or weights changed since)");
+  if (!x_dev || !moments_dev) throw NrError(NR_ERR_ARG, "null tensor argument");
+  IO io;
+  std::memset(&io, 0, sizeof(io));
+  io.sample = x_dev; io.out = moments_dev; io.in_scale = in_mul; io.in_shift = in_add; io.out_mul = 1.f; io.scale = 1.f; io.cond_batch = 1;
+  h->io = io;
+  const float zeros[16] = {0};
+  h->run((hipStream_t)stream, zeros);
+  NR_CATCH
+}
+
+extern "C" nr_status nr_gaussian_sample(nr_stream stream, const float* moments_dev, const float* noise_dev, float* out_dev, int32_t n,
+                                        int32_t z_channels, int32_t hw, float scale) {
+  NR_TRY
+  if (!moments_dev || !out_dev || n <= 0 || z_channels <= 0 || hw <= 0) throw NrError(NR_ERR_ARG, "bad argument");
+  LAUNCH_OK(nr_launch_gaussian_sample(moments_dev, noise_dev, out_dev, n, z_channels, hw, scale, (hipStream_t)stream));
   NR_CATCH
 }
 

@@ -141,8 +141,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
       const int VH = p.ups ? p.H * 2 : p.H, VW = p.ups ? p.W * 2 : p.W;
 #pragma unroll
       for (int j = 0; j < GA; ++j) {
-        int iy = a_oy[j] * p.stride + ky - 1;
-        int ix = a_ox[j] * p.stride + kx - 1;
+        int iy = a_oy[j] * p.stride + ky - (p.pad_tl0 ? 0 : 1);
+        int ix = a_ox[j] * p.stride + kx - (p.pad_tl0 ? 0 : 1);
         const bool ok = a_ok[j] && iy >= 0 && iy < VH && ix >= 0 && ix < VW;
         if (p.ups) { iy >>= 1; ix >>= 1; }
         const size_t pix = ((size_t)a_pix[j] * p.H + iy) * p.W + ix;

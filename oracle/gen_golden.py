@@ -469,6 +469,29 @@ def gen_vae(out_dir):
     vid = torch.cat([dec(pq(fr[i:i + 1])) for i in range(2)])
     out["lat"] = lat.numpy()
     out["video"] = (vid.reshape(1, 2, 3, 64, 128).permute(0, 2, 1, 3, 4) / 2 + 0.5).clamp(0, 1).numpy()
+    # encoder: vae.encode(2 * x - 1).latent_dist.sample() * 0.18215 (scripts/neuroclips_video.py:267) with the reference's
+    # Encoder + quant_conv + DiagonalGaussianDistribution; the noise of .sample() is recorded by seeding torch
+    from sgm.modules.diffusionmodules.model import Encoder
+    spec = importlib.util.spec_from_file_location("ref_sgm_dist", f"{REF}/generative_models/sgm/modules/distributions/distributions.py")
+    dist = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dist)
+    esd = vae_random_state_dict(cfg, seed=94, encoder=True)
+    enc = Encoder(ch=cfg.ch, out_ch=cfg.out_ch, ch_mult=cfg.ch_mult, num_res_blocks=cfg.num_res_blocks, attn_resolutions=[],
+                  in_channels=3, resolution=64, z_channels=cfg.z_channels, attn_type="vanilla", double_z=True)
+    e2 = {k[len("encoder."):]: v for k, v in esd.items() if k.startswith("encoder.")}
+    assert set(enc.state_dict().keys()) == set(e2.keys()), set(enc.state_dict().keys()) ^ set(e2.keys())
+    enc.load_state_dict(e2, strict=True)
+    enc.eval()
+    qc = torch.nn.Conv2d(2 * cfg.z_channels, 2 * cfg.embed_dim, 1)
+    qc.load_state_dict({"weight": esd["quant_conv.weight"], "bias": esd["quant_conv.bias"]})
+    img = torch.rand(torch.Size((2, 3, 64, 128)), generator=torch.Generator().manual_seed(95))
+    moments = qc(enc(2 * img - 1))
+    post = dist.DiagonalGaussianDistribution(moments)
+    torch.manual_seed(96)
+    lat_s = post.sample() * 0.18215
+    torch.manual_seed(96)
+    out.update(enc_img=img.numpy(), enc_moments=moments.numpy(), enc_noise=torch.randn(post.mean.shape).numpy(),
+               enc_sample=lat_s.numpy(), enc_mode=(post.mode() * 0.18215).numpy())
     np.savez_compressed(os.path.join(out_dir, "vae_tiny.npz"), **out)
     print("vae_tiny:", {k: v.shape for k, v in out.items()}, "image abs mean", float(np.abs(out["image"]).mean()),
           "video mean", float(out["video"].mean()), "clamped frac", float(((out["video"] == 0) | (out["video"] == 1)).mean()))
@@ -491,11 +514,25 @@ def gen_vae(out_dir):
     conv_sd = conv.convert_ldm_vae_checkpoint(ck, vcfg)
     ref_map = {k: names[int(v.reshape(-1)[0])] for k, v in conv_sd.items() if k.startswith(("decoder.", "post_quant_conv."))}
     ours = diffusers_vae_key_map(full)
+    # encoder half: same trick on an encoder-named checkpoint
+    from neurons_amd.vae import vae_encoder_state_dict_schema
+    enames = list(vae_encoder_state_dict_schema(full).keys())
+    ck = {"first_stage_model." + k: torch.full((1,), float(i)) for i, k in enumerate(enames)}
+    for k in ("decoder.conv_in", "decoder.conv_out", "decoder.norm_out", "post_quant_conv"):
+        ck[f"first_stage_model.{k}.weight"] = torch.zeros(1)
+        ck[f"first_stage_model.{k}.bias"] = torch.zeros(1)
+    for k in ("q", "k", "v", "proj_out"):
+        n = f"first_stage_model.encoder.mid.attn_1.{k}.weight"
+        ck[n] = ck[n].reshape(1, 1, 1, 1)
+    conv_sd = conv.convert_ldm_vae_checkpoint(ck, vcfg)
+    ref_emap = {k: enames[int(v.reshape(-1)[0])] for k, v in conv_sd.items() if k.startswith(("encoder.", "quant_conv."))}
+    ours_e = diffusers_vae_key_map(full, encoder=True)
     with open(os.path.join(out_dir, "vae_keys.json"), "w") as f:
-        json.dump({"diffusers_to_ldm": ref_map}, f, indent=0, sort_keys=True)
-    print("vae_keys.json:", len(ref_map), "decoder keys; map equal to ours:", ref_map == ours)
-    if ref_map != ours:
-        print(sorted(set(ref_map.items()) ^ set(ours.items()))[:10])
+        json.dump({"diffusers_to_ldm": ref_map, "diffusers_to_ldm_encoder": ref_emap}, f, indent=0, sort_keys=True)
+    print("vae_keys.json:", len(ref_map), "decoder keys; map equal to ours:", ref_map == ours, ";", len(ref_emap),
+          "encoder keys; equal:", ref_emap == ours_e)
+    if ref_map != ours or ref_emap != ours_e:
+        print(sorted(set(ref_map.items()) ^ set(ours.items()))[:10], sorted(set(ref_emap.items()) ^ set(ours_e.items()))[:10])
 
 
 # --------------------------------------------------------------------------------------------------

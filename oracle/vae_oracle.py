@@ -62,6 +62,35 @@ def decode(sd: SD, z, num_levels: int, num_res_blocks: int, taps=None):
     return F.conv2d(h, sd["decoder.conv_out.weight"], sd["decoder.conv_out.bias"], padding=1)
 
 
+def encode_moments(sd: SD, x, num_levels: int, num_res_blocks: int, taps=None):
+    """autoencoder.py:468-488 up to the posterior parameters: Encoder.forward (:584-609) -> quant_conv."""
+    def tap(name, t):
+        if taps is not None:
+            taps[name] = t
+    h = F.conv2d(x.float(), sd["encoder.conv_in.weight"], sd["encoder.conv_in.bias"], padding=1)
+    tap("encoder.conv_in", h)
+    for lev in range(num_levels):
+        for j in range(num_res_blocks):
+            h = resnet_block(sd, f"encoder.down.{lev}.block.{j}", h); tap(f"encoder.down.{lev}.block.{j}", h)
+        if lev != num_levels - 1:
+            # Downsample.forward (:84-91): zero-pad right/bottom by one, 3x3 stride-2 conv without padding
+            h = F.conv2d(F.pad(h, (0, 1, 0, 1)), sd[f"encoder.down.{lev}.downsample.conv.weight"],
+                         sd[f"encoder.down.{lev}.downsample.conv.bias"], stride=2)
+            tap(f"encoder.down.{lev}.downsample", h)
+    h = resnet_block(sd, "encoder.mid.block_1", h); tap("encoder.mid.block_1", h)
+    h = attn_block(sd, "encoder.mid.attn_1", h); tap("encoder.mid.attn_1", h)
+    h = resnet_block(sd, "encoder.mid.block_2", h); tap("encoder.mid.block_2", h)
+    h = F.silu(_norm(sd, "encoder.norm_out", h))
+    h = F.conv2d(h, sd["encoder.conv_out.weight"], sd["encoder.conv_out.bias"], padding=1)
+    return F.conv2d(h, sd["quant_conv.weight"], sd["quant_conv.bias"])
+
+
+def gaussian_sample(moments, noise):
+    """DiagonalGaussianDistribution.__init__/sample (sgm/modules/distributions/distributions.py:25-42)."""
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    return mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * noise
+
+
 def decode_first_stage(sd: SD, z, num_levels, num_res_blocks, scale_factor=0.18215):
     """sgm/models/diffusion.py:118-135."""
     return decode(sd, z / scale_factor, num_levels, num_res_blocks)

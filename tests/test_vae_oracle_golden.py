@@ -44,17 +44,34 @@ def test_decode_latents_matches_reference():
     assert float(((g["video"] == 0) | (g["video"] == 1)).mean()) > 0.05      # the clamp is exercised
 
 
+@torch.no_grad()
+def test_encoder_moments_and_sampling_match_reference():
+    g = np.load(GOLD)
+    cfg = tiny_vae_config()
+    esd = vae_random_state_dict(cfg, seed=94, encoder=True)
+    m = V.encode_moments(esd, 2 * torch.from_numpy(g["enc_img"]) - 1, len(cfg.ch_mult), cfg.num_res_blocks)
+    _close("moments", m, g["enc_moments"])
+    _close("sample", V.gaussian_sample(torch.from_numpy(g["enc_moments"]), torch.from_numpy(g["enc_noise"])) * 0.18215, g["enc_sample"], tol=1e-6)
+    _close("mode", torch.from_numpy(g["enc_moments"])[:, :4] * 0.18215, g["enc_mode"], tol=1e-6)
+
+
 def test_schema_is_the_sd_vae_decoder():
     sch = vae_decoder_state_dict_schema(VAEDecoderConfig())
     n = sum(int(np.prod(s)) for s in sch.values())
     assert len(sch) == 140 and n == 49_490_199          # SD-1.5 / unclip6.yaml first-stage decoder + post_quant_conv
     assert sch["decoder.mid.attn_1.q.weight"] == (512, 512, 1, 1) and sch["decoder.up.1.block.0.nin_shortcut.weight"] == (256, 512, 1, 1)
+    from neurons_amd.vae import vae_encoder_state_dict_schema
+    esch = vae_encoder_state_dict_schema(VAEDecoderConfig())
+    assert len(esch) == 108 and sum(int(np.prod(s)) for s in esch.values()) == 34_163_664
+    assert esch["encoder.conv_out.weight"] == (8, 512, 3, 3) and esch["quant_conv.weight"] == (8, 8, 1, 1)
 
 
 def test_diffusers_key_map_matches_reference_converter():
     with open(os.path.join(HERE, "golden", "vae_keys.json")) as f:
         ref = json.load(f)["diffusers_to_ldm"]
     cfg = VAEDecoderConfig()
+    with open(os.path.join(HERE, "golden", "vae_keys.json")) as f:
+        assert diffusers_vae_key_map(cfg, encoder=True) == json.load(f)["diffusers_to_ldm_encoder"]
     assert diffusers_vae_key_map(cfg) == ref
     # a diffusers-named state dict (Linear attention weights, conv_shortcut) converts to loadable first-stage names
     sch = vae_decoder_state_dict_schema(cfg)
