@@ -45,3 +45,22 @@ for name, z, path in (("clip 16 x 32x32 -> 256^2", torch.randn(16, 4, 32, 32, de
         else:
             ref = timed(lambda: V.decode(sd, z / 0.18215, 4, 2), n=2)
     print(f"{name}: fp32 PyTorch restatement on the same GPU {ref:.1f} ms -> native is {ref / ms:.1f}x")
+
+# encoder: 17 images of 256^2 (16 blurry frames + control image, scripts/neuroclips_video.py:263-283)
+from neurons_amd.vae import NativeVAEEncoder, vae_encoder_state_dict_schema  # noqa: E402
+esd = gpu_random_state_dict(vae_encoder_state_dict_schema(cfg), 4, dev)
+enc = NativeVAEEncoder(cfg).to(dev)
+enc.load_state_dict({k: v.cpu() for k, v in esd.items()})
+x = torch.rand(16, 3, 256, 256, device=dev)
+ms = timed(lambda: enc.moments(x, 2.0, -1.0))
+if len(sys.argv) > 3:
+    os.environ["NR_PROFILE_CSV"] = sys.argv[3]
+for _ in range(2):
+    p = enc.profile_last()
+tot = sum(v["ms"] for v in p.values())
+fl = sum(v["flops"] for v in p.values())
+print(f"encode 16 x 256^2: native {ms:.2f} ms (sum of launches {tot:.2f} ms, {fl / 1e12:.2f} TFLOP -> {fl / tot / 1e9:.0f} TF/s)",
+      {k: round(v["ms"], 3) for k, v in p.items()})
+with torch.no_grad():
+    ref = timed(lambda: V.encode_moments(esd, 2 * x - 1, 4, 2), n=2)
+print(f"encode 16 x 256^2: fp32 PyTorch restatement on the same GPU {ref:.1f} ms -> native is {ref / ms:.1f}x")
