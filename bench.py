@@ -145,6 +145,8 @@ def main():
     from neurons_amd.unet3d import UNet3DConfig, state_dict_schema
 
     ucfg = UNet3DConfig()
+    if args.frames > 24:   # the v3 motion module's PE table has 24 rows; longer clips need a 32-row config
+        ucfg.motion_module_kwargs = dict(ucfg.motion_module_kwargs, temporal_position_encoding_max_len=32)
     ccfg = controlnet_config_from_unet(ucfg, dict(
         set_noisy_sample_input_to_zero=True, use_simplified_condition_embedding=True, conditioning_channels=4,
         motion_module_kwargs=dict(attention_block_types=["Temporal_Self"], temporal_position_encoding_max_len=32)))

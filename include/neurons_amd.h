@@ -45,6 +45,7 @@ typedef struct nr_net nr_net;
                                  sgm/models/autoencoder.py:490 decode (= diffusers AutoencoderKL.decode)     */
 #define NR_KIND_VAE_ENCODER 4 /* generative_models/sgm/modules/diffusionmodules/model.py:495 Encoder + quant_conv
                                  (sgm/models/autoencoder.py:468-488 = diffusers AutoencoderKL.encode)         */
+#define NR_KIND_CLIP_TEXT 5   /* transformers CLIPTextModel as called by _encode_prompt (pipeline_neuroclips.py:153-240) */
 
 #define NR_MAX_LEVELS 4
 
@@ -147,11 +148,17 @@ nr_status nr_sparsectrl_forward(nr_net* h, nr_stream stream, const float* sample
  * (pipeline_neuroclips.py:460-475) in ONE call: SparseCtrl runs on its own stream concurrently with the U-Net's
  * encoder + mid block (which do not depend on it); the residual adds and the decoder wait for it.  Same results as
  * nr_sparsectrl_forward + nr_unet3d_forward.  res_*_dev: caller-owned channels-last bf16 residual buffers
- * (written by SparseCtrl, read by the U-Net).  Requires set_noisy_sample_input_to_zero (sample is not read by SparseCtrl). */
+ * (written by SparseCtrl, read by the U-Net).  Requires set_noisy_sample_input_to_zero (sample is not read by SparseCtrl).
+ * next_timesteps (host fp32 [batch], may be NULL): the timesteps of the FOLLOWING denoising step of the same clip.
+ * With the noisy sample zeroed, SparseCtrl depends on (timestep, context, condition) only, so its next evaluation is
+ * issued as soon as this step's residual adds have consumed the current one and overlaps this step's decoder; the
+ * next call uses it if its timesteps / context / cond / mask / residual pointers are identical (else it re-runs).
+ * Contract when non-NULL: ctx/cond/mask/res buffers stay alive and unmodified until the next call on these handles
+ * or nr_net_invalidate_context(ctrl).                                                                             */
 nr_status nr_denoise_step_forward(nr_net* unet, nr_net* ctrl, nr_stream stream, const float* sample_dev,
                                   const float* timesteps, const float* ctx_dev, int32_t ctx_len, const float* cond_dev,
                                   const float* mask_dev, int32_t cond_batch, float scale, void* const* res_down_dev,
-                                  void* res_mid_dev, float* out_dev);
+                                  void* res_mid_dev, float* out_dev, const float* next_timesteps);
 
 /* replaces OpenAIWrapper.forward -> UNetModel.forward (sgm/modules/diffusionmodules/wrappers.py:23-34,
  * openaimodel.py:816-853).  x_dev fp32 [batch][4][h][w] is multiplied by in_scale (= c_in of
@@ -172,6 +179,15 @@ nr_status nr_sgm_unet_forward(nr_net* h, nr_stream stream, const float* x_dev, f
  *   (1, 0, 0) returns the raw decoder output.                                                                     */
 nr_status nr_vae_decode(nr_net* h, nr_stream stream, const float* z_dev, float z_scale, float out_mul, float out_add,
                         int32_t clamp01, float* out_dev);
+
+/* replaces text_encoder(text_input_ids, attention_mask=None)[0] in _encode_prompt (pipeline_neuroclips.py:197-200,
+ * 231-234): transformers CLIPTextModel -> last_hidden_state (CLIPTextEmbeddings, 12 pre-LN encoder layers with causal
+ * self-attention and quick_gelu MLP, final_layer_norm).  Config: kind NR_KIND_CLIP_TEXT, block_out_channels[0] =
+ * hidden_size (768), num_heads (12), layers_per_block = num_hidden_layers (12), cross_attention_dim = intermediate_size
+ * (3072), in_channels = vocab_size (49408), motion_pe_max_len = max_position_embeddings (77), norm eps 1e-5;
+ * plan with (batch, 1, 1, seq_len, 0).  State-dict keys: transformers' (text_model.embeddings.token_embedding.weight ...).
+ *   ids_dev int32 [batch][seq_len] (device); out_dev fp32 [batch][seq_len][hidden].  Tokenisation stays with the caller. */
+nr_status nr_clip_text_forward(nr_net* h, nr_stream stream, const int32_t* ids_dev, float* out_dev);
 
 /* replaces vae.encode(2 * x - 1).latent_dist (scripts/neuroclips_video.py:267,282, scripts/neuroclips_video_enhance.py:
  * 268,283) = AutoencodingEngine.encode up to the moments (sgm/models/autoencoder.py:468-488: Encoder.forward

@@ -15,6 +15,7 @@ NR_KIND_SPARSECTRL = 1
 NR_KIND_SGM_UNET = 2
 NR_KIND_VAE_DECODER = 3
 NR_KIND_VAE_ENCODER = 4
+NR_KIND_CLIP_TEXT = 5
 NR_MAX_LEVELS = 4
 
 
@@ -74,9 +75,10 @@ SYMBOLS = {
     "nr_net_residual_shape": (_I32, [_VP, _I32, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
     "nr_unet3d_forward": (_I32, [_VP, _VP, _VP, _FP, _VP, _I32, C.POINTER(_VP), _VP, _VP]),
     "nr_sparsectrl_forward": (_I32, [_VP, _VP, _VP, _FP, _VP, _I32, _VP, _VP, _I32, C.c_float, C.POINTER(_VP), _VP]),
-    "nr_denoise_step_forward": (_I32, [_VP, _VP, _VP, _VP, _FP, _VP, _I32, _VP, _VP, _I32, C.c_float, C.POINTER(_VP), _VP, _VP]),
+    "nr_denoise_step_forward": (_I32, [_VP, _VP, _VP, _VP, _FP, _VP, _I32, _VP, _VP, _I32, C.c_float, C.POINTER(_VP), _VP, _VP, _FP]),
     "nr_sgm_unet_forward": (_I32, [_VP, _VP, _VP, C.c_float, _FP, _VP, _I32, _VP, _VP]),
     "nr_vae_decode": (_I32, [_VP, _VP, _VP, C.c_float, C.c_float, C.c_float, _I32, _VP]),
+    "nr_clip_text_forward": (_I32, [_VP, _VP, _VP, _VP]),
     "nr_vae_encode": (_I32, [_VP, _VP, _VP, C.c_float, C.c_float, _VP]),
     "nr_gaussian_sample": (_I32, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, C.c_float]),
     "nr_edm_cfg_euler_step": (_I32, [_VP, _VP, _VP, _VP, _I64, C.c_float, C.c_float, C.c_float, C.c_float]),

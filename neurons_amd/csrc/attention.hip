@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(NrAttnParams p) {
   const bf16x8 zero8 = bf16x8_zero();
   const int qrow = qt * 16 + c;
   const int qrow_c = min(qrow, p.Lq - 1);
+  const int klim = p.causal ? min(p.Lk, qrow + 1) : p.Lk;   // keys visible to this lane's query
 
   // Q fragments (B operand of S^T = K Q^T): lane holds Q[query c][dim 32*ks + 8*g .. +7]
   bf16x8 qf[DK];
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(NrAttnParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = k0 + 16 * t + 4 * g + r;
-        const float v = key < p.Lk ? s[t][r] * p.scale : -1e30f;
+        const float v = key < klim ? s[t][r] * p.scale : -1e30f;
         s[t][r] = v;
         mx = fmaxf(mx, v);
       }
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(NrAttnParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = k0 + 16 * t + 4 * g + r;
-        const float e = key < p.Lk ? __expf(s[t][r] - m_new) : 0.f;
+        const float e = key < klim ? __expf(s[t][r] - m_new) : 0.f;
         rs += e;
         pf[t * 4 + r] = (bf16)e;
       }
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p, in
 
 template <int DK, int DT>
 int launch_attn(const NrAttnParams& p, hipStream_t stream) {
-  if (p.Lq >= 48 && p.inner == 1) {
+  if (p.Lq >= 48 && p.inner == 1 && !p.causal) {   // causal masking lives in the per-wave kernel only
     // long sequences: block-shared K/V tiles
     int u = p.d / 8;                       // row stride in 16-byte units, forced odd (bank-conflict-free b128 reads)
     if ((u & 1) == 0) u += 1;

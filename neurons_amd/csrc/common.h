@@ -50,6 +50,8 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.f + __expf(-1.702f * x)); }
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
@@ -84,6 +86,7 @@ struct NrGemmParams {
   int ldo;
   float out_scale;     // (acc + bias + rowvec) * out_scale + res
   int geglu;           // 1: W rows are (value16|gate16)-interleaved; out has N/2 columns
+  int act;             // 0 none; 1 quick_gelu x*sigmoid(1.702x) (CLIP MLP), applied after bias/scale, before the residual
   int pad_tl0;         // 3x3 only: 1 = no top/left padding (bottom/right zero) — the VAE Downsample's F.pad (0,1,0,1)
   float* out_f32;      // non-null: write the raw fp32 accumulators to out_f32[M][N] and skip the epilogue (attention scores)
 };
@@ -100,6 +103,7 @@ struct NrAttnParams {
   int kv_div;      // kv batch index = nb / kv_div (cross-attention: frames share one text context)
   int nbatch, heads, d, Lq, Lk;
   float scale;
+  int causal;      // 1: key j is visible to query i only if j <= i (CLIP text encoder)
 };
 
 // GroupNorm launch parameters (norm.hip)

@@ -288,7 +288,43 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ a, bf16* __restrict
   if (i < n) out[i] = (bf16)a[i];
 }
 
+// CLIPTextEmbeddings (transformers CLIPTextModel, called by pipeline_neuroclips.py:153-240 _encode_prompt):
+// out[m][:] = token_embedding[ids[m]][:] + position_embedding[m % L][:]   (fp32 tables, one rounding to bf16)
+__global__ void clip_embed_kernel(const int* __restrict__ ids, const float* __restrict__ tok, const float* __restrict__ pos,
+                                  bf16* __restrict__ out, int M, int L, int C, int vocab) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = C >> 2;
+  if (idx >= (long long)M * c4) return;
+  const int m = (int)(idx / c4), c = (int)(idx - (long long)m * c4) << 2;
+  int id = ids[m];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const f32x4 a = *(const f32x4*)(tok + (size_t)id * C + c);
+  const f32x4 b = *(const f32x4*)(pos + (size_t)(m % L) * C + c);
+  bf16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (bf16)(a[e] + b[e]);
+  *(bf16x4*)(out + (size_t)m * C + c) = o;
+}
+
+__global__ void bf16_to_f32_kernel(const bf16* __restrict__ a, float* __restrict__ out, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)a[i];
+}
+
 }  // namespace
+
+extern "C" int nr_launch_clip_embed(const int* ids, const float* tok, const float* pos, bf16* out, int M, int L, int C, int vocab,
+                                    hipStream_t stream) {
+  if (C % 4 != 0) return 1;
+  const long long total = (long long)M * (C / 4);
+  hipLaunchKernelGGL(clip_embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ids, tok, pos, out, M, L, C, vocab);
+  return 0;
+}
+
+extern "C" int nr_launch_bf16_to_f32(const bf16* a, float* out, long long n, hipStream_t stream) {
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, out, n);
+  return 0;
+}
 
 extern "C" int nr_launch_conv_in_small(const float* s0, const float* s1, int c0, int c1, int src_batch, int nimg, int F,
                                        int H, int W, const float* wT, const float* bias, const float* addend, int Cout,

@@ -303,6 +303,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
           va += *(const f32x4*)rv; vb += *(const f32x4*)(rv + 4);
         }
         va *= p.out_scale; vb *= p.out_scale;
+        if (p.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { va[e] = quick_gelu_f(va[e]); vb[e] = quick_gelu_f(vb[e]); }
+        }
         if (p.res) {
           const bf16x8 r = *(const bf16x8*)(p.res + (size_t)m * p.ldr + n);
 #pragma unroll
@@ -330,6 +334,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
         if (p.bias) { const f32x4 b = *(const f32x4*)(p.bias + n); v += b; }
         if (rv) { const f32x4 t = *(const f32x4*)(rv + n); v += t; }
         v *= p.out_scale;
+        if (p.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
+        }
         if (p.res) {
           const bf16x4 r = *(const bf16x4*)(p.res + (size_t)m * p.ldr + n);
 #pragma unroll
@@ -377,6 +385,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(NrGemmParams p, int 
   if (p.bias) v += *(const f32x4*)(p.bias + n);
   if (p.rowvec) v += *(const f32x4*)(p.rowvec + (size_t)(m / p.rowvec_div) * p.rowvec_ld + n);
   v *= p.out_scale;
+  if (p.act == 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
+  }
   if (p.res) {
     const bf16x4 r = *(const bf16x4*)(p.res + (size_t)m * p.ldr + n);
 #pragma unroll

@@ -13,6 +13,7 @@ Additive extensions (defaults keep reference behaviour): ``text_embeddings=`` (s
 ``vae`` may be a ``neurons_amd.vae.NativeVAEDecoder`` (the decode then also runs in HIP) or the
 caller's PyTorch ``AutoencoderKL``; CLIP stays a PyTorch module supplied by the caller.
 """
+import os
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Union
 
@@ -60,6 +61,7 @@ class NeuroclipsPipeline:
         self._progress_bar_config = {}
         self._device = torch.device("cpu")
         self.overlap_controlnet = True   # run SparseCtrl concurrently with the U-Net encoder (nr_denoise_step_forward)
+        self.prefetch_controlnet = os.environ.get("NR_NO_PREFETCH") is None   # issue step i+1's SparseCtrl during step i
 
     # ---- DiffusionPipeline surface used by the scripts (SURVEY §8c "Python harness rows") ----
     def register_modules(self, **kwargs):
@@ -265,9 +267,11 @@ class NeuroclipsPipeline:
                     getattr(self.controlnet, "set_noisy_sample_input_to_zero", False) and self.overlap_controlnet
                 if fused:
                     # same two network evaluations (:460-475), issued as one library call that overlaps them
+                    # the next step's SparseCtrl evaluation (independent of the latents) is issued early
+                    t_next = timesteps_host[i + 1] if (i + 1 < len(timesteps_host) and self.prefetch_controlnet) else None
                     noise_pred = self.unet.forward_with_controlnet(
                         self.controlnet, latent_model_input, t, text_embeddings, controlnet_cond,
-                        controlnet_conditioning_mask, controlnet_conditioning_scale).sample
+                        controlnet_conditioning_mask, controlnet_conditioning_scale, next_timestep=t_next).sample
                 elif use_ctrl:
                     down_res, mid_res = self.controlnet(
                         latent_model_input, t, encoder_hidden_states=text_embeddings, controlnet_cond=controlnet_cond,

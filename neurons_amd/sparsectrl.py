@@ -103,6 +103,7 @@ class NativeSparseCtrl(_NativeNet):
         if self._io_cond is None or self._io_cond.shape[0] != cb:
             self._io_cond = torch.empty(cb, self.config.conditioning_channels, f, h, w, dtype=torch.float32, device=sample.device)
             self._io_mask = torch.empty(cb, 1, f, h, w, dtype=torch.float32, device=sample.device)
+        self._cond_key = None       # the fused step (unet3d.forward_with_controlnet) must re-stage its condition
         self._io_cond.copy_(controlnet_cond)
         self._io_mask.copy_(conditioning_mask)
         sample_ptr = None

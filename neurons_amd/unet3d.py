@@ -463,10 +463,12 @@ class NativeUNet3D(_NativeNet):
     __call__ = forward
 
     def forward_with_controlnet(self, controlnet, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_mask,
-                                conditioning_scale: float = 1.0):
+                                conditioning_scale: float = 1.0, next_timestep=None):
         """``controlnet(...)`` then ``self(..., down_block_additional_residuals=..., mid_block_additional_residual=...)``
         (pipeline_neuroclips.py:460-475) as ONE library call that overlaps SparseCtrl with the U-Net encoder
-        (C ABI ``nr_denoise_step_forward``).  Returns the same ``.sample`` tensor as the two separate calls."""
+        (C ABI ``nr_denoise_step_forward``).  Returns the same ``.sample`` tensor as the two separate calls.
+        ``next_timestep``: timestep of the following step of the same clip — SparseCtrl's evaluation for it (which does
+        not depend on the latents) is then issued early and overlaps this step's decoder.  Same results."""
         if not sample.is_cuda:
             raise RuntimeError("forward_with_controlnet: CUDA (ROCm) tensors required; there is no CPU fallback")
         b, c, f, h, w = sample.shape
@@ -485,16 +487,24 @@ class NativeUNet3D(_NativeNet):
         if controlnet._io_cond is None or controlnet._io_cond.shape[0] != cb:
             controlnet._io_cond = torch.empty(cb, controlnet.config.conditioning_channels, f, h, w, dtype=torch.float32, device=sample.device)
             controlnet._io_mask = torch.empty(cb, 1, f, h, w, dtype=torch.float32, device=sample.device)
-        controlnet._io_cond.copy_(controlnet_cond)
-        controlnet._io_mask.copy_(conditioning_mask)
+        # copy the (step-invariant) condition only when it changed: a prefetched SparseCtrl evaluation may be reading it
+        ckey = (controlnet_cond.data_ptr(), controlnet_cond._version, conditioning_mask.data_ptr(), conditioning_mask._version,
+                tuple(controlnet_cond.shape), controlnet._plan_key)
+        if getattr(controlnet, "_cond_key", None) != ckey:
+            _lib.check(_lib.load().nr_net_invalidate_context(controlnet._handle()))     # drops any prefetched evaluation
+            controlnet._io_cond.copy_(controlnet_cond)
+            controlnet._io_mask.copy_(conditioning_mask)
+            controlnet._cond_key = ckey
+            controlnet._cond_ref = (controlnet_cond, conditioning_mask)
         ts = self._timesteps_host(timestep, b)
+        ts_next = self._timesteps_host(next_timestep, b) if next_timestep is not None else None
         n = len(controlnet._out_bufs) - 1
         lib = _lib.load()
         _lib.check(lib.nr_denoise_step_forward(self._h, controlnet._h, torch.cuda.current_stream().cuda_stream,
                                                self._io_sample.data_ptr(), ts, self._io_ctx.data_ptr(), L,
                                                controlnet._io_cond.data_ptr(), controlnet._io_mask.data_ptr(), cb,
                                                float(conditioning_scale), controlnet._out_ptrs,
-                                               controlnet._out_bufs[n].data_ptr(), self._io_out.data_ptr()))
+                                               controlnet._out_bufs[n].data_ptr(), self._io_out.data_ptr(), ts_next))
         return UNet3DConditionOutput(sample=self._io_out.clone())
 
     def _on_plan(self):

@@ -536,6 +536,52 @@ def gen_vae(out_dir):
 
 
 # --------------------------------------------------------------------------------------------------
+# CLIP text encoder: the installed transformers CLIPTextModel (the class _encode_prompt calls; the reference pins
+# transformers==4.47.1, this container has a newer release with the same CLIP text arithmetic)
+# --------------------------------------------------------------------------------------------------
+def tiny_clip_config():
+    from neurons_amd.clip import CLIPTextConfig
+    return CLIPTextConfig(vocab_size=1000, hidden_size=128, intermediate_size=512, num_hidden_layers=3, num_attention_heads=4,
+                          max_position_embeddings=77)
+
+
+@torch.no_grad()
+def gen_clip(out_dir):
+    for name in [m for m in sys.modules if m == "diffusers" or m.startswith("diffusers.")]:
+        pass    # the in-memory diffusers stubs do not interfere with transformers' CLIP
+    tv_stub = sys.modules.pop("torchvision", None)
+    try:
+        import transformers
+        from transformers import CLIPTextConfig as HFConfig, CLIPTextModel
+    finally:
+        if tv_stub is not None:
+            sys.modules["torchvision"] = tv_stub
+    from neurons_amd.clip import clip_random_state_dict
+    cfg = tiny_clip_config()
+    sd = clip_random_state_dict(cfg, seed=97)
+    hf = CLIPTextModel(HFConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                                num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                                max_position_embeddings=cfg.max_position_embeddings, hidden_act="quick_gelu",
+                                projection_dim=64, attn_implementation="eager"))
+    hsd = hf.state_dict()
+    own = {k for k in hsd if not k.endswith("position_ids")}
+    # transformers 4.x (the reference's pin, and every SD-1.5 checkpoint) prefixes the keys with "text_model."; 5.x dropped it
+    strip = not any(k.startswith("text_model.") for k in own)
+    load = {(k[len("text_model."):] if strip else k): v for k, v in sd.items()}
+    assert own == set(load.keys()), own ^ set(load.keys())
+    missing, unexpected = hf.load_state_dict(load, strict=False)
+    assert not unexpected and all(k.endswith("position_ids") for k in missing), (missing, unexpected)
+    hf.eval()
+    g = torch.Generator().manual_seed(98)
+    ids = torch.randint(0, cfg.vocab_size, (2, 77), generator=g)
+    ids[1, 10:] = cfg.vocab_size - 1           # a short prompt padded with the end token, like the "" negative prompt
+    out = hf(ids, attention_mask=None)[0]
+    np.savez_compressed(os.path.join(out_dir, "clip_tiny.npz"), ids=ids.numpy().astype(np.int32), last_hidden_state=out.numpy(),
+                        transformers_version=np.array(transformers.__version__))
+    print("clip_tiny:", tuple(out.shape), "abs mean", out.abs().mean().item(), "transformers", transformers.__version__)
+
+
+# --------------------------------------------------------------------------------------------------
 # weight ingestion: run the reference's own converter / LoRA-merge functions on synthetic checkpoints
 # --------------------------------------------------------------------------------------------------
 def _load_ref_module(name, path):
@@ -630,6 +676,7 @@ if __name__ == "__main__":
     gen_leaf_ops(out_dir)
     gen_sgm(out_dir)
     gen_vae(out_dir)
+    gen_clip(out_dir)
     gen_weights(out_dir)
     for f in sorted(os.listdir(out_dir)):
         print(f, os.path.getsize(os.path.join(out_dir, f)) // 1024, "KiB")

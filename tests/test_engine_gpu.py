@@ -181,6 +181,42 @@ def test_overlapped_step_equals_separate_calls(cuda):
     assert rel < 2.5e-2
 
 
+def test_prefetched_sparsectrl_equals_separate_calls(cuda):
+    """next_timestep issues SparseCtrl's evaluation for the following step early (it does not depend on the latents).
+    Hits, misses (wrong prediction, changed condition, changed context) must all give the separate-call results."""
+    g = np.load(os.path.join(GOLD, "tiny_networks.npz"))
+    unet, ctrl = _tiny()
+    ctx = torch.from_numpy(g["ctx"]).cuda()
+    cond, mask = torch.from_numpy(g["cond"]).cuda(), torch.from_numpy(g["mask"]).cuda()
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    samples = [torch.from_numpy(g["sample"]).cuda()] + [torch.randn(g["sample"].shape, generator=gen, device="cuda") for _ in range(4)]
+
+    def separate(sample, t, ctx_, cond_):
+        down, mid = ctrl(sample, t, encoder_hidden_states=ctx_, controlnet_cond=cond_, conditioning_mask=mask, return_dict=False)
+        return unet(sample, t, encoder_hidden_states=ctx_, down_block_additional_residuals=down, mid_block_additional_residual=mid).sample
+
+    ts = [981, 961, 941, 921, 901]
+    want = [separate(s, t, ctx, cond) for s, t in zip(samples, ts)]
+    # a 5-step "loop" with correct predictions (4 hits)
+    for i, (s, t) in enumerate(zip(samples, ts)):
+        nxt = ts[i + 1] if i + 1 < len(ts) else None
+        assert torch.equal(want[i], unet.forward_with_controlnet(ctrl, s, t, ctx, cond, mask, 1.0, next_timestep=nxt).sample), i
+    # wrong prediction: prefetch for 961 but 941 is asked -> must re-run
+    unet.forward_with_controlnet(ctrl, samples[0], ts[0], ctx, cond, mask, 1.0, next_timestep=ts[1])
+    assert torch.equal(want[2], unet.forward_with_controlnet(ctrl, samples[2], ts[2], ctx, cond, mask, 1.0, next_timestep=ts[3]).sample)
+    # condition modified in place between steps: the prefetched evaluation (old condition) must be dropped
+    cond2 = cond.clone()
+    unet.forward_with_controlnet(ctrl, samples[0], ts[0], ctx, cond2, mask, 1.0, next_timestep=ts[1])
+    cond2.mul_(0.5)
+    got = unet.forward_with_controlnet(ctrl, samples[1], ts[1], ctx, cond2, mask, 1.0).sample
+    assert torch.equal(got, separate(samples[1], ts[1], ctx, cond2)) and not torch.equal(got, want[1])
+    # context changed between steps
+    unet.forward_with_controlnet(ctrl, samples[0], ts[0], ctx, cond, mask, 1.0, next_timestep=ts[1])
+    ctx2 = (ctx * 0.7).contiguous()
+    got = unet.forward_with_controlnet(ctrl, samples[1], ts[1], ctx2, cond, mask, 1.0).sample
+    assert torch.equal(got, separate(samples[1], ts[1], ctx2, cond))
+
+
 def test_context_cache_tracks_content(cuda):
     """The to_k|to_v projections of the context are cached across calls; a different or in-place-modified context
     must invalidate them."""
