@@ -61,7 +61,9 @@ class NeuroclipsPipeline:
         self._progress_bar_config = {}
         self._device = torch.device("cpu")
         self.overlap_controlnet = True   # run SparseCtrl concurrently with the U-Net encoder (nr_denoise_step_forward)
-        self.prefetch_controlnet = os.environ.get("NR_NO_PREFETCH") is None   # issue step i+1's SparseCtrl during step i
+        # issue step i+1's SparseCtrl evaluation during step i's decoder (results identical).  Measured neutral on
+        # MI355X (14.00 vs 13.97 frames/s: the CUs are already saturated by the encoder overlap), so off by default
+        self.prefetch_controlnet = os.environ.get("NR_PREFETCH") == "1"
 
     # ---- DiffusionPipeline surface used by the scripts (SURVEY §8c "Python harness rows") ----
     def register_modules(self, **kwargs):
