@@ -457,11 +457,11 @@ void apply_override(const NrGemmParams& p, Plan& pl, int& m_fast) {
   int bm = -1, bn = -1, sk = -1, st = -1, ord = -1, wv = -1;
   sscanf(e, "%d,%d,%d,%d,%d,%d", &bm, &bn, &sk, &st, &ord, &wv);
   if (bm > 0 && bn > 0) {
-    const bool ok = (bm == 128 && (bn == 160 || bn == 128 || bn == 64)) || (bm == 64 && bn == 64) || (bm == 256 && bn == 128);
+    const bool ok = (bm == 128 && (bn == 160 || bn == 128 || bn == 64)) || (bm == 64 && bn == 64) || (bm == 256 && (bn == 128 || bn == 160));
     if (ok && !(p.geglu && bn == 160)) { pl.bm = bm; pl.bn = bn; }
   }
   if (wv == 4 || wv == 8) pl.waves = wv;
-  if (pl.bm == 256) pl.waves = 8;
+  if (pl.bm == 256 && pl.bn == 128 && wv != 4) pl.waves = 8;
   if (pl.bn == 160 || pl.bm == 64) pl.waves = 4;
   if (sk > 0 && !p.geglu) { const int nk = p.K / 64; pl.splitk = sk > nk ? nk : sk; }
   if (st >= 2 && st <= 3) pl.stages = st;
@@ -500,7 +500,9 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
   if (pl.splitk > 1 && !workspace) return 6;
   float* partial = p.out_f32 ? p.out_f32 : (pl.splitk > 1 ? workspace : nullptr);
   const unsigned grid = (unsigned)(((p.M + pl.bm - 1) / pl.bm) * ((p.N + pl.bn - 1) / pl.bn) * pl.splitk);
-  if (pl.bm == 256) launch_tile<256, 128, 4, 2>(p, grid, pl, partial, m_fast, stream);
+  if (pl.bm == 256 && pl.bn == 160) launch_tile<256, 160, 2, 2>(p, grid, pl, partial, m_fast, stream);
+  else if (pl.bm == 256 && pl.waves == 4) launch_tile<256, 128, 2, 2>(p, grid, pl, partial, m_fast, stream);
+  else if (pl.bm == 256) launch_tile<256, 128, 4, 2>(p, grid, pl, partial, m_fast, stream);
   else if (pl.bm == 128 && pl.bn == 160) launch_tile<128, 160, 2, 2>(p, grid, pl, partial, m_fast, stream);
   else if (pl.bm == 128 && pl.bn == 128 && pl.waves == 8) launch_tile<128, 128, 2, 4>(p, grid, pl, partial, m_fast, stream);
   else if (pl.bm == 128 && pl.bn == 128) launch_tile<128, 128, 2, 2>(p, grid, pl, partial, m_fast, stream);

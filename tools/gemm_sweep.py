@@ -25,6 +25,16 @@ CONFIGS = ["-1,-1,-1,2,-1,4", "128,128,1,2,-1,4", "128,128,1,2,-1,8", "128,64,1,
            "128,128,2,2,-1,8", "128,64,2,2,-1,4", "128,64,4,2,-1,4", "128,64,2,2,-1,8", "128,64,4,2,-1,8",
            "64,64,2,2,-1,4", "64,64,4,2,-1,4", "64,64,8,2,-1,4", "256,128,2,2,-1,8", "256,128,4,2,-1,8"]
 
+if os.environ.get("SWEEP_CONFIGS"):      # e.g. SWEEP_CONFIGS="256,128,1,2,-1,4;256,160,1,2,-1,4"
+    CONFIGS = ["-1,-1,-1,2,-1,4"] + os.environ["SWEEP_CONFIGS"].split(";")
+if os.environ.get("SWEEP_EXTRA"):        # extra shapes for the VAE: "conv:16,128,128,256,256,0;lin:8192,640,2560,1"
+    SHAPES = []
+    for item in os.environ["SWEEP_EXTRA"].split(";"):
+        kind, vals = item.split(":")
+        v = [int(x) for x in vals.split(",")]
+        SHAPES.append(("lin", v[0], v[1], v[2], bool(v[3])) if kind == "lin" else ("conv", (v[0], v[1], v[2]), v[3], v[4], bool(v[5])))
+
+
 def bench(fn, iters=20):
     for _ in range(3):
         fn()
