@@ -410,6 +410,12 @@ Plan choose_plan(const NrGemmParams& p) {
   const int nk = p.K / 64;
   Plan pl;
   pl.splitk = 1; pl.stages = 2; pl.waves = 4;
+  // 4x4-level convs (M <= 1024, K >= 8192): L2-bandwidth-bound with small tiles (every n-tile re-reads A, every m-tile
+  // re-reads W), so take the biggest tile and get the parallelism from a deep deterministic split-K instead
+  if (!p.geglu && p.M <= 1024 && nk >= 128 && p.N % 160 == 0) {
+    pl.bm = 128; pl.bn = 160; pl.splitk = nk >= 300 ? 16 : 8;
+    return pl;
+  }
   const bool n128 = p.N % 128 == 0 || p.N >= 960;          // <= 6 % padded columns otherwise
   if (!p.geglu && p.N % 160 == 0 && p.N < 960 && p.N % 128 != 0 && nk >= 20 && nblk(128, 160) >= 256) { pl.bm = 128; pl.bn = 160; }
   else if (n128 && nblk(128, 128) >= 400) { pl.bm = 128; pl.bn = 128; pl.waves = 8; }
@@ -447,7 +453,8 @@ void launch_cfg(const NrGemmParams& p, unsigned grid, int splitk, float* partial
 template <int BM, int BN, int WGM, int WGN>
 void launch_tile(const NrGemmParams& p, unsigned grid, const Plan& pl, float* partial, int m_fast, hipStream_t stream) {
   if (pl.stages <= 2) launch_cfg<BM, BN, 2, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);
-  else launch_cfg<BM, BN, 3, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);
+  else if (pl.stages == 3 || BM * BN > 128 * 64) launch_cfg<BM, BN, 3, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);
+  else launch_cfg<BM, BN, 4, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);   // deep ring: small tiles only
 }
 
 // test/tuning override: NR_IGEMM_FORCE="bm,bn,splitk,stages,order" (any field <0 keeps the heuristic's choice)
@@ -464,7 +471,7 @@ void apply_override(const NrGemmParams& p, Plan& pl, int& m_fast) {
   if (pl.bm == 256 && pl.bn == 128 && wv != 4) pl.waves = 8;
   if (pl.bn == 160 || pl.bm == 64) pl.waves = 4;
   if (sk > 0 && !p.geglu) { const int nk = p.K / 64; pl.splitk = sk > nk ? nk : sk; }
-  if (st >= 2 && st <= 3) pl.stages = st;
+  if (st >= 2 && st <= 4) pl.stages = st;
   if (ord >= 0) m_fast = ord;
 }
 
