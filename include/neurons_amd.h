@@ -245,6 +245,12 @@ nr_status nr_net_read_tap(nr_net* h, int32_t i, float* host_out, int64_t capacit
 nr_status nr_op_gemm(nr_stream stream, const void* a_dev, int32_t lda, const void* w_dev, const float* bias_dev,
                      const void* res_dev, int32_t ldr, void* out_dev, int32_t ldo, int32_t M, int32_t N, int32_t K,
                      int32_t geglu);
+/* LayerNorm folded into the GEMM (engine: ln_linear): w_scaled[n][k] = gamma[k] W[n][k] (bf16), ln_c[n] = sum_k w_scaled[n][k],
+ * bias_folded[n] = bias[n] + sum_k beta[k] W[n][k]; out = rstd_m (a . w_scaled^T - mean_m ln_c) + bias_folded with the row
+ * statistics of `a` accumulated inside the kernel.  act: 0 none, 1 quick_gelu. */
+nr_status nr_op_ln_gemm(nr_stream stream, const void* a_dev, int32_t lda, const void* w_scaled_dev, const float* ln_c_dev,
+                        const float* bias_folded_dev, float eps, const void* res_dev, int32_t ldr, void* out_dev, int32_t ldo,
+                        int32_t M, int32_t N, int32_t K, int32_t geglu, int32_t act);
 nr_status nr_op_conv3x3(nr_stream stream, const void* x0_dev, int32_t c0, const void* x1_dev, int32_t c1, int32_t nimg,
                         int32_t H, int32_t W, int32_t stride, int32_t ups, const void* w_dev, const float* bias_dev,
                         const float* rowvec_dev, int32_t rowvec_div, const void* res_dev, void* out_dev, int32_t Cout);

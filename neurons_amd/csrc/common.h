@@ -78,7 +78,8 @@ struct NrGemmParams {
   int M, N, K;
   const float* bias;   // [N] fp32 or null
   const float* rowvec; // [M/rowvec_div][N] fp32 or null (time-embedding add)
-  int rowvec_div;      // row m uses rowvec[(m / rowvec_div) * rowvec_ld + n]
+  int rowvec_div;      // row m uses rowvec[((m / rowvec_div) % rowvec_mod) * rowvec_ld + n]
+  int rowvec_mod;      // 0 = no modulo (time embedding per image batch); F = frame index (temporal PE term)
   int rowvec_ld;
   const bf16* res;     // residual [M][ldr] or null
   int ldr;
@@ -86,6 +87,11 @@ struct NrGemmParams {
   int ldo;
   float out_scale;     // (acc + bias + rowvec) * out_scale + res
   int geglu;           // 1: W rows are (value16|gate16)-interleaved; out has N/2 columns
+  // LayerNorm folded into the GEMM (1x1 only): w holds gamma-scaled rows W'[n][k] = gamma[k] W[n][k], ln_c[n] = sum_k W'[n][k],
+  // bias already contains beta . W[n][:]; the kernel accumulates the row sums of the raw activations it streams anyway and
+  // applies out = rstd_m * (acc - mean_m * ln_c[n]) + bias[n] in the epilogue.  null = plain GEMM.
+  const float* ln_c;
+  float ln_eps;
   int act;             // 0 none; 1 quick_gelu x*sigmoid(1.702x) (CLIP MLP), applied after bias/scale, before the residual
   int pad_tl0;         // 3x3 only: 1 = no top/left padding (bottom/right zero) — the VAE Downsample's F.pad (0,1,0,1)
   float* out_f32;      // non-null: write the raw fp32 accumulators to out_f32[M][N] and skip the epilogue (attention scores)

@@ -81,6 +81,12 @@ struct NrError : std::runtime_error {
     if (_r != 0) throw NrError(NR_ERR_UNSUPPORTED, std::string(#expr) + " -> " + std::to_string(_r)); \
   } while (0)
 
+inline float bf2f_host(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
 inline uint16_t f2bf_host(float f) {
   uint32_t u;
   std::memcpy(&u, &f, 4);
@@ -317,6 +323,84 @@ struct nr_net {
       return upload(name, h.data(), h.size() * 4);
     });
   }
+
+  // LayerNorm folded into the consuming Linear: y = W (gamma * xhat + beta) + b = rstd * (W' x - mean * c) + b'
+  // with W'[n][k] = gamma[k] W[n][k] (bf16), c[n] = sum_k W'[n][k], b'[n] = b[n] + sum_k beta[k] W[n][k].
+  // The igemm accumulates the row statistics of x itself (gemm.hip, LNF), so no LayerNorm pass touches HBM.
+  // wkeys: matrices [Neach][K] stacked along N (fused q|k|v); bkeys: their biases (empty = none);
+  // geglu: single [2*Neach][K] projection with the value/gate row interleave of w_geglu.
+  struct LnW { const bf16* w; const float* c; const float* b; };
+  LnW w_ln_linear(const std::vector<std::string>& wkeys, const std::vector<std::string>& bkeys, const std::string& ln, int Neach,
+                  int K, bool geglu) {
+    std::string name = ln + "|";
+    const int rows_each = geglu ? 2 * Neach : Neach;
+    for (auto& k : wkeys) { check_shape(k, need(k), {rows_each, K}); name += k + "|"; }
+    for (auto& k : bkeys) { check_shape(k, need(k), {rows_each}); name += k + "|"; }
+    check_shape(ln + ".weight", need(ln + ".weight"), {K});
+    check_shape(ln + ".bias", need(ln + ".bias"), {K});
+    LnW r{nullptr, nullptr, nullptr};
+    if (dry) return r;
+    const std::string nw = "lnw:" + name, nc = "lnc:" + name, nb = "lnb:" + name;
+    auto it = dev.find(nw);
+    if (it != dev.end()) { r.w = (const bf16*)it->second; r.c = (const float*)dev.at(nc); r.b = (const float*)dev.at(nb); return r; }
+    const HostTensor& g = data_of(ln + ".weight");
+    const HostTensor& be = data_of(ln + ".bias");
+    const size_t N = (size_t)rows_each * wkeys.size();
+    std::vector<uint16_t> hw(N * K);
+    std::vector<float> hc(N), hb(N);
+    for (size_t mi = 0; mi < wkeys.size(); ++mi) {
+      const HostTensor& W = data_of(wkeys[mi]);
+      const HostTensor* B = bkeys.empty() ? nullptr : &data_of(bkeys[mi]);
+      for (int n = 0; n < rows_each; ++n) {
+        int src = n;
+        if (geglu) { const int q = n / 32, j = n % 32; src = j < 16 ? q * 16 + j : Neach + q * 16 + (j - 16); }
+        const float* wr = W.data.data() + (size_t)src * K;
+        const size_t dst = mi * rows_each + n;
+        double c = 0.0, b = B ? (double)B->data[src] : 0.0;
+        for (int k = 0; k < K; ++k) {
+          const uint16_t q16 = f2bf_host(g.data[k] * wr[k]);
+          hw[dst * K + k] = q16;
+          c += (double)bf2f_host(q16);
+          b += (double)be.data[k] * (double)wr[k];
+        }
+        hc[dst] = (float)c; hb[dst] = (float)b;
+      }
+    }
+    r.w = (const bf16*)upload(nw, hw.data(), hw.size() * 2);
+    r.c = (const float*)upload(nc, hc.data(), hc.size() * 4);
+    r.b = (const float*)upload(nb, hb.data(), hb.size() * 4);
+    return r;
+  }
+  // temporal positional encoding pushed through the q|k|v projection: rv[f][n] = sum_k pe[f][k] W[n][k], f < max_len
+  // (motion_module.py:241-243,274-278 add pe AFTER the LayerNorm, so W(LN(x) + pe) = W LN(x) + W pe)
+  const float* pe_projection(const std::vector<std::string>& wkeys, int Neach, int K, int max_len) {
+    std::string name = "perv:" + std::to_string(max_len) + ":";
+    for (auto& k : wkeys) name += k + "|";
+    return (const float*)cached(name, [&]() {
+      const size_t N = (size_t)Neach * wkeys.size();
+      std::vector<float> pe((size_t)max_len * K);
+      const float kk = (float)(-std::log(10000.0) / (double)K);
+      for (int pos = 0; pos < max_len; ++pos)
+        for (int i = 0; i < K; i += 2) {
+          const float a = (float)pos * std::exp((float)i * kk);
+          pe[(size_t)pos * K + i] = std::sin(a);
+          if (i + 1 < K) pe[(size_t)pos * K + i + 1] = std::cos(a);
+        }
+      std::vector<float> rv((size_t)max_len * N);
+      for (size_t mi = 0; mi < wkeys.size(); ++mi) {
+        const HostTensor& W = data_of(wkeys[mi]);
+        for (int n = 0; n < Neach; ++n)
+          for (int f = 0; f < max_len; ++f) {
+            double a = 0.0;
+            const float* wr = W.data.data() + (size_t)n * K;
+            const float* pr = pe.data() + (size_t)f * K;
+            for (int k = 0; k < K; ++k) a += (double)pr[k] * (double)wr[k];
+            rv[(size_t)f * N + mi * Neach + n] = (float)a;
+          }
+      }
+      return upload(name, rv.data(), rv.size() * 4);
+    });
+  }
   // GEGLU projection [2*inner][K]: rows permuted so each 32-row group is 16 value rows then their 16 gate rows
   const bf16* w_geglu(const std::string& key, int inner, int K) {
     const HostTensor& t = need(key);
@@ -435,13 +519,14 @@ struct nr_net {
 
   struct GemmOpt {
     const float* bias = nullptr;
-    const float* rowvec = nullptr; int rowvec_div = 1, rowvec_ld = 0;
+    const float* rowvec = nullptr; int rowvec_div = 1, rowvec_ld = 0, rowvec_mod = 0;
     const Act* res = nullptr;
     float scale = 1.f;
     int geglu = 0;
     Act* out = nullptr;      // write into this existing activation (may alias res)
     int pad_tl0 = 0;         // 3x3: no top/left padding (VAE Downsample)
     int act = 0;             // 1: quick_gelu
+    const float* ln_c = nullptr;   // LayerNorm folded into this GEMM (see w_ln_linear)
   };
 
   // generic conv / linear.  x1: optional channel-concat second source.
@@ -459,8 +544,8 @@ struct nr_net {
     p.OH = OH; p.OW = OW; p.ksize = ksize; p.stride = stride; p.ups = ups;
     p.w = w;
     p.M = x0.nimg * OH * OW; p.N = Cout; p.K = ksize * ksize * (p.c0 + p.c1);
-    p.bias = o.bias; p.rowvec = o.rowvec; p.rowvec_div = o.rowvec_div; p.rowvec_ld = o.rowvec_ld;
-    p.out_scale = o.scale; p.geglu = o.geglu; p.pad_tl0 = o.pad_tl0; p.act = o.act;
+    p.bias = o.bias; p.rowvec = o.rowvec; p.rowvec_div = o.rowvec_div; p.rowvec_ld = o.rowvec_ld; p.rowvec_mod = o.rowvec_mod;
+    p.out_scale = o.scale; p.geglu = o.geglu; p.pad_tl0 = o.pad_tl0; p.act = o.act; p.ln_c = o.ln_c; p.ln_eps = 1e-5f;
     const int outC = o.geglu ? Cout / 2 : Cout;
     Act out = o.out ? *o.out : new_act(x0.nimg, OH, OW, outC);
     if (out.C != outC || out.rows() != p.M) throw NrError(NR_ERR_STATE, "conv: output shape mismatch");
@@ -612,11 +697,55 @@ struct nr_net {
     return out;
   }
 
+
+  // LayerNorm (+ temporal PE) -> Linear as one launch (LN folded into the igemm) or, with NR_NO_LN_FUSE=1, as the
+  // layernorm kernel followed by a plain igemm (A/B and fallback path; same results to rounding).
+  // Neach: rows of each stacked matrix (geglu: the inner width, the matrix has 2*Neach rows).
+  Act ln_linear(const Act& x, const std::string& ln, const std::vector<std::string>& wkeys, const std::vector<std::string>& bkeys,
+                int Neach, bool geglu, int act, bool temporal_pe) {
+    static const char* mode = getenv("NR_LN_FUSE");            // "0" never, "1" always, unset: per shape
+    const int K = x.C;
+    const int N = (geglu ? 2 * Neach : Neach) * (int)wkeys.size();
+    // Every n-tile block of the fused GEMM recomputes the row statistics (~1-2 us per block round), so the fusion pays
+    // when the LayerNorm launch it removes costs more than that: small M (latency-bound LN) or narrow N.  Measured on
+    // BASELINE config 2 (profiles/README.md): wide GEMMs at the 32x32 / 16x16 levels are faster with the separate LN.
+    const long long M = x.rows();
+    bool fuse = !((M >= 8192 && N >= 4 * K) || (M >= 32768 && N >= 3 * K));
+    if (mode) fuse = mode[0] == '1';
+    if (const char* sm = getenv("NR_LN_SITES")) {   // debug: bit 0 plain single, 1 stacked qkv, 2 geglu, 3 temporal
+      const int site = temporal_pe ? 3 : (geglu ? 2 : (wkeys.size() > 1 ? 1 : 0));
+      if (!((atoi(sm) >> site) & 1)) fuse = false;
+    }
+    GemmOpt o;
+    o.geglu = geglu ? 1 : 0; o.act = act;
+    if (fuse) {
+      const LnW lw = w_ln_linear(wkeys, bkeys, ln, Neach, K, geglu);
+      o.bias = lw.b; o.ln_c = lw.c;
+      if (temporal_pe) {
+        o.rowvec = pe_projection(wkeys, Neach, K, cfg.motion_pe_max_len);
+        o.rowvec_div = x.H * x.W; o.rowvec_ld = N; o.rowvec_mod = F;
+      }
+      return linear(x, lw.w, N, o);
+    }
+    Act n = layernorm(x, ln, temporal_pe ? pe_table(K, cfg.motion_pe_max_len) : nullptr, temporal_pe ? F : 1);
+    const bf16* w;
+    if (geglu) {
+      w = w_geglu(wkeys[0], Neach, K);
+      if (!bkeys.empty()) o.bias = b_geglu(bkeys[0], Neach);
+    } else if (wkeys.size() > 1) {
+      w = w_linear_cat(wkeys, Neach, K);
+      if (!bkeys.empty()) o.bias = b_cat(bkeys, Neach);
+    } else {
+      w = w_linear(wkeys[0], Neach, K);
+      if (!bkeys.empty()) o.bias = w_f32(bkeys[0], Neach);
+    }
+    return linear(n, w, N, o);
+  }
+
   // FeedForward(GEGLU) + residual, in place on t (motion_module_new.py:441-471,497-518)
-  void feed_forward(Act& t, const Act& normed, const std::string& pre) {
+  void feed_forward(Act& t, const std::string& ln, const std::string& pre) {
     const int C = t.C, inner = 4 * C;
-    GemmOpt o1; o1.bias = b_geglu(pre + ".net.0.proj.bias", inner); o1.geglu = 1;
-    Act hmid = linear(normed, w_geglu(pre + ".net.0.proj.weight", inner, C), 2 * inner, o1);
+    Act hmid = ln_linear(t, ln, {pre + ".net.0.proj.weight"}, {pre + ".net.0.proj.bias"}, inner, true, 0, false);
     GemmOpt o2; o2.bias = w_f32(pre + ".net.2.bias", C); o2.res = &t; o2.out = &t;
     linear(hmid, w_linear(pre + ".net.2.weight", C, inner), C, o2);
   }
@@ -634,20 +763,14 @@ struct nr_net {
     for (int dd = 0; dd < depth; ++dd) {
       const std::string b = pre + ".transformer_blocks." + std::to_string(dd);
       {  // self-attention
-        Act n1 = layernorm(t, b + ".norm1", nullptr, 1);
-        GemmOpt oq;
-        Act qkv = linear(n1, w_linear_cat({b + ".attn1.to_q.weight", b + ".attn1.to_k.weight", b + ".attn1.to_v.weight"}, C, C), 3 * C, oq);
-        n1 = Act();
+        Act qkv = ln_linear(t, b + ".norm1", {b + ".attn1.to_q.weight", b + ".attn1.to_k.weight", b + ".attn1.to_v.weight"}, {}, C, false, 0, false);
         Act a = attention(0, qkv, nullptr, C, heads);
         qkv = Act();
         GemmOpt oo; oo.bias = w_f32(b + ".attn1.to_out.0.bias", C); oo.res = &t; oo.out = &t;
         linear(a, w_linear(b + ".attn1.to_out.0.weight", C, C), C, oo);
       }
       {  // cross-attention on the context (attention.py:100: context repeated per frame)
-        Act n2 = layernorm(t, b + ".norm2", nullptr, 1);
-        GemmOpt oq;
-        Act q = linear(n2, w_linear(b + ".attn2.to_q.weight", C, C), C, oq);
-        n2 = Act();
+        Act q = ln_linear(t, b + ".norm2", {b + ".attn2.to_q.weight"}, {}, C, false, 0, false);
         GemmOpt ok;
         building_ctx = true;      // K|V of the context: recomputed only when the context changes
         Act kv = new_act_persistent(ctx_bf.nimg, ctx_bf.H, ctx_bf.W, 2 * C);
@@ -660,10 +783,7 @@ struct nr_net {
         GemmOpt oo; oo.bias = w_f32(b + ".attn2.to_out.0.bias", C); oo.res = &t; oo.out = &t;
         linear(a, w_linear(b + ".attn2.to_out.0.weight", C, C), C, oo);
       }
-      {
-        Act n3 = layernorm(t, b + ".norm3", nullptr, 1);
-        feed_forward(t, n3, b + ".ff");
-      }
+      feed_forward(t, b + ".norm3", b + ".ff");
     }
     GemmOpt op; op.bias = w_f32(pre + ".proj_out.bias", C); op.res = &x;
     Act out = linear(t, w_linear(pre + ".proj_out.weight", C, C), C, op);
@@ -683,22 +803,17 @@ struct nr_net {
     Act t = linear(hn, w_linear(pre + ".proj_in.weight", C, C), C, oi);
     hn = Act();
     const std::string b = pre + ".transformer_blocks.0";
-    const float* pe = pe_table(C, cfg.motion_pe_max_len);
     for (int k = 0; k < cfg.motion_num_attention_blocks; ++k) {
       const std::string ab = b + ".attention_blocks." + std::to_string(k);
-      Act n = layernorm(t, b + ".norms." + std::to_string(k), pe, F);   // LayerNorm, then + pe[frame] (motion_module.py:212,277)
-      GemmOpt oq;
-      Act qkv = linear(n, w_linear_cat({ab + ".to_q.weight", ab + ".to_k.weight", ab + ".to_v.weight"}, C, C), 3 * C, oq);
-      n = Act();
+      // LayerNorm, then + pe[frame] (motion_module.py:212,277): both folded into the q|k|v GEMM
+      Act qkv = ln_linear(t, b + ".norms." + std::to_string(k), {ab + ".to_q.weight", ab + ".to_k.weight", ab + ".to_v.weight"}, {}, C,
+                          false, 0, true);
       Act a = attention(2, qkv, nullptr, C, heads);
       qkv = Act();
       GemmOpt oo; oo.bias = w_f32(ab + ".to_out.0.bias", C); oo.res = &t; oo.out = &t;
       linear(a, w_linear(ab + ".to_out.0.weight", C, C), C, oo);
     }
-    {
-      Act n = layernorm(t, b + ".ff_norm", nullptr, 1);
-      feed_forward(t, n, b + ".ff");
-    }
+    feed_forward(t, b + ".ff_norm", b + ".ff");
     GemmOpt op; op.bias = w_f32(pre + ".proj_out.bias", C); op.res = &x;
     Act out = linear(t, w_linear(pre + ".proj_out.weight", C, C), C, op);
     tap(pre0, out);
@@ -1086,11 +1201,8 @@ struct nr_net {
     for (int i = 0; i < cfg.layers_per_block; ++i) {
       const std::string lp = tm + "encoder.layers." + std::to_string(i);
       const std::string ap = lp + ".self_attn";
-      Act n1 = layernorm(x, lp + ".layer_norm1", nullptr, 1);
-      GemmOpt oq;
-      oq.bias = b_cat({ap + ".q_proj.bias", ap + ".k_proj.bias", ap + ".v_proj.bias"}, C);
-      Act qkv = linear(n1, w_linear_cat({ap + ".q_proj.weight", ap + ".k_proj.weight", ap + ".v_proj.weight"}, C, C), 3 * C, oq);
-      n1 = Act();
+      Act qkv = ln_linear(x, lp + ".layer_norm1", {ap + ".q_proj.weight", ap + ".k_proj.weight", ap + ".v_proj.weight"},
+                          {ap + ".q_proj.bias", ap + ".k_proj.bias", ap + ".v_proj.bias"}, C, false, 0, false);
       Act ao = attention(0, qkv, nullptr, C, heads, 1);      // causal mask (CLIPTextTransformer builds it for every call)
       qkv = Act();
       // residual updates run in place, except in debug mode where every tap keeps its own buffer
@@ -1098,10 +1210,7 @@ struct nr_net {
       Act x1 = linear(ao, w_linear(ap + ".out_proj.weight", C, C), C, oo);
       x = x1;
       ao = Act();
-      Act n2 = layernorm(x, lp + ".layer_norm2", nullptr, 1);
-      GemmOpt o1; o1.bias = w_f32(lp + ".mlp.fc1.bias", inter); o1.act = 1;
-      Act hmid = linear(n2, w_linear(lp + ".mlp.fc1.weight", inter, C), inter, o1);
-      n2 = Act();
+      Act hmid = ln_linear(x, lp + ".layer_norm2", {lp + ".mlp.fc1.weight"}, {lp + ".mlp.fc1.bias"}, inter, false, 1, false);
       GemmOpt o2; o2.bias = w_f32(lp + ".mlp.fc2.bias", C); o2.res = &x; o2.out = keep_all ? nullptr : &x;
       Act x2 = linear(hmid, w_linear(lp + ".mlp.fc2.weight", C, inter), C, o2);
       x = x2;
@@ -1847,6 +1956,20 @@ extern "C" nr_status nr_op_gemm(nr_stream stream, const void* a, int32_t lda, co
   p.w = (const bf16*)w; p.M = M; p.N = N; p.K = K; p.bias = bias; p.res = (const bf16*)res; p.ldr = ldr;
   p.out = (bf16*)out; p.ldo = ldo; p.out_scale = 1.f; p.geglu = geglu; p.rowvec_div = 1;
   LAUNCH_OK(nr_launch_igemm(&p, op_workspace(p), (hipStream_t)stream));
+  NR_CATCH
+}
+
+extern "C" nr_status nr_op_ln_gemm(nr_stream stream, const void* a, int32_t lda, const void* w_scaled, const float* ln_c,
+                                   const float* bias_folded, float eps, const void* res, int32_t ldr, void* out, int32_t ldo,
+                                   int32_t M, int32_t N, int32_t K, int32_t geglu, int32_t act) {
+  NR_TRY
+  if (!ln_c) throw NrError(NR_ERR_ARG, "ln_c is required");
+  NrGemmParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.a0 = (const bf16*)a; p.c0 = K; p.lda0 = lda; p.H = p.W = p.OH = p.OW = 1; p.ksize = 1; p.stride = 1;
+  p.w = (const bf16*)w_scaled; p.M = M; p.N = N; p.K = K; p.bias = bias_folded; p.res = (const bf16*)res; p.ldr = ldr;
+  p.out = (bf16*)out; p.ldo = ldo; p.out_scale = 1.f; p.geglu = geglu; p.rowvec_div = 1; p.ln_c = ln_c; p.ln_eps = eps; p.act = act;
+  LAUNCH_OK(nr_launch_igemm(&p, nullptr, (hipStream_t)stream));
   NR_CATCH
 }
 

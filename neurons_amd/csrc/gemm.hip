@@ -41,8 +41,14 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+__device__ __forceinline__ size_t rowvec_row(const NrGemmParams& p, int m) {
+  int r = m / p.rowvec_div;
+  if (p.rowvec_mod) r %= p.rowvec_mod;
+  return (size_t)r * p.rowvec_ld;
+}
+
 // WGM x WGN = wave grid over the (M, N) tile; 64*WGM*WGN threads
-template <int BM, int BN, int NS, int WGM, int WGN>
+template <int BM, int BN, int NS, int WGM, int WGN, bool LNF = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams p, int splitk, float* partial, int m_fast) {
   constexpr int BK = 64;
   constexpr int NW = WGM * WGN;
@@ -182,6 +188,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
     for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fg = lane >> 4;
+  // LayerNorm fusion: row sums / sums of squares of the raw activation fragments.  The WGN waves that share an A slab
+  // split the k-steps between them (v_dot2c_f32_bf16: 8 VALU ops per fragment), combined through LDS after the loop.
+  float ln_s1[MT], ln_s2[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) { ln_s1[j] = 0.f; ln_s2[j] = 0.f; }
+  float* ln_stat = reinterpret_cast<float*>(smem + NS * TILE);   // LNF only: 2 * WGN * BM floats behind the operand ring
 
   // ---- main loop: ring of NS LDS buffers, tiles kt+1 .. kt+NS-2 stay in flight across the barrier ----
   constexpr int G = GA + GB;                 // LDS-DMA instructions per wave per k-tile (wave-uniform)
@@ -232,7 +244,59 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
 #pragma unroll
         for (int j = 0; j < MT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], xf[ks][j], acc[i][j], 0, 0, 0);
+    if constexpr (LNF) {
+      const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if (((2 * kt + ks) & (WGN - 1)) != wn) continue;      // this k-step belongs to a sibling wave
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bf16x2 pr = {xf[ks][j][2 * e], xf[ks][j][2 * e + 1]};
+            ln_s2[j] = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, ln_s2[j], false);
+            ln_s1[j] = __builtin_amdgcn_fdot2_f32_bf16(pr, one2, ln_s1[j], false);
+          }
+      }
+    }
     cur = cur + 1 == NS ? 0 : cur + 1;
+  }
+  // per-row mean / rstd of this wave's MT row tiles (lane: row fr of each tile)
+  float ln_mu[MT], ln_rs[MT];
+  if constexpr (LNF) {
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      float a = ln_s1[j], b = ln_s2[j];
+      a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+      a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+      if (fg == 0) {
+        const int row = wm * WM + j * 16 + fr;
+        ln_stat[(0 * WGN + wn) * BM + row] = a;
+        ln_stat[(1 * WGN + wn) * BM + row] = b;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int row = wm * WM + j * 16 + fr;
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < WGN; ++w) { a += ln_stat[(0 * WGN + w) * BM + row]; b += ln_stat[(1 * WGN + w) * BM + row]; }
+      const float inv = 1.0f / (float)p.K;
+      const float mu = a * inv;
+      ln_mu[j] = mu;
+      ln_rs[j] = rsqrtf(fmaxf(b * inv - mu * mu, 0.f) + p.ln_eps);
+    }
+    // acc <- rstd_m * (acc - mean_m * sum_k W'[n][k]); the (beta . W + bias) term is p.bias, added by the epilogues below
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int n = n0 + wn * WN + i * 16 + 4 * fg;
+      const f32x4 cn = n < p.N ? *(const f32x4*)(p.ln_c + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = ln_rs[j] * (acc[i][j][r] - ln_mu[j] * cn[r]);
+    }
   }
 
   // ---- epilogue: lane holds out[m = ..+fr][n = ..+4*fg + r], r = 0..3 ----
@@ -299,7 +363,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
       if (!p.geglu) {
         if (p.bias) { va += *(const f32x4*)(p.bias + n); vb += *(const f32x4*)(p.bias + n + 4); }
         if (p.rowvec) {
-          const float* rv = p.rowvec + (size_t)(m / p.rowvec_div) * p.rowvec_ld + n;
+          const float* rv = p.rowvec + rowvec_row(p, m) + n;
           va += *(const f32x4*)rv; vb += *(const f32x4*)(rv + 4);
         }
         va *= p.out_scale; vb *= p.out_scale;
@@ -324,7 +388,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
   for (int j = 0; j < MT; ++j) {
     const int m = m0 + wm * WM + j * 16 + fr;
     if (m >= p.M) continue;
-    const float* rv = p.rowvec ? p.rowvec + (size_t)(m / p.rowvec_div) * p.rowvec_ld : nullptr;
+    const float* rv = p.rowvec ? p.rowvec + rowvec_row(p, m) : nullptr;
     if (!p.geglu) {
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
@@ -383,7 +447,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(NrGemmParams p, int 
   f32x4 v = *(const f32x4*)src;
   for (int s = 1; s < splitk; ++s) v += *(const f32x4*)(src + s * slab);
   if (p.bias) v += *(const f32x4*)(p.bias + n);
-  if (p.rowvec) v += *(const f32x4*)(p.rowvec + (size_t)(m / p.rowvec_div) * p.rowvec_ld + n);
+  if (p.rowvec) v += *(const f32x4*)(p.rowvec + rowvec_row(p, m) + n);
   v *= p.out_scale;
   if (p.act == 1) {
 #pragma unroll
@@ -441,6 +505,23 @@ Plan choose_plan(const NrGemmParams& p) {
 template <int BM, int BN, int NS, int WGM, int WGN>
 void launch_cfg(const NrGemmParams& p, unsigned grid, int splitk, float* partial, int m_fast, hipStream_t stream) {
   const size_t shm = (size_t)NS * (BM + BN) * 64 * sizeof(bf16);
+  // LayerNorm-fused variant: instantiated for the tiles the transformer GEMMs use (nr_launch_igemm maps others onto them).
+  // Its row-statistics exchange buffer lives in the DYNAMIC allocation behind the ring: a static __shared__ array next to
+  // > 64 KiB of dynamic LDS made the first launch (and any hipGraph node captured from it) run with a short allocation.
+  constexpr bool LN_OK = NS == 2 && BM <= 128 && BN <= 128;
+  if (p.ln_c) {
+    if constexpr (LN_OK) {
+      const size_t shm_ln = shm + (size_t)2 * WGN * BM * sizeof(float);
+      static bool attr_ln = false;
+      if (!attr_ln) {
+        (void)hipFuncSetAttribute((const void*)igemm_bf16_kernel<BM, BN, NS, WGM, WGN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_ln);
+        attr_ln = true;
+      }
+      hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, NS, WGM, WGN, true>), dim3(grid), dim3(64 * WGM * WGN), shm_ln, stream, p, splitk,
+                         partial, m_fast);
+    }
+    return;
+  }
   static bool attr_set = false;
   if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (gfx950 has 160 KiB per CU)
     (void)hipFuncSetAttribute((const void*)igemm_bf16_kernel<BM, BN, NS, WGM, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -479,7 +560,7 @@ void apply_override(const NrGemmParams& p, Plan& pl, int& m_fast) {
 
 // fp32 scratch (bytes) a launch of this shape needs for split-K slabs (0 if none)
 extern "C" size_t nr_igemm_workspace_bytes(const NrGemmParams* pp) {
-  if (pp->out_f32) return 0;
+  if (pp->out_f32 || pp->ln_c) return 0;
   Plan pl = choose_plan(*pp);
   int mf = 0;
   apply_override(*pp, pl, mf);
@@ -500,6 +581,12 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
   const double a_elems = (double)p.M * Cin * (p.ksize == 3 ? (p.stride == 2 ? 4.0 : (p.ups ? 0.25 : 1.0)) : 1.0);
   int m_fast = w_elems > a_elems ? 1 : 0;
   apply_override(p, pl, m_fast);
+  if (p.ln_c) {      // LayerNorm-fused: every block must see the whole row (K = C) -> no split-K; supported tiles only
+    if (p.ksize != 1 || p.a1 || p.out_f32) return 8;
+    pl.splitk = 1; pl.stages = 2;
+    if (pl.bm > 128) { pl.bm = 128; pl.bn = 128; pl.waves = 8; }
+    if (pl.bn > 128) { pl.bn = 128; pl.waves = 8; }
+  }
   if (p.out_f32) {   // raw fp32 result: the kernel's slab path with a single K slice, no reduce pass
     if (p.geglu) return 7;
     pl.splitk = 1;

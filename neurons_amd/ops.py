@@ -42,6 +42,26 @@ def gemm(a, w, bias=None, res=None, geglu=False):
     return out
 
 
+def ln_gemm(a, w, gamma, beta, bias=None, res=None, eps=1e-5, act=0):
+    """out = Linear(LayerNorm(a)) with the LayerNorm folded into the GEMM (engine: ln_linear).  The folding of gamma / beta
+    into (w_scaled, ln_c, bias_folded) is done here on the host exactly as engine.hip's w_ln_linear does."""
+    _chk_bf16(a, res)
+    M, K = a.shape
+    N = w.shape[0]
+    wf = w.float()
+    ws = (wf * gamma.float()[None]).to(torch.bfloat16).contiguous()
+    c = ws.float().sum(dim=1).contiguous()
+    b = (wf.double() @ beta.double()).float()
+    if bias is not None:
+        b = b + bias.float()
+    b = b.contiguous()
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    lib = _lib.load()
+    _lib.check(lib.nr_op_ln_gemm(_stream(), _ptr(a), K, _ptr(ws), _ptr(c), _ptr(b), float(eps), _ptr(res), N, _ptr(out), N, M, N, K, 0,
+                                 int(act)))
+    return out
+
+
 def geglu_permute(w, b):
     """Reorder a GEGLU projection (rows [value(inner) | gate(inner)]) into 16-value/16-gate interleave."""
     inner = w.shape[0] // 2

@@ -189,3 +189,22 @@ def test_cfg_ddim_step(cuda):
     err = (out - ref).abs().max().item()
     print(f"[cfg_ddim] max_err={err:.3e}")
     assert err < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 320, 320), (4096, 960, 320), (300, 1280, 1280), (2048, 128, 64), (154, 3072, 768)])
+def test_ln_gemm_matches_layernorm_then_linear_and_is_deterministic(cuda, M, N, K):
+    """LayerNorm folded into the igemm (row statistics accumulated inside the kernel) vs fp32 torch LN -> Linear."""
+    from neurons_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g, device="cuda") * 2.0 + 0.7).to(torch.bfloat16)      # non-zero mean rows
+    w = torch.randn(N, K, generator=g, device="cuda") * K ** -0.5
+    gamma = 1.0 + 0.2 * torch.randn(K, generator=g, device="cuda")
+    beta = 0.1 * torch.randn(K, generator=g, device="cuda")
+    bias = 0.1 * torch.randn(N, generator=g, device="cuda")
+    res = torch.randn(M, N, generator=g, device="cuda").to(torch.bfloat16)
+    out = ops.ln_gemm(a, w, gamma, beta, bias, res)
+    ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(a.float(), (K,), gamma, beta, 1e-5), w, bias) + res.float()
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 2e-2 * ref.abs().max().item(), err
+    for _ in range(20):
+        assert torch.equal(out, ops.ln_gemm(a, w, gamma, beta, bias, res))
