@@ -42,11 +42,67 @@ def parse():
     ap.add_argument("--latent", type=int, default=32, help="latent side (pixels/8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--workload", choices=["video", "keyframe"], default="video",
-                    help="video = BASELINE config 2 (headline); keyframe = config 3: sgm unCLIP U-Net, Euler-EDM + CFG 5.0")
+    ap.add_argument("--workload", choices=["video", "keyframe", "vae"], default="video",
+                    help="video = BASELINE config 2 (headline); keyframe = config 3: sgm unCLIP U-Net, Euler-EDM + CFG 5.0; "
+                         "vae = the first-stage round trip of one clip (SURVEY 8f rank 1): encode 16 frames + decode 16 frames")
     ap.add_argument("--keyframe-steps", type=int, default=50)
     ap.add_argument("--keyframe-latent", type=int, default=64, help="64 = BASELINE config 3 (512 px); 96 = reference-faithful (768 px, 38 steps)")
     return ap.parse_args()
+
+
+def vae_main(args):
+    """SURVEY §8f rank 1 (single GPU): one step = encode the clip's 16 blurry frames (scripts/neuroclips_video.py:267) and
+    decode its 16 denoised frames (decode_latents), both through the C ABI.  Prints one JSON line with frames/s."""
+    from neurons_amd.vae import NativeVAEDecoder, NativeVAEEncoder, VAEDecoderConfig, vae_decoder_state_dict_schema, vae_encoder_state_dict_schema
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    cfg = VAEDecoderConfig()
+    dsd = gpu_random_state_dict(vae_decoder_state_dict_schema(cfg), 3, dev)
+    esd = gpu_random_state_dict(vae_encoder_state_dict_schema(cfg), 4, dev)
+    dec, enc = NativeVAEDecoder(cfg).to(dev), NativeVAEEncoder(cfg).to(dev)
+    dec.load_state_dict({k: v.cpu() for k, v in dsd.items()})
+    enc.load_state_dict({k: v.cpu() for k, v in esd.items()})
+    F, L = args.frames, args.latent
+    g = torch.Generator(device=dev).manual_seed(5)
+    items = [(torch.rand(F, 3, L * 8, L * 8, generator=g, device=dev), torch.randn(1, 4, F, L, L, generator=g, device=dev) * 0.18215)
+             for _ in range(args.warmup + args.steps)]
+
+    def step(img, lat):
+        z = enc.encode(img, in_mul=2.0, in_add=-1.0).sample(generator=g, scale=0.18215)
+        return z, dec.decode_latents(lat)
+
+    for it in items[:args.warmup]:
+        step(*it)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for it in items[args.warmup:]:
+        z, vid = step(*it)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t1
+    pd, pe = dec.profile_last(), enc.profile_last()
+    ig_ms = pd["igemm"]["ms"] + pe["igemm"]["ms"]
+    ig_fl = pd["igemm"]["flops"] + pe["igemm"]["flops"]
+    res = {
+        "metric": "first-stage VAE frames/sec (encode + decode of a 16f x 256^2 clip)", "value": round(args.steps * F / el, 3), "unit": "frames/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"SURVEY 8f rank 1: encode {F} x 3x{L * 8}x{L * 8} images + decode ({F},4,{L},{L}) latents, SD-1.5 VAE "
+                               f"(ch 128, mult 1,2,4,4), random-init weights", "output_finite": bool(torch.isfinite(vid).all() and torch.isfinite(z).all())},
+        "roofline": {"bound": "mfma", "kernel": "igemm_bf16_kernel (3x3 conv)", "achieved": round(ig_fl / (ig_ms * 1e-3) / 1e12, 2),
+                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ig_fl / (ig_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                     "per_class_ms": {"decode": {k: round(v["ms"], 3) for k, v in pd.items()}, "encode": {k: round(v["ms"], 3) for k, v in pe.items()}}}}
+    if not args.no_cpu_baseline:
+        from oracle import vae_oracle as V
+        hd = {k: v.cpu() for k, v in dsd.items()}
+        he = {k: v.cpu() for k, v in esd.items()}
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            V.encode_moments(he, 2 * items[0][0][:1].cpu() - 1, 4, 2)
+            V.decode(hd, items[0][1][:, :, 0].cpu() / 0.18215, 4, 2)
+            dt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"oracle encode + decode of ONE {L * 8}x{L * 8} frame took {dt:.2f} s on {torch.get_num_threads()} threads"}
+    print(json.dumps(res))
 
 
 def keyframe_main(args):
@@ -126,6 +182,8 @@ def main():
     args = parse()
     if args.workload == "keyframe":
         return keyframe_main(args)
+    if args.workload == "vae":
+        return vae_main(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
