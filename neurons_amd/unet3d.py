@@ -416,6 +416,51 @@ def _as_nhwc_bf16(r, frames):
 class NativeUNet3D(_NativeNet):
     _kind = _lib.NR_KIND_UNET3D
 
+    @classmethod
+    def from_pretrained_2d(cls, pretrained_model_name_or_path, unet_additional_kwargs=None, subfolder=None, **kwargs):
+        """``UNet3DConditionModel.from_pretrained_2d`` (unet.py:477-572) for a LOCAL diffusers directory (there is no hub
+        access): read ``<path>[/<subfolder>]/config.json`` of the 2-D SD U-Net, force the 3-D block types exactly as the
+        reference does (:551-562), apply ``unet_additional_kwargs`` (inference-v3.yaml), then load
+        ``diffusion_pytorch_model.safetensors`` (or ``.bin``) with ``strict=False`` — the motion-module keys stay missing
+        until ``load_weights`` brings the motion checkpoint (util.py:106-121)."""
+        import json
+        import os
+        root = os.path.join(pretrained_model_name_or_path, subfolder) if subfolder else pretrained_model_name_or_path
+        with open(os.path.join(root, "config.json")) as f:
+            config = json.load(f)
+        config["down_block_types"] = ["CrossAttnDownBlock3D", "CrossAttnDownBlock3D", "CrossAttnDownBlock3D", "DownBlock3D"]
+        config["up_block_types"] = ["UpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D"]
+        config.update(unet_additional_kwargs or {})
+        known = {f for f in UNet3DConfig.__dataclass_fields__}
+        # 2-D switches the NEURONS configs leave at their defaults (rejected if set otherwise) and bookkeeping keys
+        inert = {"_class_name": None, "_diffusers_version": None, "_name_or_path": None, "center_input_sample": False, "flip_sin_to_cos": True,
+                 "freq_shift": 0, "downsample_padding": 1, "mid_block_scale_factor": 1, "act_fn": "silu", "dual_cross_attention": False,
+                 "use_linear_projection": False, "class_embed_type": None, "num_class_embeds": None, "upcast_attention": False,
+                 "resnet_time_scale_shift": "default", "only_cross_attention": False, "mid_block_type": "UNetMidBlock3DCrossAttn",
+                 "unet_use_cross_frame_attention": False, "unet_use_temporal_attention": False}
+        fields = {}
+        for k, v in config.items():
+            if k in known:
+                fields[k] = tuple(v) if isinstance(v, list) else v
+            elif k in inert:
+                if inert[k] is not None and v is not None and v != inert[k]:
+                    raise NotImplementedError(f"config.json: {k}={v!r} is not built (the NEURONS inference path uses {inert[k]!r})")
+            else:
+                raise NotImplementedError(f"config.json: unknown U-Net option {k!r}")
+        model = cls(UNet3DConfig(**fields))
+        print(f"loaded 3D unet's pretrained weights from {pretrained_model_name_or_path} ...")
+        st = os.path.join(root, "diffusion_pytorch_model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            state_dict = load_file(st)
+        else:
+            state_dict = torch.load(os.path.join(root, "diffusion_pytorch_model.bin"), map_location="cpu")
+        m, u = model.load_state_dict(state_dict, strict=False)
+        print(f"### missing keys: {len(m)}; \n### unexpected keys: {len(u)};")
+        params = [int(np.prod(shape)) if "motion_modules." in n else 0 for n, shape in model._schema.items()]
+        print(f"### Motion Module Parameters: {sum(params) / 1e6} M")
+        return model
+
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, attention_mask=None,
                 down_block_additional_residuals: Optional[Sequence[torch.Tensor]] = None,
                 mid_block_additional_residual: Optional[torch.Tensor] = None, return_dict: bool = True):

@@ -92,3 +92,40 @@ def test_motion_module_filter():
                          "down_blocks.0.motion_modules.0.temporal_transformer.transformer_blocks.0.attention_blocks.0.pos_encoder.pe": torch.zeros(1),
                          "conv_in.weight": torch.zeros(1)}}
     assert list(W.filter_motion_module(sd)) == ["down_blocks.0.motion_modules.0.temporal_transformer.proj_in.weight"]
+
+
+def test_from_pretrained_2d_local_directory(tmp_path):
+    """UNet3DConditionModel.from_pretrained_2d (unet.py:477-572) on a local SD-style directory: 2-D config.json + safetensors
+    weights; the motion-module keys are the only missing ones; unknown / unsupported options are refused."""
+    import json
+    from safetensors.torch import save_file
+    from neurons_amd import NativeUNet3D
+    from neurons_amd.unet3d import random_state_dict, state_dict_schema
+    from oracle.gen_golden import tiny_unet_config
+    cfg = tiny_unet_config()
+    sd = random_state_dict(cfg, seed=5)
+    sd2d = {k: v.contiguous() for k, v in sd.items() if "motion_modules." not in k}
+    root = os.path.join(tmp_path, "sd", "unet")
+    os.makedirs(root)
+    save_file(sd2d, os.path.join(root, "diffusion_pytorch_model.safetensors"))
+    conf = {"_class_name": "UNet2DConditionModel", "_diffusers_version": "0.6.0", "act_fn": "silu", "attention_head_dim": cfg.attention_head_dim,
+            "block_out_channels": list(cfg.block_out_channels), "center_input_sample": False, "cross_attention_dim": cfg.cross_attention_dim,
+            "down_block_types": ["CrossAttnDownBlock2D"] * 3 + ["DownBlock2D"], "downsample_padding": 1, "flip_sin_to_cos": True, "freq_shift": 0,
+            "in_channels": 4, "layers_per_block": 2, "mid_block_scale_factor": 1, "norm_eps": 1e-05, "norm_num_groups": cfg.norm_num_groups,
+            "out_channels": 4, "sample_size": 64, "up_block_types": ["UpBlock2D"] + ["CrossAttnUpBlock2D"] * 3}
+    with open(os.path.join(root, "config.json"), "w") as f:
+        json.dump(conf, f)
+    extra = dict(use_inflated_groupnorm=True, use_motion_module=True, motion_module_resolutions=[1, 2, 4, 8], motion_module_mid_block=False,
+                 motion_module_type="Vanilla", motion_module_kwargs=dict(cfg.motion_module_kwargs))
+    unet = NativeUNet3D.from_pretrained_2d(os.path.join(tmp_path, "sd"), subfolder="unet", unet_additional_kwargs=extra)
+    assert unet.config.down_block_types == ("CrossAttnDownBlock3D",) * 3 + ("DownBlock3D",) and unet.config.sample_size == 64
+    schema = state_dict_schema(cfg)
+    assert set(unet._pending) == set(sd2d) and all("motion_modules." in k for k in schema if k not in unet._loaded)
+    # the motion checkpoint then completes it (load_weights path, util.py:106-121)
+    missing, unexpected = unet.load_state_dict({k: v for k, v in sd.items() if "motion_modules." in k}, strict=False)
+    assert not missing and not unexpected
+    conf["dual_cross_attention"] = True
+    with open(os.path.join(root, "config.json"), "w") as f:
+        json.dump(conf, f)
+    with pytest.raises(NotImplementedError, match="dual_cross_attention"):
+        NativeUNet3D.from_pretrained_2d(os.path.join(tmp_path, "sd"), subfolder="unet", unet_additional_kwargs=extra)
