@@ -75,10 +75,14 @@ struct NrError : std::runtime_error {
     if (_e != hipSuccess) throw NrError(NR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
   } while (0)
 
+// launcher return code (unsupported shape) AND the HIP launch status: a rejected launch (bad LDS size, bad grid) must
+// fail loudly instead of leaving the previous contents of the output buffer in place
 #define LAUNCH_OK(expr)                                                                              \
   do {                                                                                               \
     int _r = (expr);                                                                                 \
     if (_r != 0) throw NrError(NR_ERR_UNSUPPORTED, std::string(#expr) + " -> " + std::to_string(_r)); \
+    hipError_t _le = hipGetLastError();                                                              \
+    if (_le != hipSuccess) throw NrError(NR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_le)); \
   } while (0)
 
 inline float bf2f_host(uint16_t h) {

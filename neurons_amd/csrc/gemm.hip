@@ -542,6 +542,11 @@ void launch_tile(const NrGemmParams& p, unsigned grid, const Plan& pl, float* pa
 void apply_override(const NrGemmParams& p, Plan& pl, int& m_fast) {
   const char* e = getenv("NR_IGEMM_FORCE");
   if (!e) return;
+  // optional filters so an in-situ A/B (bench.py under hipGraph, no per-launch host overhead) can target one shape class:
+  // NR_IGEMM_FORCE_MAXM / _MINM bound p.M, NR_IGEMM_FORCE_KS selects 1x1 or 3x3 launches
+  if (const char* f = getenv("NR_IGEMM_FORCE_MAXM")) if (p.M > atoi(f)) return;
+  if (const char* f = getenv("NR_IGEMM_FORCE_MINM")) if (p.M < atoi(f)) return;
+  if (const char* f = getenv("NR_IGEMM_FORCE_KS")) if (p.ksize != atoi(f)) return;
   int bm = -1, bn = -1, sk = -1, st = -1, ord = -1, wv = -1;
   sscanf(e, "%d,%d,%d,%d,%d,%d", &bm, &bn, &sk, &st, &ord, &wv);
   if (bm > 0 && bn > 0) {
