@@ -295,6 +295,7 @@ def main():
                          "per_class_ms_per_ddim_step": breakdown,
                          "whole_step_algorithmic": {"tflop": round(step_flops / 1e12, 3), "gbytes": round(step_bytes / 1e9, 2)}},
         }
+        result["config"]["psnr_vs_reference_db"] = psnr_vs_reference(dev)     # reference-generated 10-step fixture (>= 40 dB required)
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(host_sd, ucfg, ccfg, args)
     if dist is not None:
@@ -302,6 +303,37 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+
+
+def psnr_vs_reference(dev):
+    """"PSNR vs ref" half of BASELINE.json's metric, measured live: the reference-generated C1 fixture (tests/golden/
+    c1_loop.npz: 8-frame 64x64 clip, 10 DDIM steps, CFG 8.5, SparseCtrl on, produced by the reference's own classes in fp32)
+    run through the same pipeline code path on the tiny full-topology networks it was recorded with."""
+    import numpy as np
+    from neurons_amd import _lib, DDIMScheduler, NativeSparseCtrl, NativeUNet3D, NeuroclipsPipeline
+    from neurons_amd.sparsectrl import controlnet_config_from_unet
+    from neurons_amd.unet3d import UNet3DConfig, random_state_dict
+    path = os.path.join(ROOT, "tests", "golden", "c1_loop.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    ucfg = UNet3DConfig(sample_size=8, block_out_channels=(64, 64, 128, 128), cross_attention_dim=64)
+    ccfg = controlnet_config_from_unet(ucfg, dict(
+        set_noisy_sample_input_to_zero=True, use_simplified_condition_embedding=True, conditioning_channels=4,
+        motion_module_kwargs=dict(num_attention_heads=8, num_transformer_block=1, attention_block_types=["Temporal_Self"],
+                                  temporal_position_encoding=True, temporal_position_encoding_max_len=32, temporal_attention_dim_div=1)))
+    unet, ctrl = NativeUNet3D(ucfg).to(dev), NativeSparseCtrl(ccfg).to(dev)
+    unet.load_state_dict(random_state_dict(ucfg, _lib.NR_KIND_UNET3D, seed=11))
+    ctrl.load_state_dict(random_state_dict(ccfg, _lib.NR_KIND_SPARSECTRL, seed=12))
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
+    pipe = NeuroclipsPipeline(None, None, None, unet, sched, ctrl).to(dev)
+    out = pipe("", video_length=8, height=64, width=64, num_inference_steps=int(g["steps"]), guidance_scale=float(g["guidance"]),
+               latents=torch.from_numpy(g["latents"]).to(dev), noise=torch.from_numpy(g["noise"]), text_embeddings=torch.from_numpy(g["ctx"]).to(dev),
+               controlnet_images=torch.from_numpy(g["cimg"]).to(dev), controlnet_image_index=[0], low_strength=0.3, output_type="latent").videos
+    want = torch.from_numpy(g["final"])
+    mse = ((out.float().cpu() - want) ** 2).mean().item()
+    rng = (want.max() - want.min()).item()
+    return round(10.0 * float(np.log10(rng * rng / (mse + 1e-20))), 2)
 
 
 def pmc_traffic():
