@@ -225,3 +225,43 @@ def test_ln_gemm_rows_with_large_mean(cuda):
     err = (out.float() - ref).abs().max().item()
     print("large-mean LN-GEMM max err", err, "ref max", ref.abs().max().item())
     assert err <= 3e-2 * ref.abs().max().item(), err
+
+
+@pytest.mark.parametrize("M,N,K,geglu,ln", [(32768, 960, 320, False, False), (32768, 2560, 320, True, True), (8192, 1920, 640, False, True),
+                                            (8192, 5120, 640, True, False), (9000, 1000 // 8 * 8 + 24, 320, False, True), (8192, 960, 64, False, True)])
+def test_short_k_projection_shapes_match_torch(cuda, M, N, K, geglu, ln):
+    """The q|k|v / GEGLU projection shapes of the 32x32 and 16x16 levels (short K, many n-tiles, ragged M and N) against fp32
+    torch, with and without the folded LayerNorm / GEGLU epilogue / residual."""
+    from neurons_amd import ops
+    N = (N // 32) * 32
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g, device="cuda") * 1.5 + 0.3).to(torch.bfloat16)
+    w = torch.randn(N, K, generator=g, device="cuda") * K ** -0.5
+    bias = 0.1 * torch.randn(N, generator=g, device="cuda")
+    gamma = 1.0 + 0.2 * torch.randn(K, generator=g, device="cuda")
+    beta = 0.1 * torch.randn(K, generator=g, device="cuda")
+    x = torch.nn.functional.layer_norm(a.float(), (K,), gamma, beta, 1e-5) if ln else a.float()
+    h = torch.nn.functional.linear(x, w if ln else w.to(torch.bfloat16).float(), bias)
+    if geglu:
+        ref = h[:, :N // 2] * torch.nn.functional.gelu(h[:, N // 2:])
+        if ln:
+            wf = w.float()
+            ws = (wf * gamma[None]).to(torch.bfloat16)
+            c = ws.float().sum(1)
+            b = (wf.double() @ beta.double()).float() + bias
+            wp, _ = ops.geglu_permute(ws, None)
+            cp, bp = ops.geglu_permute(c[:, None], b)
+            out = torch.empty(M, N // 2, dtype=torch.bfloat16, device="cuda")
+            from neurons_amd import _lib
+            _lib.check(_lib.load().nr_op_ln_gemm(torch.cuda.current_stream().cuda_stream, a.data_ptr(), K, wp.data_ptr(), cp.contiguous().data_ptr(),
+                                                 bp.data_ptr(), 1e-5, None, 0, out.data_ptr(), N // 2, M, N, K, 1, 0))
+        else:
+            wp, bp = ops.geglu_permute(w.to(torch.bfloat16), bias)
+            out = ops.gemm(a, wp, bp, None, geglu=True)
+    else:
+        res = torch.randn(M, N, generator=g, device="cuda").to(torch.bfloat16)
+        ref = h + res.float()
+        out = ops.ln_gemm(a, w, gamma, beta, bias, res) if ln else ops.gemm(a, w.to(torch.bfloat16), bias, res)
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 2e-2 * ref.abs().max().item(), err
+    torch.cuda.synchronize()
