@@ -106,6 +106,51 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(NrGnParams p) {
   __syncthreads();
   const int pbeg = chunk * p.pix_per_blk;
   const int pend = min(p.hw, pbeg + p.pix_per_blk);
+  if (CP <= 256) {
+    // thread = (pixel lane, fixed 16-byte channel chunk): scale / shift of its 8 channels live in registers, no integer
+    // division in the streaming loop, four independent loads in flight per thread
+    const int PL = 256 / CP;
+    const int pl = tid / CP, cc = tid - pl * CP;
+    if (pl < PL) {
+      const int c = cc << 3;
+      float a8[8], b8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { a8[e] = sc[c + e]; b8[e] = sh[c + e]; }
+      const bf16* src; int ld;
+      if (c < p.c0) { src = p.x0 + c; ld = p.ld0; } else { src = p.x1 + (c - p.c0); ld = p.ld1; }
+      const size_t img_row = (size_t)img * p.hw;
+      bf16* dst = p.out + c;
+      int px = pbeg + pl;
+      for (; px + 3 * PL < pend; px += 4 * PL) {
+        bf16x8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const bf16x8*)(src + (img_row + px + u * PL) * ld);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float f = (float)v[u][e] * a8[e] + b8[e];
+            if (p.silu) f = silu_f(f);
+            o[e] = (bf16)f;
+          }
+          *(bf16x8*)(dst + (img_row + px + u * PL) * p.ldo) = o;
+        }
+      }
+      for (; px < pend; px += PL) {
+        const bf16x8 v = *(const bf16x8*)(src + (img_row + px) * ld);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float f = (float)v[e] * a8[e] + b8[e];
+          if (p.silu) f = silu_f(f);
+          o[e] = (bf16)f;
+        }
+        *(bf16x8*)(dst + (img_row + px) * p.ldo) = o;
+      }
+    }
+    return;
+  }
   const int total = (pend - pbeg) * CP;
   for (int idx = tid; idx < total; idx += 256) {
     const int px = pbeg + idx / CP;
