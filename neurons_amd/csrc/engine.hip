@@ -716,10 +716,6 @@ struct nr_net {
     const long long M = x.rows();
     bool fuse = !((M >= 8192 && N >= 4 * K) || (M >= 32768 && N >= 3 * K));
     if (mode) fuse = mode[0] == '1';
-    if (const char* sm = getenv("NR_LN_SITES")) {   // debug: bit 0 plain single, 1 stacked qkv, 2 geglu, 3 temporal
-      const int site = temporal_pe ? 3 : (geglu ? 2 : (wkeys.size() > 1 ? 1 : 0));
-      if (!((atoi(sm) >> site) & 1)) fuse = false;
-    }
     GemmOpt o;
     o.geglu = geglu ? 1 : 0; o.act = act;
     if (fuse) {
@@ -1787,8 +1783,6 @@ extern "C" nr_status nr_denoise_step_forward(nr_net* unet, nr_net* ctrl, nr_stre
     bool hit = ctrl->prefetch_valid && !ctrl->ctx_dirty && ctrl->prefetch_io == ic;
     for (int i = 0; hit && i < ctrl->B2; ++i) hit = ctrl->prefetch_t[i] == timesteps[i];
     ctrl->prefetch_valid = false;
-    static const bool dbg = getenv("NR_DEBUG_PREFETCH") != nullptr;
-    if (dbg) fprintf(stderr, "[nr] denoise step t=%g: SparseCtrl prefetch %s\n", timesteps[0], hit ? "hit" : "miss");
     if (!hit) {
       HIP_OK(hipStreamWaitEvent(ctrl->own_stream, unet->ev_in, 0));
       ctrl->set_timesteps(ctrl->own_stream, timesteps);
