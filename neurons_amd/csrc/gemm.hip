@@ -487,6 +487,12 @@ Plan choose_plan(const NrGemmParams& p) {
   else if (nblk(64, 64) >= 256 && nk <= 96) { pl.bm = 64; pl.bn = 64; }
   else if (p.M >= 1024 && nblk(128, 64) >= 64) { pl.bm = 128; pl.bn = 64; }
   else { pl.bm = 64; pl.bn = 64; }
+  // 4x4-level / sgm 16x16-level Linears (M <= 512): fewer blocks than CUs, every k-step waits for cold weights from HBM.
+  // A 4-deep ring (3 tiles in flight) and, where the epilogue allows, 64x32 tiles (twice the blocks) measured -10 % on the
+  // sgm keyframe step (tools/igemm_ab_sgm.sh); deeper rings (6, 8) and split-K + reduce were slower.
+  if (p.ksize == 1 && p.M <= 512 && nk >= 8) {
+    pl.bm = 64; pl.bn = p.geglu ? 64 : 32; pl.waves = 4; pl.stages = 4;
+  }
   if (!p.geglu) {
     const long long tiles = nblk(pl.bm, pl.bn);
     const int cap_m = p.M >= 8192 ? 2 : (p.M >= 2048 ? 4 : 8);      // bounds the fp32 slab traffic (8*M*N*split bytes)
@@ -508,7 +514,7 @@ void launch_cfg(const NrGemmParams& p, unsigned grid, int splitk, float* partial
   // LayerNorm-fused variant: instantiated for the tiles the transformer GEMMs use (nr_launch_igemm maps others onto them).
   // Its row-statistics exchange buffer lives in the DYNAMIC allocation behind the ring: a static __shared__ array next to
   // > 64 KiB of dynamic LDS made the first launch (and any hipGraph node captured from it) run with a short allocation.
-  constexpr bool LN_OK = NS == 2 && BM <= 128 && BN <= 128;
+  constexpr bool LN_OK = (NS == 2 && BM <= 128 && BN <= 128) || (NS == 4 && BM * BN <= 64 * 64);
   if (p.ln_c) {
     if constexpr (LN_OK) {
       const size_t shm_ln = shm + (size_t)2 * WGN * BM * sizeof(float);
@@ -535,7 +541,9 @@ template <int BM, int BN, int WGM, int WGN>
 void launch_tile(const NrGemmParams& p, unsigned grid, const Plan& pl, float* partial, int m_fast, hipStream_t stream) {
   if (pl.stages <= 2) launch_cfg<BM, BN, 2, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);
   else if (pl.stages == 3 || BM * BN > 128 * 64) launch_cfg<BM, BN, 3, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);
-  else launch_cfg<BM, BN, 4, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);   // deep ring: small tiles only
+  else if (pl.stages <= 4 || BM * BN > 64 * 64) launch_cfg<BM, BN, 4, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);   // deep ring: small tiles only
+  else if (pl.stages <= 6) launch_cfg<BM, BN, 6, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);
+  else launch_cfg<BM, BN, 8, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);
 }
 
 // test/tuning override: NR_IGEMM_FORCE="bm,bn,splitk,stages,order" (any field <0 keeps the heuristic's choice)
@@ -550,14 +558,14 @@ void apply_override(const NrGemmParams& p, Plan& pl, int& m_fast) {
   int bm = -1, bn = -1, sk = -1, st = -1, ord = -1, wv = -1;
   sscanf(e, "%d,%d,%d,%d,%d,%d", &bm, &bn, &sk, &st, &ord, &wv);
   if (bm > 0 && bn > 0) {
-    const bool ok = (bm == 128 && (bn == 160 || bn == 128 || bn == 64)) || (bm == 64 && bn == 64) || (bm == 256 && (bn == 128 || bn == 160));
-    if (ok && !(p.geglu && bn == 160)) { pl.bm = bm; pl.bn = bn; }
+    const bool ok = (bm == 128 && (bn == 160 || bn == 128 || bn == 64)) || (bm == 64 && (bn == 64 || bn == 32)) || (bm == 256 && (bn == 128 || bn == 160));
+    if (ok && !(p.geglu && (bn == 160 || bn == 32))) { pl.bm = bm; pl.bn = bn; }
   }
   if (wv == 4 || wv == 8) pl.waves = wv;
   if (pl.bm == 256 && pl.bn == 128 && wv != 4) pl.waves = 8;
   if (pl.bn == 160 || pl.bm == 64) pl.waves = 4;
   if (sk > 0 && !p.geglu) { const int nk = p.K / 64; pl.splitk = sk > nk ? nk : sk; }
-  if (st >= 2 && st <= 4) pl.stages = st;
+  if (st >= 2 && st <= 8) pl.stages = st;
   if (ord >= 0) m_fast = ord;
 }
 
@@ -588,7 +596,8 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
   apply_override(p, pl, m_fast);
   if (p.ln_c) {      // LayerNorm-fused: every block must see the whole row (K = C) -> no split-K; supported tiles only
     if (p.ksize != 1 || p.a1 || p.out_f32) return 8;
-    pl.splitk = 1; pl.stages = 2;
+    pl.splitk = 1;
+    if (!(pl.stages == 4 && pl.bm * pl.bn <= 64 * 64)) pl.stages = 2;
     if (pl.bm > 128) { pl.bm = 128; pl.bn = 128; pl.waves = 8; }
     if (pl.bn > 128) { pl.bn = 128; pl.waves = 8; }
   }
@@ -607,6 +616,7 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
   else if (pl.bm == 128 && pl.bn == 128) launch_tile<128, 128, 2, 2>(p, grid, pl, partial, m_fast, stream);
   else if (pl.bm == 128 && pl.bn == 64 && pl.waves == 8) launch_tile<128, 64, 4, 2>(p, grid, pl, partial, m_fast, stream);
   else if (pl.bm == 128 && pl.bn == 64) launch_tile<128, 64, 2, 2>(p, grid, pl, partial, m_fast, stream);
+  else if (pl.bm == 64 && pl.bn == 32) launch_tile<64, 32, 2, 2>(p, grid, pl, partial, m_fast, stream);
   else launch_tile<64, 64, 2, 2>(p, grid, pl, partial, m_fast, stream);
   if (pl.splitk > 1) {
     const long long total = (long long)p.M * (p.N / 4);
