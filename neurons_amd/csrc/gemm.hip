@@ -490,7 +490,8 @@ Plan choose_plan(const NrGemmParams& p) {
   // 4x4-level / sgm 16x16-level Linears (M <= 512): fewer blocks than CUs, every k-step waits for cold weights from HBM.
   // A 4-deep ring (3 tiles in flight) and, where the epilogue allows, 64x32 tiles (twice the blocks) measured -10 % on the
   // sgm keyframe step (tools/igemm_ab_sgm.sh); deeper rings (6, 8) and split-K + reduce were slower.
-  if (p.ksize == 1 && p.M <= 512 && nk >= 8) {
+  static const bool smallm_rule = !(getenv("NR_IGEMM_SMALLM") && getenv("NR_IGEMM_SMALLM")[0] == '0');   // A/B switch
+  if (smallm_rule && p.ksize == 1 && p.M <= 512 && nk >= 8) {
     pl.bm = 64; pl.bn = p.geglu ? 64 : 32; pl.waves = 4; pl.stages = 4;
   }
   if (!p.geglu) {
@@ -597,6 +598,7 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
   if (p.ln_c) {      // LayerNorm-fused: every block must see the whole row (K = C) -> no split-K; supported tiles only
     if (p.ksize != 1 || p.a1 || p.out_f32) return 8;
     pl.splitk = 1;
+    if (pl.bn == 32) pl.bn = 64;             // every n-tile recomputes the row statistics: keep the n-tiles wide
     if (!(pl.stages == 4 && pl.bm * pl.bn <= 64 * 64)) pl.stages = 2;
     if (pl.bm > 128) { pl.bm = 128; pl.bn = 128; pl.waves = 8; }
     if (pl.bn > 128) { pl.bn = 128; pl.waves = 8; }
