@@ -328,11 +328,13 @@ void launch_ln(const bf16* x, int ldx, bf16* out, int ldo, int M, int C, const f
 
 extern "C" int nr_gn_workspace_floats(int nimg, int hw, int groups, int* pix_per_blk_out, int* nchunk_out) {
   // aim for >= ~16 chunks per image but at least 8 and at most 128 pixels per block (large images: many chunks,
-  // folded by gn_finalize)
+  // folded by gn_finalize); small batches (sgm U-Net: 2 images, VAE keyframe: 1) shrink the chunks until the streaming
+  // kernels have >= 256 blocks
   int ppb = (hw + 15) / 16;
   if (ppb < 8) ppb = 8;
   if (ppb > 128) ppb = 128;
   if (ppb > hw) ppb = hw;
+  while (ppb > 2 && (long long)nimg * ((hw + ppb - 1) / ppb) < 256) ppb = (ppb + 1) / 2;
   const int nchunk = (hw + ppb - 1) / ppb;
   if (pix_per_blk_out) *pix_per_blk_out = ppb;
   if (nchunk_out) *nchunk_out = nchunk;

@@ -35,7 +35,10 @@ def test_tiny_decode_first_stage_matches_reference_golden(cuda):
     rel, psnr = metrics("tiny VAE decode_first_stage vs reference", img, g["image"])
     assert psnr >= 40.0 and rel < 2.5e-2
     assert torch.equal(img, dec.decode_first_stage(z))                        # deterministic (graph replay)
-    assert torch.equal(img[1:], dec.decode_first_stage(z[1:]))                # images are independent
+    # images are independent; a different batch size re-chunks the GroupNorm partial sums (fp32 summation order), so the
+    # comparison is "far inside the parity tolerance", not bitwise
+    _, p1 = metrics("image 1 alone vs in a batch of 2", dec.decode_first_stage(z[1:]), img[1:])
+    assert p1 >= 60.0
 
 
 def test_tiny_decode_latents_matches_reference_golden(cuda):
