@@ -540,9 +540,11 @@ void launch_cfg(const NrGemmParams& p, unsigned grid, int splitk, float* partial
 
 template <int BM, int BN, int WGM, int WGN>
 void launch_tile(const NrGemmParams& p, unsigned grid, const Plan& pl, float* partial, int m_fast, hipStream_t stream) {
+  constexpr size_t STAGE = (size_t)(BM + BN) * 64 * sizeof(bf16);
+  constexpr bool FITS4 = 4 * STAGE <= 160 * 1024;
   if (pl.stages <= 2) launch_cfg<BM, BN, 2, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);
-  else if (pl.stages == 3 || BM * BN > 128 * 64) launch_cfg<BM, BN, 3, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);
-  else if (pl.stages <= 4 || BM * BN > 64 * 64) launch_cfg<BM, BN, 4, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);   // deep ring: small tiles only
+  else if (pl.stages == 3 || !FITS4) launch_cfg<BM, BN, 3, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);
+  else if (pl.stages <= 4 || BM * BN > 64 * 64) launch_cfg<BM, BN, 4, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);   // deep ring
   else if (pl.stages <= 6) launch_cfg<BM, BN, 6, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);
   else launch_cfg<BM, BN, 8, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);
 }
