@@ -290,7 +290,13 @@ def main():
                        "hip_graph": not args.no_graph, "output_finite": finite, "setup_s": round(setup_s, 1)},
             "roofline": {"bound": "mfma", "kernel": "igemm_bf16_kernel (3x3/1x1 conv + Linear)", "achieved": round(achieved, 2),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                         "traffic": pmc_traffic() if (Bc == 1 and F == 16 and L == 32) else None, "launches_per_ddim_step": ig_n, "ms_per_ddim_step": round(ig_ms, 3),
+                         # HBM bytes of the igemm class per DDIM step (GB) from the committed rocprofv3 PMC passes, next to the
+                         # class's algorithmic bytes: traffic >> algorithmic = operand re-reads / split-K slabs
+                         "traffic": (pmc_traffic() or {}).get("igemm_hbm_gbytes_per_ddim_step") if (Bc == 1 and F == 16 and L == 32) else None,
+                         "traffic_unit": "GB per DDIM step (igemm class, PMC FETCH_SIZE x2 + WRITE_SIZE)",
+                         "traffic_detail": pmc_traffic() if (Bc == 1 and F == 16 and L == 32) else None,
+                         "algorithmic_gbytes_per_ddim_step": round((pu["igemm"]["bytes"] + pc["igemm"]["bytes"]) / 1e9, 2),
+                         "launches_per_ddim_step": ig_n, "ms_per_ddim_step": round(ig_ms, 3),
                          "algorithmic_tflop_per_ddim_step": round(ig_fl / 1e12, 3),
                          "per_class_ms_per_ddim_step": breakdown,
                          "whole_step_algorithmic": {"tflop": round(step_flops / 1e12, 3), "gbytes": round(step_bytes / 1e9, 2)}},
