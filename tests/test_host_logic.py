@@ -29,6 +29,29 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
 
 
+def test_ctypes_structs_mirror_the_header():
+    """nr_net_config / nr_profile in include/neurons_amd.h and their ctypes mirrors must agree field by field (name, order,
+    array length); a drift would silently shift every later field across the ABI."""
+    import ctypes as C
+    import re
+    hdr = open(os.path.join(ROOT, "include", "neurons_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    body = re.search(r"typedef struct nr_net_config \{(.*?)\} nr_net_config;", hdr, flags=re.S).group(1)
+    fields = re.findall(r"(int32_t|float)\s+(\w+)(?:\[(\w+)\])?\s*;", body)
+    assert len(fields) == len(_lib.NrNetConfig._fields_) >= 22
+    for (ctype, name, arr), (pname, ptype) in zip(fields, _lib.NrNetConfig._fields_):
+        assert name == pname, (name, pname)
+        base = C.c_float if ctype == "float" else C.c_int32
+        if arr:
+            n = _lib.NR_MAX_LEVELS if arr == "NR_MAX_LEVELS" else int(arr)
+            assert ptype._length_ == n and ptype._type_ is base, name
+        else:
+            assert ptype is base, name
+    for const in ("NR_KIND_UNET3D", "NR_KIND_SPARSECTRL", "NR_KIND_SGM_UNET", "NR_KIND_VAE_DECODER", "NR_KIND_VAE_ENCODER", "NR_KIND_CLIP_TEXT",
+                  "NR_MAX_LEVELS"):
+        assert int(re.search(rf"#define {const} (\d+)", hdr).group(1)) == getattr(_lib, const), const
+
+
 def test_create_fails_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
