@@ -480,6 +480,11 @@ Plan choose_plan(const NrGemmParams& p) {
     pl.bm = 128; pl.bn = 160; pl.splitk = nk >= 300 ? 16 : 8;
     return pl;
   }
+  // same reasoning one level up (8x8 convs, M = 2048, K >= 8192): +1.5 % on the DDIM step over 128x64 tiles with split-K 4
+  if (!p.geglu && p.ksize == 3 && p.M <= 2048 && nk >= 128 && p.N % 160 == 0) {
+    pl.bm = 128; pl.bn = 160; pl.splitk = 4;
+    return pl;
+  }
   const bool n128 = p.N % 128 == 0 || p.N >= 960;          // <= 6 % padded columns otherwise
   if (!p.geglu && p.N % 160 == 0 && p.N < 960 && p.N % 128 != 0 && nk >= 20 && nblk(128, 160) >= 256) { pl.bm = 128; pl.bn = 160; }
   else if (n128 && nblk(128, 128) >= 400) { pl.bm = 128; pl.bn = 128; pl.waves = 8; }
