@@ -159,25 +159,7 @@ def keyframe_main(args):
                      "algorithmic_tflop_per_step": round(sum(v["flops"] for v in p.values()) / 1e12, 3)}}))
 
 
-def gpu_random_state_dict(schema, seed, device):
-    """Seeded weights generated on the GPU (fast for 1.8 G parameters); same scaling rules as
-    neurons_amd.unet3d.random_state_dict."""
-    g = torch.Generator(device=device).manual_seed(seed)
-    sd = {}
-    for name, shape in schema.items():
-        z = torch.randn(shape, generator=g, device=device, dtype=torch.float32)
-        if name.endswith(".bias"):
-            is_norm = ".norm" in name or "norms." in name or "conv_norm_out" in name or "ff_norm" in name
-            z = (0.1 if is_norm else 0.02) * z
-        elif len(shape) == 1:
-            z = 1.0 + 0.1 * z
-        else:
-            fan_in = 1
-            for s in shape[1:]:
-                fan_in *= s
-            z = z / (fan_in ** 0.5)
-        sd[name] = z
-    return sd
+from neurons_amd.synth import gpu_random_state_dict  # noqa: E402
 
 
 def main():

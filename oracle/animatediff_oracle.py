@@ -381,9 +381,11 @@ def add_noise(x, noise, t, alphas_cumprod):
 def neuroclips_denoise(unet_sd: SD, unet_cfg: OracleConfig, ctrl_sd: Optional[SD], ctrl_cfg: Optional[OracleConfig],
                        latents, noise, text_embeddings, controlnet_images, controlnet_image_index=(0,),
                        num_inference_steps=50, guidance_scale=8.5, controlnet_conditioning_scale=1.0,
-                       return_eps_steps: Sequence[int] = ()):
+                       return_eps_steps: Sequence[int] = (), x_log: Optional[dict] = None):
     """NeuroclipsPipeline.__call__ denoising part — pipeline_neuroclips.py:377-489, on explicit latents / noise /
-    text embeddings (uncond first).  ``latents`` are noised to timesteps[0] and all timesteps run."""
+    text embeddings (uncond first).  ``latents`` are noised to timesteps[0] and all timesteps run.
+    Diagnostics: ``return_eps_steps`` -> raw (pre-CFG) eps of those step indices; ``x_log`` (a dict) receives the latents
+    each of those steps started from and, under ``"after"``, the latents after every step."""
     ac = ddim_alphas_cumprod()
     ts = ddim_timesteps(num_inference_steps)
     video_length = latents.shape[2]
@@ -410,8 +412,12 @@ def neuroclips_denoise(unet_sd: SD, unet_cfg: OracleConfig, ctrl_sd: Optional[SD
         eps = unet3d_forward(unet_sd, unet_cfg, xin, t, text_embeddings, down, mid)   # :470-475
         if i in return_eps_steps:
             eps_log[i] = eps
+            if x_log is not None:
+                x_log[i] = x
         if do_cfg:                                                               # :478-480
             eu, et = eps.chunk(2)
             eps = eu + guidance_scale * (et - eu)
         x = ddim_step(eps, t, x, ac, num_inference_steps)                        # :483
+        if x_log is not None:
+            x_log.setdefault("after", []).append(x)
     return x, eps_log

@@ -148,25 +148,9 @@ def reference_classes():
     return UNet3DConditionModel, SparseControlNetModel, ref_attention, ref_mm, ref_resnet
 
 
-# --------------------------------------------------------------------------------------------------
-# shared tiny configuration (also imported by tests/)
-# --------------------------------------------------------------------------------------------------
-def tiny_unet_config():
-    from neurons_amd.unet3d import UNet3DConfig
-    return UNet3DConfig(sample_size=8, block_out_channels=(64, 64, 128, 128), cross_attention_dim=64)
-
-
-def tiny_ctrl_config():
-    from neurons_amd.sparsectrl import controlnet_config_from_unet
-    return controlnet_config_from_unet(tiny_unet_config(), dict(
-        set_noisy_sample_input_to_zero=True, use_simplified_condition_embedding=True, conditioning_channels=4,
-        use_motion_module=True, motion_module_resolutions=[1, 2, 4, 8], motion_module_mid_block=False,
-        motion_module_type="Vanilla",
-        motion_module_kwargs=dict(num_attention_heads=8, num_transformer_block=1, attention_block_types=["Temporal_Self"],
-                                  temporal_position_encoding=True, temporal_position_encoding_max_len=32,
-                                  temporal_attention_dim_div=1)))
-
-
+# shared tiny configurations live in tests/tiny_configs.py (plain configuration, no reference import)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from tiny_configs import tiny_clip_config, tiny_ctrl_config, tiny_sgm_config, tiny_unet_config, tiny_vae_config  # noqa: E402,F401
 def build_reference_unet(cfg, sd):
     UNet3D, _, _, _, _ = reference_classes()
     mm = dict(cfg.motion_module_kwargs)
@@ -376,12 +360,6 @@ def install_sgm_scaffolding():
         _mod("omegaconf", ListConfig=list, OmegaConf=type("OmegaConf", (), {}), DictConfig=dict)
 
 
-def tiny_sgm_config():
-    from neurons_amd.sgm import SGMUNetConfig
-    return SGMUNetConfig(model_channels=64, channel_mult=(1, 2, 4), num_res_blocks=2, attention_resolutions=(4, 2),
-                         num_head_channels=32, transformer_depth=(1, 2, 3), context_dim=128, adm_in_channels=64)
-
-
 def build_reference_sgm(cfg, sd):
     install_sgm_scaffolding()
     from sgm.modules.diffusionmodules.openaimodel import UNetModel
@@ -439,11 +417,6 @@ def gen_sgm(out_dir):
 # it, autoencoder.py:459,490-494; that class itself needs Lightning) and the diffusers<->LDM VAE key map from the
 # reference's convert_ldm_vae_checkpoint
 # --------------------------------------------------------------------------------------------------
-def tiny_vae_config():
-    from neurons_amd.vae import VAEDecoderConfig
-    return VAEDecoderConfig(ch=64, ch_mult=(1, 1, 2, 2), num_res_blocks=2)
-
-
 @torch.no_grad()
 def gen_vae(out_dir):
     from neurons_amd.vae import vae_random_state_dict, diffusers_vae_key_map, VAEDecoderConfig
@@ -539,12 +512,6 @@ def gen_vae(out_dir):
 # CLIP text encoder: the installed transformers CLIPTextModel (the class _encode_prompt calls; the reference pins
 # transformers==4.47.1, this container has a newer release with the same CLIP text arithmetic)
 # --------------------------------------------------------------------------------------------------
-def tiny_clip_config():
-    from neurons_amd.clip import CLIPTextConfig
-    return CLIPTextConfig(vocab_size=1000, hidden_size=128, intermediate_size=512, num_hidden_layers=3, num_attention_heads=4,
-                          max_position_embeddings=77)
-
-
 @torch.no_grad()
 def gen_clip(out_dir):
     for name in [m for m in sys.modules if m == "diffusers" or m.startswith("diffusers.")]:
@@ -666,6 +633,93 @@ def gen_weights(out_dir):
     print("weights.json:", len(ref_map), "mapped keys;", len(changed), "tensors changed by LoRA; map equal to ours:", ref_map == km)
 
 
+# --------------------------------------------------------------------------------------------------
+# a18: the reference's OWN utils.unclip_recon (utils.py:302-350), imported from where it lies and called on a stand-in
+# DiffusionEngine that is wired from the reference's sampler / denoiser / wrapper / UNetModel / Decoder classes
+# (DiffusionEngine itself needs pytorch_lightning; what unclip_recon touches of it is .ema_scope(), .sampler, .denoiser,
+# .model and .decode_first_stage, the last restated from models/diffusion.py:118-135 + autoencoder.py:490-494).
+# The four random draws inside unclip_recon (z, uc tokens, noise, offset) are recorded by replaying the same seed.
+# --------------------------------------------------------------------------------------------------
+def load_ref_utils():
+    """Import /root/reference/utils.py: its module-level imports of torchvision.transforms / webdataset /
+    generative_models.sgm (Lightning) get non-arithmetic stand-ins; unclip_recon itself only uses torch + append_dims."""
+    install_sgm_scaffolding()
+    class _Inert:                       # utils.py builds a torchvision Compose/Resize at import time (:265-267, pixcorr only)
+        def __call__(self, *a, **k):
+            return self
+
+        def __getattr__(self, k):
+            return self
+
+    tv = sys.modules.get("torchvision") or _mod("torchvision")
+    tv.__path__ = []
+    tr = _mod("torchvision.transforms")
+    tr.__getattr__ = lambda k: _Inert()
+    tv.transforms = tr
+    if "webdataset" not in sys.modules:
+        _mod("webdataset")
+    base = f"{REF}/generative_models"
+    for name, path in (("generative_models", base), ("generative_models.sgm", f"{base}/sgm")):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = [path]
+            sys.modules[name] = m
+    return _load_ref_module("ref_utils", f"{REF}/utils.py")
+
+
+@torch.no_grad()
+def gen_unclip(out_dir, num_steps=5, seed=123):
+    import contextlib
+    import warnings
+    from neurons_amd.sgm import sgm_random_state_dict
+    from neurons_amd.vae import vae_random_state_dict
+    from neurons_amd.synth import randn
+    ref_utils = load_ref_utils()
+    from sgm.modules.diffusionmodules.denoiser import DiscreteDenoiser
+    from sgm.modules.diffusionmodules.model import Decoder
+    from sgm.modules.diffusionmodules.sampling import EulerEDMSampler
+    from sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
+    cfg, vcfg = tiny_sgm_config(), tiny_vae_config()
+    net = build_reference_sgm(cfg, sgm_random_state_dict(cfg, seed=71))
+    vsd = vae_random_state_dict(vcfg, seed=91)
+    dec = Decoder(ch=vcfg.ch, out_ch=vcfg.out_ch, ch_mult=vcfg.ch_mult, num_res_blocks=vcfg.num_res_blocks, attn_resolutions=[],
+                  in_channels=3, resolution=64, z_channels=vcfg.z_channels, attn_type="vanilla", double_z=True)
+    dec.load_state_dict({k[len("decoder."):]: v for k, v in vsd.items() if k.startswith("decoder.")}, strict=True)
+    dec.eval()
+    pq = torch.nn.Conv2d(vcfg.embed_dim, vcfg.z_channels, 1)
+    pq.load_state_dict({"weight": vsd["post_quant_conv.weight"], "bias": vsd["post_quant_conv.bias"]})
+    dcfg = {"target": "sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization"}
+    engine = types.SimpleNamespace(
+        ema_scope=contextlib.nullcontext,
+        sampler=EulerEDMSampler(num_steps=num_steps, discretization_config=dcfg, device="cpu",
+                                guider_config={"target": "sgm.modules.diffusionmodules.guiders.VanillaCFG", "params": {"scale": 5.0}}),
+        denoiser=DiscreteDenoiser(scaling_config={"target": "sgm.modules.diffusionmodules.denoiser_scaling.EpsScaling"}, num_idx=1000,
+                                  discretization_config=dcfg),
+        model=OpenAIWrapper(net),
+        decode_first_stage=lambda z: dec(pq(z / 0.18215)))     # diffusion.py:118-135 (scale_factor 0.18215, unclip6.yaml)
+    x = randn("unclip.tokens", (1, 24, cfg.context_dim), 76)              # prior_out[[i]] * mask  (recon_keyframe_neurons_enhance.py:458-462)
+    vector_suffix = randn("unclip.vec", (1, cfg.adm_in_channels), 77)
+    torch.manual_seed(seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                                   # torch.cuda.amp.autocast on a CPU-only build: disabled, fp32
+        samples = ref_utils.unclip_recon(x, engine, vector_suffix, num_samples=1, offset_noise_level=0.04, device="cpu")
+    # replay the draws in the order unclip_recon makes them (utils.py:308, :318, :323, :328-330)
+    torch.manual_seed(seed)
+    z = torch.randn(1, 4, 96, 96)
+    uc_tokens = torch.randn_like(x)
+    noise = torch.randn_like(z)
+    offset = torch.randn(z.shape[0])
+    assert tuple(samples.shape) == (1, 3, 768, 768)
+    st = 4                                                                 # keep every 4th pixel: the fixture stays < 1 MB
+    np.savez_compressed(os.path.join(out_dir, "unclip_tiny.npz"), tokens=x.numpy(), vector_suffix=vector_suffix.numpy(), z=z.numpy(),
+                        uc_tokens=uc_tokens.numpy(), noise=noise.numpy(), offset=offset.numpy(), num_steps=np.array(num_steps),
+                        seed=np.array(seed), stride=np.array(st), samples_sub=samples[:, :, ::st, ::st].numpy().astype(np.float16),
+                        samples_mean=np.array(samples.double().mean().item()), samples_sq=np.array((samples.double() ** 2).mean().item()),
+                        clamped_frac=np.array(((samples == 0) | (samples == 1)).double().mean().item()))
+    print("unclip_tiny: samples", tuple(samples.shape), "mean", samples.mean().item(), "std", samples.std().item(),
+          "clamped frac", ((samples == 0) | (samples == 1)).double().mean().item())
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -678,5 +732,6 @@ if __name__ == "__main__":
     gen_vae(out_dir)
     gen_clip(out_dir)
     gen_weights(out_dir)
+    gen_unclip(out_dir)
     for f in sorted(os.listdir(out_dir)):
         print(f, os.path.getsize(os.path.join(out_dir, f)) // 1024, "KiB")

@@ -162,3 +162,20 @@ def euler_edm_sample(sd: SD, cfg, x, cond, uc, num_steps, scale):
         d = (x - den) / sigma
         x = x + d * (nxt - sigma)
     return x
+
+
+def unclip_recon(sd: SD, cfg, tokens, vector_suffix, z, uc_tokens, noise, offset, num_steps, decode_first_stage,
+                 scale=5.0, offset_noise_level=0.04):
+    """utils.unclip_recon (utils.py:302-350) on explicit draws: ``z`` (:308), ``uc_tokens`` = randn_like(x) (:318),
+    ``noise`` (:323), ``offset`` = randn(n) (:328-330).  ``decode_first_stage`` is the first-stage decode (:343,
+    models/diffusion.py:118-135), e.g. ``lambda z: vae_oracle.decode_first_stage(...)``.  PINNED: the fixture
+    tests/golden/unclip_tiny.npz was produced by calling the reference's own function (oracle/gen_golden.py: gen_unclip)."""
+    n = z.shape[0]
+    c = {"crossattn": tokens.repeat(n, 1, 1), "vector": vector_suffix.repeat(n, 1)}                  # :315
+    uc = {"crossattn": uc_tokens.repeat(n, 1, 1), "vector": vector_suffix.repeat(n, 1)}             # :318-319
+    sigmas = legacy_ddpm_sigmas(num_steps).to(z.device)                                               # :324
+    if offset_noise_level > 0.0:
+        noise = noise + offset_noise_level * offset.reshape(-1, 1, 1, 1)                              # :327-331
+    noised_z = (z + noise * sigmas[0]) / torch.sqrt(1.0 + sigmas[0] ** 2.0)                           # :332-335
+    samples_z = euler_edm_sample(sd, cfg, noised_z, c, uc, num_steps, scale)                          # :340
+    return torch.clamp(decode_first_stage(samples_z) * 0.8 + 0.2, min=0.0, max=1.0)                   # :343-348

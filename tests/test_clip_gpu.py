@@ -18,7 +18,7 @@ from test_engine_gpu import metrics  # noqa: E402
 
 def _tiny():
     from neurons_amd.clip import NativeCLIPTextModel, clip_random_state_dict
-    from oracle.gen_golden import tiny_clip_config
+    from tiny_configs import tiny_clip_config
     cfg = tiny_clip_config()
     sd = clip_random_state_dict(cfg, seed=97)
     enc = NativeCLIPTextModel(cfg).to("cuda")

@@ -13,7 +13,7 @@ GOLD = os.path.join(HERE, "golden", "clip_tiny.npz")
 
 from neurons_amd.clip import CLIPTextConfig, NativeCLIPTextModel, clip_random_state_dict, clip_state_dict_schema  # noqa: E402
 from oracle import clip_oracle as CO  # noqa: E402
-from oracle.gen_golden import tiny_clip_config  # noqa: E402
+from tiny_configs import tiny_clip_config  # noqa: E402
 
 
 @torch.no_grad()

@@ -34,7 +34,7 @@ def metrics(name, got, want):
 def _tiny():
     from neurons_amd import _lib, NativeUNet3D, NativeSparseCtrl
     from neurons_amd.unet3d import random_state_dict
-    from oracle.gen_golden import tiny_ctrl_config, tiny_unet_config
+    from tiny_configs import tiny_ctrl_config, tiny_unet_config
     ucfg, ccfg = tiny_unet_config(), tiny_ctrl_config()
     unet = NativeUNet3D(ucfg).to("cuda")
     unet.load_state_dict(random_state_dict(ucfg, _lib.NR_KIND_UNET3D, seed=11))
@@ -92,7 +92,7 @@ def test_tiny_unet_taps_vs_oracle(cuda):
     from neurons_amd import _lib
     from neurons_amd.unet3d import random_state_dict
     from oracle import animatediff_oracle as O
-    from oracle.gen_golden import tiny_unet_config
+    from tiny_configs import tiny_unet_config
     g = np.load(os.path.join(GOLD, "tiny_networks.npz"))
     ucfg = tiny_unet_config()
     sd = random_state_dict(ucfg, _lib.NR_KIND_UNET3D, seed=11)

@@ -16,7 +16,7 @@ from neurons_amd import _lib  # noqa: E402
 from neurons_amd.synth import randn  # noqa: E402
 from neurons_amd.unet3d import random_state_dict  # noqa: E402
 from oracle import animatediff_oracle as O  # noqa: E402
-from oracle.gen_golden import tiny_ctrl_config, tiny_unet_config  # noqa: E402
+from tiny_configs import tiny_ctrl_config, tiny_unet_config  # noqa: E402
 
 
 def _close(name, got, want, tol=2e-4):

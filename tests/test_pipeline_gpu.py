@@ -49,7 +49,7 @@ def test_c1_loop_to_pixels_with_native_vae(cuda):
     from neurons_amd import DDIMScheduler, NeuroclipsPipeline
     from neurons_amd.vae import NativeVAEDecoder, vae_random_state_dict
     from oracle import vae_oracle as V
-    from oracle.gen_golden import tiny_vae_config
+    from tiny_configs import tiny_vae_config
     g = np.load(os.path.join(GOLD, "c1_loop.npz"))
     unet, ctrl = _tiny()
     vcfg = tiny_vae_config()

@@ -17,7 +17,7 @@ from test_engine_gpu import metrics  # noqa: E402
 
 def _tiny_net():
     from neurons_amd.sgm import NativeSGMUNet, sgm_random_state_dict
-    from oracle.gen_golden import tiny_sgm_config
+    from tiny_configs import tiny_sgm_config
     cfg = tiny_sgm_config()
     net = NativeSGMUNet(cfg).to("cuda")
     net.load_state_dict(sgm_random_state_dict(cfg, seed=71))

@@ -11,7 +11,7 @@ GOLD = os.path.join(HERE, "golden", "sgm_tiny.npz")
 
 from neurons_amd.sgm import DiscreteDenoiser, LegacyDDPMDiscretization, SGMUNetConfig, sgm_random_state_dict, sgm_state_dict_schema  # noqa: E402
 from oracle import sgm_oracle as S  # noqa: E402
-from oracle.gen_golden import tiny_sgm_config  # noqa: E402
+from tiny_configs import tiny_sgm_config  # noqa: E402
 
 
 def _close(name, got, want, tol=2e-4):
@@ -57,3 +57,26 @@ def test_euler_cfg_loop_matches_reference():
 def test_full_size_schema_matches_survey():
     sc = sgm_state_dict_schema(SGMUNetConfig())
     assert abs(sum(int(np.prod(s)) for s in sc.values()) / 1e6 - 2501.3) < 0.1     # 2 501 M parameters
+
+
+@torch.no_grad()
+def test_unclip_recon_harness_matches_reference():
+    """a18: the fixture is the output of the reference's OWN utils.unclip_recon (gen_golden.gen_unclip); the oracle's
+    restatement of the harness (noised_z, offset noise, uc tokens, uc-first CFG, clamp(x*.8+.2)) must reproduce it."""
+    from neurons_amd.vae import vae_random_state_dict
+    from oracle import vae_oracle as V
+    from tiny_configs import tiny_vae_config
+    g = np.load(os.path.join(HERE, "golden", "unclip_tiny.npz"))
+    cfg, vcfg = tiny_sgm_config(), tiny_vae_config()
+    sd = sgm_random_state_dict(cfg, seed=71)
+    vsd = vae_random_state_dict(vcfg, seed=91)
+    t = {k: torch.from_numpy(g[k]) for k in ("tokens", "vector_suffix", "z", "uc_tokens", "noise", "offset")}
+    out = S.unclip_recon(sd, cfg, t["tokens"], t["vector_suffix"], t["z"], t["uc_tokens"], t["noise"], t["offset"], int(g["num_steps"]),
+                         lambda z: V.decode_first_stage(vsd, z, len(vcfg.ch_mult), vcfg.num_res_blocks))
+    assert tuple(out.shape) == (1, 3, 768, 768)
+    st = int(g["stride"])
+    want = torch.from_numpy(g["samples_sub"].astype(np.float32))
+    err = (out[:, :, ::st, ::st] - want).abs().max().item()
+    assert err <= 2e-3, err                                      # fp16 storage of values in [0, 1]: 5e-4, + fp32 reassociation
+    assert abs(out.double().mean().item() - float(g["samples_mean"])) < 1e-4
+    assert abs((out.double() ** 2).mean().item() - float(g["samples_sq"])) < 1e-4

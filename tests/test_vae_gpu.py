@@ -19,7 +19,7 @@ from test_engine_gpu import metrics  # noqa: E402
 
 def _tiny():
     from neurons_amd.vae import NativeVAEDecoder, vae_random_state_dict
-    from oracle.gen_golden import tiny_vae_config
+    from tiny_configs import tiny_vae_config
     cfg = tiny_vae_config()
     sd = vae_random_state_dict(cfg, seed=91)
     dec = NativeVAEDecoder(cfg).to("cuda")
@@ -153,7 +153,7 @@ def test_vae_input_errors(cuda):
 
 def _tiny_enc():
     from neurons_amd.vae import NativeVAEEncoder, vae_random_state_dict
-    from oracle.gen_golden import tiny_vae_config
+    from tiny_configs import tiny_vae_config
     cfg = tiny_vae_config()
     esd = vae_random_state_dict(cfg, seed=94, encoder=True)
     enc = NativeVAEEncoder(cfg).to("cuda")

@@ -15,7 +15,7 @@ GOLD = os.path.join(HERE, "golden", "vae_tiny.npz")
 from neurons_amd.vae import (VAEDecoderConfig, convert_diffusers_vae_state_dict, diffusers_vae_key_map,  # noqa: E402
                              vae_decoder_state_dict_schema, vae_random_state_dict, NativeVAEDecoder)
 from oracle import vae_oracle as V  # noqa: E402
-from oracle.gen_golden import tiny_vae_config  # noqa: E402
+from tiny_configs import tiny_vae_config  # noqa: E402
 
 
 def _close(name, got, want, tol=2e-4):

@@ -14,7 +14,7 @@ from neurons_amd import _lib, NativeUNet3D  # noqa: E402
 from neurons_amd.synth import randn  # noqa: E402
 from neurons_amd.unet3d import UNet3DConfig, random_state_dict, state_dict_schema  # noqa: E402
 from neurons_amd import weights as W  # noqa: E402
-from oracle.gen_golden import tiny_unet_config  # noqa: E402
+from tiny_configs import tiny_unet_config  # noqa: E402
 
 GOLD = json.load(open(os.path.join(HERE, "golden", "weights.json")))
 
@@ -101,7 +101,7 @@ def test_from_pretrained_2d_local_directory(tmp_path):
     from safetensors.torch import save_file
     from neurons_amd import NativeUNet3D
     from neurons_amd.unet3d import random_state_dict, state_dict_schema
-    from oracle.gen_golden import tiny_unet_config
+    from tiny_configs import tiny_unet_config
     cfg = tiny_unet_config()
     sd = random_state_dict(cfg, seed=5)
     sd2d = {k: v.contiguous() for k, v in sd.items() if "motion_modules." not in k}
