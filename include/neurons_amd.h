@@ -251,6 +251,14 @@ nr_status nr_op_gemm(nr_stream stream, const void* a_dev, int32_t lda, const voi
 nr_status nr_op_ln_gemm(nr_stream stream, const void* a_dev, int32_t lda, const void* w_scaled_dev, const float* ln_c_dev,
                         const float* bias_folded_dev, float eps, const void* res_dev, int32_t ldr, void* out_dev, int32_t ldo,
                         int32_t M, int32_t N, int32_t K, int32_t geglu, int32_t act);
+/* every epilogue option of the Linear kernels in one call: folded LayerNorm (ln_c as above, or NULL), fp32 row-vector term
+ * rowvec[((m / rowvec_div) % rowvec_mod) * rowvec_ld + n] (rowvec_mod 0 = no modulo; the time-embedding add of resnet.py:193-194 and
+ * the temporal positional encoding pushed through to_q|k|v, motion_module.py:241-243,274-278), out = (acc + bias + rowvec) * out_scale
+ * [quick_gelu] + res.  K = 320 on >= 4096 rows runs on the register-resident row-panel kernel (rowpanel.hip). */
+nr_status nr_op_gemm_ex(nr_stream stream, const void* a_dev, int32_t lda, const void* w_dev, const float* bias_dev,
+                        const float* ln_c_dev, float ln_eps, const float* rowvec_dev, int32_t rowvec_div, int32_t rowvec_mod,
+                        int32_t rowvec_ld, const void* res_dev, int32_t ldr, void* out_dev, int32_t ldo, int32_t M, int32_t N,
+                        int32_t K, int32_t geglu, int32_t act, float out_scale);
 nr_status nr_op_conv3x3(nr_stream stream, const void* x0_dev, int32_t c0, const void* x1_dev, int32_t c1, int32_t nimg,
                         int32_t H, int32_t W, int32_t stride, int32_t ups, const void* w_dev, const float* bias_dev,
                         const float* rowvec_dev, int32_t rowvec_div, const void* res_dev, void* out_dev, int32_t Cout);

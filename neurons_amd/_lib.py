@@ -90,6 +90,8 @@ SYMBOLS = {
     "nr_net_read_tap": (_I32, [_VP, _I32, _VP, _I64, C.POINTER(_I32), C.POINTER(_I32)]),
     "nr_op_gemm": (_I32, [_VP, _VP, _I32, _VP, _VP, _VP, _I32, _VP, _I32, _I32, _I32, _I32, _I32]),
     "nr_op_ln_gemm": (_I32, [_VP, _VP, _I32, _VP, _VP, _VP, C.c_float, _VP, _I32, _VP, _I32, _I32, _I32, _I32, _I32, _I32]),
+    "nr_op_gemm_ex": (_I32, [_VP, _VP, _I32, _VP, _VP, _VP, C.c_float, _VP, _I32, _I32, _I32, _VP, _I32, _VP, _I32, _I32, _I32, _I32, _I32, _I32,
+                             C.c_float]),
     "nr_op_conv3x3": (_I32, [_VP, _VP, _I32, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _I32, _VP, _VP, _I32]),
     "nr_op_groupnorm": (_I32, [_VP, _VP, _I32, _VP, _I32, _I32, _I32, _I32, _VP, _VP, C.c_float, _I32, _VP, _VP]),
     "nr_op_layernorm": (_I32, [_VP, _VP, _VP, _I32, _I32, _VP, _VP, C.c_float, _VP, _I32, _I32]),

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .unet3d import _NativeNet
+from .unet3d import _on_device, _NativeNet
 
 
 @dataclass
@@ -114,10 +114,10 @@ class NativeCLIPTextModel(_NativeNet):
 
     def _on_plan(self):
         b, f, h, w, L = self._plan_key
-        dev = torch.device("cuda", torch.cuda.current_device())
-        self.device = dev
+        dev = self.device
         self._io_ids = torch.empty(b, w, dtype=torch.int32, device=dev)
 
+    @_on_device
     def forward(self, input_ids, attention_mask=None, **kwargs):
         if attention_mask is not None or kwargs:
             raise NotImplementedError("attention_mask / extra arguments are not built (SD-1.5: attention_mask=None)")

@@ -97,6 +97,21 @@ struct NrGemmParams {
   float* out_f32;      // non-null: write the raw fp32 accumulators to out_f32[M][N] and skip the epilogue (attention scores)
 };
 
+// Row-panel GEMM (rowpanel.hip): out = epilogue(a . w^T), K = 320, the 256-row panel held in registers
+struct NrRowPanelParams {
+  const bf16* a; int lda;            // [M][K]
+  const bf16* w;                     // [N][K] (GEGLU: value/gate-interleaved rows)
+  int M, N;
+  const float* bias;                 // [N] or null
+  const float* ln_c; float ln_eps;   // LayerNorm folded as in NrGemmParams (ln_c null = plain GEMM)
+  const float* rowvec; int rowvec_div, rowvec_mod, rowvec_ld;   // fp32 row-vector term, indexing as NrGemmParams
+  const bf16* res; int ldr;          // residual [M][ldr] or null
+  bf16* out; int ldo;
+  float out_scale; int geglu; int act;
+  int nsplit;                        // workgroups per 256-row panel (each takes a contiguous range of 64-column chunks)
+  int dbg;                           // timing experiments only (NR_RP_DBG): 1 no stores, 2 no DMA after the prologue, 4 no barrier wait
+};
+
 struct NrAttnParams {
   const bf16* q; const bf16* k; const bf16* v; bf16* out;
   // element offset of (batch nb, seq s, head h, dim x):

@@ -715,6 +715,10 @@ struct nr_net {
     // BASELINE config 2 (profiles/README.md): wide GEMMs at the 32x32 / 16x16 levels are faster with the separate LN.
     const long long M = x.rows();
     bool fuse = !((M >= 8192 && N >= 4 * K) || (M >= 32768 && N >= 3 * K));
+    // K = 320 on >= 4096 rows runs on the row-panel kernel (rowpanel.hip): the row statistics come from the register panel once
+    // per workgroup, so the folded LayerNorm is free there
+    static const bool rowpanel_on = !(getenv("NR_ROWPANEL") && getenv("NR_ROWPANEL")[0] == '0');
+    if (rowpanel_on && K == 320 && M >= 4096) fuse = true;
     if (mode) fuse = mode[0] == '1';
     GemmOpt o;
     o.geglu = geglu ? 1 : 0; o.act = act;
@@ -1968,6 +1972,22 @@ extern "C" nr_status nr_op_ln_gemm(nr_stream stream, const void* a, int32_t lda,
   p.w = (const bf16*)w_scaled; p.M = M; p.N = N; p.K = K; p.bias = bias_folded; p.res = (const bf16*)res; p.ldr = ldr;
   p.out = (bf16*)out; p.ldo = ldo; p.out_scale = 1.f; p.geglu = geglu; p.rowvec_div = 1; p.ln_c = ln_c; p.ln_eps = eps; p.act = act;
   LAUNCH_OK(nr_launch_igemm(&p, nullptr, (hipStream_t)stream));
+  NR_CATCH
+}
+
+extern "C" nr_status nr_op_gemm_ex(nr_stream stream, const void* a, int32_t lda, const void* w, const float* bias, const float* ln_c,
+                                   float ln_eps, const float* rowvec, int32_t rowvec_div, int32_t rowvec_mod, int32_t rowvec_ld,
+                                   const void* res, int32_t ldr, void* out, int32_t ldo, int32_t M, int32_t N, int32_t K, int32_t geglu,
+                                   int32_t act, float out_scale) {
+  NR_TRY
+  NrGemmParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.a0 = (const bf16*)a; p.c0 = K; p.lda0 = lda; p.H = p.W = p.OH = p.OW = 1; p.ksize = 1; p.stride = 1;
+  p.w = (const bf16*)w; p.M = M; p.N = N; p.K = K; p.bias = bias; p.res = (const bf16*)res; p.ldr = ldr;
+  p.out = (bf16*)out; p.ldo = ldo; p.out_scale = out_scale; p.geglu = geglu; p.act = act;
+  p.rowvec = rowvec; p.rowvec_div = rowvec_div > 0 ? rowvec_div : 1; p.rowvec_mod = rowvec_mod; p.rowvec_ld = rowvec_ld;
+  p.ln_c = ln_c; p.ln_eps = ln_eps;
+  LAUNCH_OK(nr_launch_igemm(&p, ln_c ? nullptr : op_workspace(p), (hipStream_t)stream));
   NR_CATCH
 }
 

@@ -520,8 +520,19 @@ Plan choose_plan(const NrGemmParams& p) {
   return pl;
 }
 
+// hipFuncSetAttribute is per device: one bit per device ordinal and instantiation
+inline bool attr_needed(unsigned long long& mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (mask & bit) return false;
+  mask |= bit;
+  return true;
+}
+
+// returns 0 on success, 9 when the requested (tile, LayerNorm-fused) combination has no instantiation
 template <int BM, int BN, int NS, int WGM, int WGN>
-void launch_cfg(const NrGemmParams& p, unsigned grid, int splitk, float* partial, int m_fast, hipStream_t stream) {
+int launch_cfg(const NrGemmParams& p, unsigned grid, int splitk, float* partial, int m_fast, hipStream_t stream) {
   const size_t shm = (size_t)NS * (BM + BN) * 64 * sizeof(bf16);
   // LayerNorm-fused variant: instantiated for the tiles the transformer GEMMs use (nr_launch_igemm maps others onto them).
   // Its row-statistics exchange buffer lives in the DYNAMIC allocation behind the ring: a static __shared__ array next to
@@ -530,34 +541,32 @@ void launch_cfg(const NrGemmParams& p, unsigned grid, int splitk, float* partial
   if (p.ln_c) {
     if constexpr (LN_OK) {
       const size_t shm_ln = shm + (size_t)2 * WGN * BM * sizeof(float);
-      static bool attr_ln = false;
-      if (!attr_ln) {
+      static unsigned long long attr_ln = 0;
+      if (attr_needed(attr_ln))
         (void)hipFuncSetAttribute((const void*)igemm_bf16_kernel<BM, BN, NS, WGM, WGN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_ln);
-        attr_ln = true;
-      }
       hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, NS, WGM, WGN, true>), dim3(grid), dim3(64 * WGM * WGN), shm_ln, stream, p, splitk,
                          partial, m_fast);
+      return 0;
     }
-    return;
+    return 9;
   }
-  static bool attr_set = false;
-  if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (gfx950 has 160 KiB per CU)
+  static unsigned long long attr_set = 0;
+  if (attr_needed(attr_set))   // > 64 KiB of dynamic LDS needs the opt-in attribute (gfx950 has 160 KiB per CU), per device
     (void)hipFuncSetAttribute((const void*)igemm_bf16_kernel<BM, BN, NS, WGM, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    attr_set = true;
-  }
   hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, NS, WGM, WGN>), dim3(grid), dim3(64 * WGM * WGN), shm, stream, p, splitk,
                      partial, m_fast);
+  return 0;
 }
 
 template <int BM, int BN, int WGM, int WGN>
-void launch_tile(const NrGemmParams& p, unsigned grid, const Plan& pl, float* partial, int m_fast, hipStream_t stream) {
+int launch_tile(const NrGemmParams& p, unsigned grid, const Plan& pl, float* partial, int m_fast, hipStream_t stream) {
   constexpr size_t STAGE = (size_t)(BM + BN) * 64 * sizeof(bf16);
   constexpr bool FITS4 = 4 * STAGE <= 160 * 1024;
-  if (pl.stages <= 2) launch_cfg<BM, BN, 2, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);
-  else if (pl.stages == 3 || !FITS4) launch_cfg<BM, BN, 3, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);
-  else if (pl.stages <= 4 || BM * BN > 64 * 64) launch_cfg<BM, BN, 4, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);   // deep ring
-  else if (pl.stages <= 6) launch_cfg<BM, BN, 6, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);
-  else launch_cfg<BM, BN, 8, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);
+  if (pl.stages <= 2) return launch_cfg<BM, BN, 2, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);
+  if (pl.stages == 3 || !FITS4) return launch_cfg<BM, BN, 3, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);
+  if (pl.stages <= 4 || BM * BN > 64 * 64) return launch_cfg<BM, BN, 4, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);   // deep ring
+  if (pl.stages <= 6) return launch_cfg<BM, BN, 6, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);
+  return launch_cfg<BM, BN, 8, WGM, WGN>(p, grid, pl.splitk, partial, m_fast, stream);
 }
 
 // test/tuning override: NR_IGEMM_FORCE="bm,bn,splitk,stages,order" (any field <0 keeps the heuristic's choice)
@@ -587,9 +596,13 @@ void apply_override(const NrGemmParams& p, Plan& pl, int& m_fast) {
 
 }  // namespace
 
+extern "C" int nr_rowpanel_eligible(const NrGemmParams* pp);
+extern "C" int nr_launch_rowpanel(const NrGemmParams* pp, hipStream_t stream);
+
 // fp32 scratch (bytes) a launch of this shape needs for split-K slabs (0 if none)
 extern "C" size_t nr_igemm_workspace_bytes(const NrGemmParams* pp) {
   if (pp->out_f32 || pp->ln_c) return 0;
+  if (nr_rowpanel_eligible(pp)) return 0;
   Plan pl = choose_plan(*pp);
   int mf = 0;
   apply_override(*pp, pl, mf);
@@ -601,6 +614,8 @@ extern "C" size_t nr_igemm_workspace_bytes(const NrGemmParams* pp) {
 extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStream_t stream) {
   const NrGemmParams& p = *pp;
   const int Cin = p.c0 + p.c1;
+  // K = 320 Linears on >= 4096 rows: the register-resident row-panel kernel (rowpanel.hip)
+  if (p.K == p.ksize * p.ksize * Cin && nr_rowpanel_eligible(pp)) return nr_launch_rowpanel(pp, stream);
   if (p.K % 64 != 0 || Cin % 64 != 0 || p.N % 32 != 0) return 1;
   if (p.a1 && (p.c0 % 64 != 0)) return 2;
   if (p.K != p.ksize * p.ksize * Cin) return 3;
@@ -625,16 +640,18 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
   if (pl.splitk > 1 && !workspace) return 6;
   float* partial = p.out_f32 ? p.out_f32 : (pl.splitk > 1 ? workspace : nullptr);
   const unsigned grid = (unsigned)(((p.M + pl.bm - 1) / pl.bm) * ((p.N + pl.bn - 1) / pl.bn) * pl.splitk);
-  if (pl.bm == 256 && pl.bn == 160) launch_tile<256, 160, 2, 2>(p, grid, pl, partial, m_fast, stream);
-  else if (pl.bm == 256 && pl.waves == 4) launch_tile<256, 128, 2, 2>(p, grid, pl, partial, m_fast, stream);
-  else if (pl.bm == 256) launch_tile<256, 128, 4, 2>(p, grid, pl, partial, m_fast, stream);
-  else if (pl.bm == 128 && pl.bn == 160) launch_tile<128, 160, 2, 2>(p, grid, pl, partial, m_fast, stream);
-  else if (pl.bm == 128 && pl.bn == 128 && pl.waves == 8) launch_tile<128, 128, 2, 4>(p, grid, pl, partial, m_fast, stream);
-  else if (pl.bm == 128 && pl.bn == 128) launch_tile<128, 128, 2, 2>(p, grid, pl, partial, m_fast, stream);
-  else if (pl.bm == 128 && pl.bn == 64 && pl.waves == 8) launch_tile<128, 64, 4, 2>(p, grid, pl, partial, m_fast, stream);
-  else if (pl.bm == 128 && pl.bn == 64) launch_tile<128, 64, 2, 2>(p, grid, pl, partial, m_fast, stream);
-  else if (pl.bm == 64 && pl.bn == 32) launch_tile<64, 32, 2, 2>(p, grid, pl, partial, m_fast, stream);
-  else launch_tile<64, 64, 2, 2>(p, grid, pl, partial, m_fast, stream);
+  int rc;
+  if (pl.bm == 256 && pl.bn == 160) rc = launch_tile<256, 160, 2, 2>(p, grid, pl, partial, m_fast, stream);
+  else if (pl.bm == 256 && pl.waves == 4) rc = launch_tile<256, 128, 2, 2>(p, grid, pl, partial, m_fast, stream);
+  else if (pl.bm == 256) rc = launch_tile<256, 128, 4, 2>(p, grid, pl, partial, m_fast, stream);
+  else if (pl.bm == 128 && pl.bn == 160) rc = launch_tile<128, 160, 2, 2>(p, grid, pl, partial, m_fast, stream);
+  else if (pl.bm == 128 && pl.bn == 128 && pl.waves == 8) rc = launch_tile<128, 128, 2, 4>(p, grid, pl, partial, m_fast, stream);
+  else if (pl.bm == 128 && pl.bn == 128) rc = launch_tile<128, 128, 2, 2>(p, grid, pl, partial, m_fast, stream);
+  else if (pl.bm == 128 && pl.bn == 64 && pl.waves == 8) rc = launch_tile<128, 64, 4, 2>(p, grid, pl, partial, m_fast, stream);
+  else if (pl.bm == 128 && pl.bn == 64) rc = launch_tile<128, 64, 2, 2>(p, grid, pl, partial, m_fast, stream);
+  else if (pl.bm == 64 && pl.bn == 32) rc = launch_tile<64, 32, 2, 2>(p, grid, pl, partial, m_fast, stream);
+  else rc = launch_tile<64, 64, 2, 2>(p, grid, pl, partial, m_fast, stream);
+  if (rc) return rc;      // no instantiation for this (tile, LayerNorm-fused) request: fail loudly, never skip the launch
   if (pl.splitk > 1) {
     const long long total = (long long)p.M * (p.N / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p, pl.splitk,

@@ -62,6 +62,34 @@ def ln_gemm(a, w, gamma, beta, bias=None, res=None, eps=1e-5, act=0):
     return out
 
 
+def gemm_ex(a, w, bias=None, ln=None, eps=1e-5, rowvec=None, rowvec_div=1, rowvec_mod=0, res=None, act=0, out_scale=1.0):
+    """out = (Linear([LayerNorm](a)) + rowvec[(m // rowvec_div) % rowvec_mod]) * out_scale [quick_gelu] + res.  ``ln`` = (gamma, beta)
+    folds the LayerNorm into the weights on the host exactly as engine.hip's w_ln_linear does; ``w`` is fp32 or bf16 [N, K]."""
+    _chk_bf16(a, res)
+    _chk_f32(rowvec)
+    M, K = a.shape
+    N = w.shape[0]
+    wf = w.float()
+    ln_c = None
+    b = None if bias is None else bias.float().contiguous()
+    if ln is not None:
+        gamma, beta = ln
+        ws = (wf * gamma.float()[None]).to(torch.bfloat16).contiguous()
+        ln_c = ws.float().sum(dim=1).contiguous()
+        b = (wf.double() @ beta.double()).float()
+        if bias is not None:
+            b = b + bias.float()
+        b = b.contiguous()
+    else:
+        ws = w.to(torch.bfloat16).contiguous()
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    lib = _lib.load()
+    _lib.check(lib.nr_op_gemm_ex(_stream(), _ptr(a), K, _ptr(ws), _ptr(b), _ptr(ln_c), float(eps), _ptr(rowvec), int(rowvec_div),
+                                 int(rowvec_mod), 0 if rowvec is None else rowvec.shape[1], _ptr(res), N, _ptr(out), N, M, N, K, 0, int(act),
+                                 float(out_scale)))
+    return out
+
+
 def geglu_permute(w, b):
     """Reorder a GEGLU projection (rows [value(inner) | gate(inner)]) into 16-value/16-gate interleave."""
     inner = w.shape[0] // 2

@@ -275,10 +275,11 @@ class NeuroclipsPipeline:
                         self.controlnet, latent_model_input, t, text_embeddings, controlnet_cond,
                         controlnet_conditioning_mask, controlnet_conditioning_scale, next_timestep=t_next).sample
                 elif use_ctrl:
+                    zc = {"zero_copy": True} if hasattr(self.controlnet, "_out_bufs") else {}    # consumed before the next call
                     down_res, mid_res = self.controlnet(
                         latent_model_input, t, encoder_hidden_states=text_embeddings, controlnet_cond=controlnet_cond,
                         conditioning_mask=controlnet_conditioning_mask, conditioning_scale=controlnet_conditioning_scale,
-                        guess_mode=False, return_dict=False)
+                        guess_mode=False, return_dict=False, **zc)
                 if not fused:
                     noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=text_embeddings,
                                            down_block_additional_residuals=down_res,

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .unet3d import _NativeNet, _ff_keys
+from .unet3d import _on_device, _NativeNet, _ff_keys
 
 
 @dataclass
@@ -178,13 +178,13 @@ class NativeSGMUNet(_NativeNet):
 
     def _on_plan(self):
         b, f, h, w, L = self._plan_key
-        dev = torch.device("cuda", torch.cuda.current_device())
-        self.device = dev
+        dev = self.device
         self._io_x = torch.empty(b, self.config.in_channels, h, w, dtype=torch.float32, device=dev)
         self._io_ctx = torch.empty(b, L, self.config.context_dim, dtype=torch.float32, device=dev)
         self._io_y = torch.empty(b, self.config.adm_in_channels, dtype=torch.float32, device=dev)
         self._io_out = torch.empty(b, self.config.out_channels, h, w, dtype=torch.float32, device=dev)
 
+    @_on_device
     def forward(self, x, timesteps=None, context=None, y=None, in_scale: float = 1.0, **kwargs):
         if kwargs:
             raise NotImplementedError(f"unsupported arguments {sorted(kwargs)}")

@@ -12,7 +12,7 @@ from typing import List, Optional
 import torch
 
 from . import _lib
-from .unet3d import UNet3DConfig, _NativeNet
+from .unet3d import _on_device, UNet3DConfig, _NativeNet
 
 
 @dataclass
@@ -58,8 +58,7 @@ class NativeSparseCtrl(_NativeNet):
 
     def _on_plan(self):
         b, f, h, w, L = self._plan_key
-        dev = torch.device("cuda", torch.cuda.current_device())
-        self.device = dev
+        dev = self.device
         lib = _lib.load()
         n = int(lib.nr_net_num_residuals(self._h))
         bufs = []
@@ -73,9 +72,14 @@ class NativeSparseCtrl(_NativeNet):
         self._io_sample = torch.empty(b, self.config.in_channels, f, h, w, dtype=torch.float32, device=dev)
         self._io_cond = None
 
+    @_on_device
     def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_mask=None,
                 conditioning_scale: float = 1.0, class_labels=None, attention_mask=None, cross_attention_kwargs=None,
-                guess_mode: bool = False, return_dict: bool = True):
+                guess_mode: bool = False, return_dict: bool = True, zero_copy: bool = False):
+        """``SparseControlNetModel.forward`` (sparse_controlnet.py:450-581).  Like the reference it returns FRESH tensors: the
+        residuals are cloned out of the engine's persistent output buffers, which the next forward on this handle overwrites.
+        ``zero_copy=True`` (used by the pipeline, which consumes the residuals before the next call) returns strided views of
+        those buffers instead: valid only until the next forward."""
         if class_labels is not None or attention_mask is not None:
             raise NotImplementedError("class_labels / attention_mask are not used on the NEURONS path")
         if guess_mode:
@@ -117,7 +121,7 @@ class NativeSparseCtrl(_NativeNet):
                                              self._io_cond.data_ptr(), self._io_mask.data_ptr(), cb,
                                              float(conditioning_scale), self._out_ptrs, self._out_bufs[n].data_ptr()))
         # logical (b, C, f, h, w) views over the channels-last buffers
-        views = [t.permute(0, 4, 1, 2, 3) for t in self._out_bufs]
+        views = [(t if zero_copy else t.clone()).permute(0, 4, 1, 2, 3) for t in self._out_bufs]
         down, mid = views[:n], views[n]
         if not return_dict:
             return (down, mid)

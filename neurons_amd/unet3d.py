@@ -250,6 +250,41 @@ def random_state_dict(cfg: UNet3DConfig, kind: int = _lib.NR_KIND_UNET3D, seed: 
     return sd
 
 
+def _tensors_in(args, kwargs):
+    for a in list(args) + list(kwargs.values()):
+        if torch.is_tensor(a):
+            yield a
+        elif isinstance(a, (list, tuple)):
+            for b in a:
+                if torch.is_tensor(b):
+                    yield b
+        elif isinstance(a, dict):
+            for b in a.values():
+                if torch.is_tensor(b):
+                    yield b
+
+
+def _on_device(fn):
+    """Run a forward-like method with the handle's GPU current.  ``nr_net_create`` / ``hipMalloc`` / the plan arena and every
+    kernel launch use the CURRENT HIP device, so a network moved with ``.to('cuda:1')`` must never run while device 0 is current;
+    tensors living on another GPU are rejected instead of being handed to a kernel that cannot address them."""
+    import functools
+
+    @functools.wraps(fn)
+    def inner(self, *args, **kwargs):
+        cuda = [t for t in _tensors_in(args, kwargs) if t.is_cuda]
+        if self.device.type != "cuda":
+            if not cuda:
+                return fn(self, *args, **kwargs)      # the method raises its own "CUDA tensors required" error
+            self.device = cuda[0].device                 # never moved explicitly: adopt the first input's GPU (handle not created yet)
+        for t in cuda:
+            if t.device != self.device:
+                raise RuntimeError(f"{type(self).__name__} lives on {self.device} but got a tensor on {t.device}")
+        with torch.cuda.device(self.device):
+            return fn(self, *args, **kwargs)
+    return inner
+
+
 class _NativeNet:
     """Shared handle management for the two networks."""
     _kind = _lib.NR_KIND_UNET3D
@@ -283,9 +318,14 @@ class _NativeNet:
     # -- module-like surface ---------------------------------------------------------------------------
     def to(self, device=None, dtype=None):
         if device is not None:
-            self.device = torch.device(device)
-            if self.device.type != "cuda":
+            dev = torch.device(device)
+            if dev.type != "cuda":
                 raise RuntimeError("neurons_amd networks run on MI355X only (device must be 'cuda'); there is no CPU fallback")
+            if dev.index is None:
+                dev = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+            if self._h is not None and dev != self.device:
+                raise RuntimeError(f"{type(self).__name__} already holds weights on {self.device}; create a new instance for {dev}")
+            self.device = dev
         return self
 
     def cuda(self, device=None):
@@ -310,9 +350,12 @@ class _NativeNet:
         if self._h is None:
             if not torch.cuda.is_available():
                 raise RuntimeError("neurons_amd: no HIP device visible; the networks run in libneurons_amd.so on MI355X only")
+            if self.device.type != "cuda":
+                self.device = torch.device("cuda", torch.cuda.current_device())
             lib = _lib.load()
             h = C.c_void_p()
-            _lib.check(lib.nr_net_create(C.byref(self._cconf), C.byref(h)))
+            with torch.cuda.device(self.device):       # the handle is bound to the device that is current at creation
+                _lib.check(lib.nr_net_create(C.byref(self._cconf), C.byref(h)))
             self._h = h
             _lib.check(lib.nr_net_set_graph(self._h, 1 if self._graph else 0))
         return self._h
@@ -368,6 +411,7 @@ class _NativeNet:
             self._ctx_key, self._ctx_plan = key, self._plan_key
             self._ctx_ref = ctx     # keep it alive: its address cannot be recycled for different contents while cached
 
+    @_on_device
     def profile_last(self):
         """Per-kernel-class time / algorithmic work of the most recent forward (HIP events per launch)."""
         prof = _lib.NrProfile()
@@ -461,6 +505,7 @@ class NativeUNet3D(_NativeNet):
         print(f"### Motion Module Parameters: {sum(params) / 1e6} M")
         return model
 
+    @_on_device
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, attention_mask=None,
                 down_block_additional_residuals: Optional[Sequence[torch.Tensor]] = None,
                 mid_block_additional_residual: Optional[torch.Tensor] = None, return_dict: bool = True):
@@ -507,6 +552,7 @@ class NativeUNet3D(_NativeNet):
 
     __call__ = forward
 
+    @_on_device
     def forward_with_controlnet(self, controlnet, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_mask,
                                 conditioning_scale: float = 1.0, next_timestep=None):
         """``controlnet(...)`` then ``self(..., down_block_additional_residuals=..., mid_block_additional_residual=...)``
@@ -524,6 +570,9 @@ class NativeUNet3D(_NativeNet):
         if b % cb != 0 or conditioning_mask.shape[0] != cb:
             raise ValueError("controlnet_cond batch must divide the sample batch")
         L = ctx.shape[1]
+        if controlnet.device.type == "cuda" and controlnet.device != self.device:
+            raise RuntimeError(f"U-Net on {self.device} but SparseCtrl on {controlnet.device}")
+        controlnet.to(self.device)
         self._ensure_plan(b, f, h, w, L)
         controlnet._ensure_plan(b, f, h, w, L)
         self._io_sample.copy_(sample)
@@ -554,8 +603,7 @@ class NativeUNet3D(_NativeNet):
 
     def _on_plan(self):
         b, f, h, w, L = self._plan_key
-        dev = torch.device("cuda", torch.cuda.current_device())
-        self.device = dev
+        dev = self.device
         self._io_sample = torch.empty(b, self.config.in_channels, f, h, w, dtype=torch.float32, device=dev)
         self._io_ctx = torch.empty(b, L, self.config.cross_attention_dim, dtype=torch.float32, device=dev)
         self._io_out = torch.empty(b, self.config.out_channels, f, h, w, dtype=torch.float32, device=dev)

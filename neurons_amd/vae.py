@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .unet3d import _NativeNet
+from .unet3d import _on_device, _NativeNet
 
 
 @dataclass
@@ -214,12 +214,12 @@ class NativeVAEDecoder(_NativeNet):
 
     def _on_plan(self):
         b, f, h, w, L = self._plan_key
-        dev = torch.device("cuda", torch.cuda.current_device())
-        self.device = dev
+        dev = self.device
         up = 2 ** (len(self.config.ch_mult) - 1)
         self._io_z = torch.empty(b, self.config.z_channels, h, w, dtype=torch.float32, device=dev)
         self._out_shape = (self.config.out_ch, h * up, w * up)
 
+    @_on_device
     def decode(self, z, z_scale: float = 1.0, unit_range: bool = False, chunk: int = None, post=None):
         """z [n][4][h][w] (any float dtype, on the GPU) -> fp32 [n][3][8h][8w].  ``z_scale`` multiplies the latent
         first (1 / scale_factor); ``post=(mul, add)`` fuses ``clamp(x * mul + add, 0, 1)`` into the last kernel
@@ -320,10 +320,10 @@ class NativeVAEEncoder(_NativeNet):
 
     def _on_plan(self):
         b, f, h, w, L = self._plan_key
-        dev = torch.device("cuda", torch.cuda.current_device())
-        self.device = dev
+        dev = self.device
         self._io_x = torch.empty(b, 3, h, w, dtype=torch.float32, device=dev)
 
+    @_on_device
     def moments(self, x, in_mul: float = 1.0, in_add: float = 0.0):
         """x [n][3][h][w] on the GPU -> fp32 (mean | logvar) [n][2z][h/8][w/8]; the network sees x * in_mul + in_add."""
         if not x.is_cuda:
@@ -377,7 +377,7 @@ class NativeAutoencoderKL:
         self.encoder.to(device)
         self.decoder.to(device)
         if device is not None:
-            self.device = torch.device(device)
+            self.device = self.decoder.device
         return self
 
     def eval(self):
@@ -398,6 +398,11 @@ class NativeAutoencoderKL:
         if strict and (missing or unexpected):
             raise RuntimeError(f"Error(s) in loading state_dict for NativeAutoencoderKL: missing {missing[:6]} unexpected {unexpected[:6]}")
         return missing, unexpected
+
+    def load_ldm_state_dict(self, sd, strict=True):
+        """First-stage tensors of an LDM / DreamBooth checkpoint (``first_stage_model.`` prefix already stripped): the native
+        engines use these names as they are, so no key conversion is needed (reference: convert_ldm_vae_checkpoint, util.py:138)."""
+        return self.load_state_dict(sd, strict=strict)
 
     def encode(self, x):
         return _EncodeOutput(self.encoder.encode(x))

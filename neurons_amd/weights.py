@@ -150,12 +150,40 @@ def apply_deltas(net, deltas: Dict[str, torch.Tensor]):
         net._pending[k] = net._pending[k].float() + d.reshape(net._pending[k].shape)
 
 
+def te_lora_deltas(lora_sd: Dict[str, torch.Tensor], te_schema, alpha: float = 0.6, prefix: str = "lora_te") -> Dict[str, torch.Tensor]:
+    """The text-encoder half of ``convert_lora`` (:50-112): ``lora_te_text_model_encoder_layers_0_self_attn_q_proj.lora_down.weight``
+    -> delta for ``text_model.encoder.layers.0.self_attn.q_proj.weight``.  ``te_schema``: the encoder's parameter names."""
+    under = {k[:-len(".weight")].replace(".", "_"): k for k in te_schema if k.endswith(".weight")}
+    deltas, seen = {}, set()
+    for key in lora_sd:
+        if ".alpha" in key or key in seen or "text" not in key:
+            continue
+        name = key.split(".")[0].split(prefix + "_")[-1]
+        if name not in under:
+            raise KeyError(f"LoRA layer {key} has no counterpart in the text encoder")
+        up_key, down_key = key.replace("lora_down", "lora_up"), key.replace("lora_up", "lora_down")
+        d = alpha * torch.mm(lora_sd[up_key].float(), lora_sd[down_key].float())
+        target = under[name]
+        deltas[target] = deltas[target] + d if target in deltas else d
+        seen.update((up_key, down_key))
+    return deltas
+
+
+def _is_native(obj) -> bool:
+    return hasattr(obj, "_pending") and hasattr(obj, "_schema")
+
+
 def load_weights(animation_pipeline, motion_module_path="", motion_module_lora_configs=(), adapter_lora_path="",
                  adapter_lora_scale=1.0, dreambooth_model_path="", lora_model_path="", lora_alpha=0.8,
                  vae_converter=None, text_encoder_converter=None):
-    """Drop-in for ``animatediff.utils.util.load_weights`` with a native ``pipeline.unet``.  VAE / CLIP conversion of a
-    DreamBooth checkpoint stays with the caller's PyTorch modules: pass the reference's ``convert_ldm_vae_checkpoint`` /
-    ``convert_ldm_clip_checkpoint`` as ``vae_converter`` / ``text_encoder_converter`` to keep that behaviour."""
+    """Drop-in for ``animatediff.utils.util.load_weights`` (util.py:92-185) with a native ``pipeline.unet``.
+
+    DreamBooth checkpoint (:125-144): the reference ALWAYS replaces VAE, U-Net and text encoder.  Here: a native VAE
+    (``NativeAutoencoderKL``) takes its ``first_stage_model.*`` tensors directly (it uses the LDM key names), a native CLIP
+    (``NativeCLIPTextModel``) its ``cond_stage_model.transformer.*`` tensors; for PyTorch modules pass the reference's
+    ``convert_ldm_vae_checkpoint`` / ``convert_ldm_clip_checkpoint`` as ``vae_converter`` / ``text_encoder_converter``.  With
+    neither, this raises instead of silently keeping the base VAE / text encoder (the videos would differ from the
+    reference's).  Kohya LoRA (:147-160): the ``lora_te_*`` deltas are merged into the text encoder as ``convert_lora`` does."""
     unet = animation_pipeline.unet
     if motion_module_path != "":
         sd = filter_motion_module(torch.load(motion_module_path, map_location="cpu"))
@@ -170,16 +198,44 @@ def load_weights(animation_pipeline, motion_module_path="", motion_module_lora_c
                     ckpt[key] = f.get_tensor(key)
         else:
             ckpt = torch.load(dreambooth_model_path, map_location="cpu")
+        vae = getattr(animation_pipeline, "vae", None)
+        te = getattr(animation_pipeline, "text_encoder", None)
+        # 1. vae
         if vae_converter is not None:
-            animation_pipeline.vae.load_state_dict(vae_converter(ckpt, animation_pipeline.vae.config))
+            vae.load_state_dict(vae_converter(ckpt, vae.config))
+        elif vae is not None and hasattr(vae, "load_ldm_state_dict"):
+            vae.load_ldm_state_dict({k[len("first_stage_model."):]: v for k, v in ckpt.items() if k.startswith("first_stage_model.")})
+        elif vae is not None:
+            raise ValueError("load_weights(dreambooth_model_path=...): the reference also replaces the VAE (util.py:137-139); pass "
+                             "vae_converter=convert_ldm_vae_checkpoint for a PyTorch VAE, or use NativeAutoencoderKL")
+        # 2. unet
         unet.load_state_dict(convert_ldm_unet_checkpoint(ckpt, unet.config), strict=False)
+        # 3. text_model
         if text_encoder_converter is not None:
             animation_pipeline.text_encoder = text_encoder_converter(ckpt)
+        elif te is not None and _is_native(te):
+            pre = "cond_stage_model.transformer."
+            te.load_state_dict({k[len(pre):]: v for k, v in ckpt.items() if k.startswith(pre)})
+        elif te is not None:
+            raise ValueError("load_weights(dreambooth_model_path=...): the reference also replaces the text encoder (util.py:143-144); "
+                             "pass text_encoder_converter=convert_ldm_clip_checkpoint for a PyTorch CLIP, or use NativeCLIPTextModel")
     if lora_model_path != "":
         assert lora_model_path.endswith(".safetensors")
         from safetensors.torch import load_file
-        deltas, _ = kohya_lora_deltas(load_file(lora_model_path), unet.config, alpha=lora_alpha)
+        lsd = load_file(lora_model_path)
+        deltas, te_keys = kohya_lora_deltas(lsd, unet.config, alpha=lora_alpha)
         apply_deltas(unet, deltas)
+        if te_keys:
+            te = getattr(animation_pipeline, "text_encoder", None)
+            if te is not None and _is_native(te):
+                apply_deltas(te, te_lora_deltas(lsd, te._schema, alpha=lora_alpha))
+            elif isinstance(te, torch.nn.Module):
+                params = dict(te.named_parameters())
+                for k, d in te_lora_deltas(lsd, [n for n in params], alpha=lora_alpha).items():
+                    params[k].data += d.to(params[k].device, params[k].dtype)
+            else:
+                raise ValueError(f"the LoRA carries {len(te_keys)} text-encoder tensors (lora_te_*) but the pipeline has no text encoder "
+                                 "to merge them into (convert_lora merges them, :66-68)")
     if adapter_lora_path != "":
         sd = torch.load(adapter_lora_path, map_location="cpu")
         sd = sd["state_dict"] if "state_dict" in sd else sd

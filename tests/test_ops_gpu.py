@@ -265,3 +265,29 @@ def test_short_k_projection_shapes_match_torch(cuda, M, N, K, geglu, ln):
     err = (out.float() - ref).abs().max().item()
     assert err <= 2e-2 * ref.abs().max().item(), err
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M,N,K", [(32768, 960, 320), (4096 + 80, 320, 320), (2048, 1920, 640), (640, 960, 320)])
+def test_gemm_ex_temporal_pe_rowvec_scale_act(cuda, M, N, K):
+    """The temporal q|k|v projection as the engine issues it: LayerNorm folded into the GEMM and the positional encoding pushed
+    through the projection as an fp32 row vector selected by the row's frame, (m // hw) % F (motion_module.py:241-243,274-278),
+    plus the out_scale / quick_gelu epilogue options.  K = 320 with >= 4096 rows runs on the row-panel kernel (rowpanel.hip),
+    the other shapes on the tiled igemm: both against fp32 torch."""
+    from neurons_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    F_, hw = 16, 8
+    a = (torch.randn(M, K, generator=g, device="cuda") * 1.3 - 0.4).to(torch.bfloat16)
+    w = torch.randn(N, K, generator=g, device="cuda") * K ** -0.5
+    gamma = 1.0 + 0.2 * torch.randn(K, generator=g, device="cuda")
+    beta = 0.1 * torch.randn(K, generator=g, device="cuda")
+    pe = torch.randn(F_, K, generator=g, device="cuda")
+    rv = (pe.double() @ w.double().t()).float().contiguous()           # engine: pe_projection
+    out = ops.gemm_ex(a, w, None, ln=(gamma, beta), rowvec=rv, rowvec_div=hw, rowvec_mod=F_)
+    fidx = (torch.arange(M, device="cuda") // hw) % F_
+    ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(a.float(), (K,), gamma, beta, 1e-5) + pe[fidx], w)
+    _cmp(f"ln+pe gemm {M}x{N}x{K}", out, ref)
+    bias = 0.1 * torch.randn(N, generator=g, device="cuda")
+    res = torch.randn(M, N, generator=g, device="cuda").to(torch.bfloat16)
+    out2 = ops.gemm_ex(a, w, bias, res=res, act=1, out_scale=0.5)
+    h = (a.float() @ w.to(torch.bfloat16).float().t() + bias) * 0.5
+    _cmp(f"scale+quick_gelu+res gemm {M}x{N}x{K}", out2, h * torch.sigmoid(1.702 * h) + res.float())

@@ -129,3 +129,51 @@ def test_from_pretrained_2d_local_directory(tmp_path):
         json.dump(conf, f)
     with pytest.raises(NotImplementedError, match="dual_cross_attention"):
         NativeUNet3D.from_pretrained_2d(os.path.join(tmp_path, "sd"), subfolder="unet", unet_additional_kwargs=extra)
+
+
+def test_load_weights_merges_text_encoder_lora_and_refuses_silent_dreambooth_skips(tmp_path):
+    """the reference's convert_lora merges the lora_te_* deltas into pipeline.text_encoder (:66-68,99-107) and its
+    DreamBooth branch always replaces VAE and text encoder (util.py:137-144).  load_weights must do the same or fail loudly."""
+    import types
+    from safetensors.torch import save_file
+    from neurons_amd.clip import NativeCLIPTextModel, clip_random_state_dict
+    from tiny_configs import tiny_clip_config, tiny_unet_config
+    cfg, ccfg = tiny_unet_config(), tiny_clip_config()
+    sd = random_state_dict(cfg, _lib.NR_KIND_UNET3D, seed=11)
+    tsd = clip_random_state_dict(ccfg, seed=97)
+    unet = NativeUNet3D(cfg)
+    unet.load_state_dict(sd)
+    te = NativeCLIPTextModel(ccfg)
+    te.load_state_dict(tsd)
+    H = ccfg.hidden_size
+    name = "lora_te_text_model_encoder_layers_1_self_attn_q_proj"
+    g = torch.Generator().manual_seed(3)
+    lora = {name + ".lora_down.weight": torch.randn(4, H, generator=g), name + ".lora_up.weight": torch.randn(H, 4, generator=g),
+            name + ".alpha": torch.tensor(4.0)}
+    path = os.path.join(tmp_path, "l.safetensors")
+    save_file(lora, path)
+    pipe = types.SimpleNamespace(unet=unet, text_encoder=te, vae=None)
+    W.load_weights(pipe, lora_model_path=path, lora_alpha=0.8)
+    key = "text_model.encoder.layers.1.self_attn.q_proj.weight"
+    want = tsd[key] + 0.8 * lora[name + ".lora_up.weight"] @ lora[name + ".lora_down.weight"]
+    assert torch.allclose(te._pending[key].float(), want, atol=1e-6)
+    # a torch text encoder gets the same in-place merge as the reference performs
+    lin = torch.nn.Module()
+    lin.text_model = torch.nn.Module(); lin.text_model.encoder = torch.nn.Module(); lin.text_model.encoder.layers = torch.nn.ModuleList(
+        [torch.nn.Module(), torch.nn.Module()])
+    lin.text_model.encoder.layers[1].self_attn = torch.nn.Module()
+    lin.text_model.encoder.layers[1].self_attn.q_proj = torch.nn.Linear(H, H, bias=False)
+    w0 = lin.text_model.encoder.layers[1].self_attn.q_proj.weight.detach().clone()
+    unet2 = NativeUNet3D(cfg)
+    unet2.load_state_dict(sd)
+    W.load_weights(types.SimpleNamespace(unet=unet2, text_encoder=lin, vae=None), lora_model_path=path, lora_alpha=0.8)
+    assert torch.allclose(lin.text_model.encoder.layers[1].self_attn.q_proj.weight, w0 + (want - tsd[key]), atol=1e-6)
+    with pytest.raises(ValueError, match="text-encoder tensors"):
+        unet3 = NativeUNet3D(cfg)
+        unet3.load_state_dict(sd)
+        W.load_weights(types.SimpleNamespace(unet=unet3, text_encoder=None, vae=None), lora_model_path=path)
+    # DreamBooth: a PyTorch VAE without vae_converter must not be skipped silently
+    ck = os.path.join(tmp_path, "db.safetensors")
+    save_file({"model.diffusion_model.dummy": torch.zeros(1)}, ck)
+    with pytest.raises(ValueError, match="replaces the VAE"):
+        W.load_weights(types.SimpleNamespace(unet=unet, text_encoder=te, vae=torch.nn.Identity()), dreambooth_model_path=ck)
