@@ -185,6 +185,11 @@ struct IO {
   bool operator==(const IO& o) const { return std::memcmp(this, &o, sizeof(IO)) == 0; }
 };
 
+__global__ void copy16_kernel(const uint4* __restrict__ a, uint4* __restrict__ b, long long n16) {   // debug snapshots only
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n16) b[i] = a[i];
+}
+
 struct TimestepVals { float v[16]; };
 __global__ void set_timesteps_kernel(float* dst, TimestepVals tv, int n) {
   if (threadIdx.x < n) dst[threadIdx.x] = tv.v[threadIdx.x];
@@ -520,6 +525,11 @@ struct nr_net {
   void tap(const std::string& name, const Act& a) {
     if (!dry && keep_all) taps.push_back(Tap{name, a.ptr, a.rows(), a.C, a.ld});
   }
+  // debug only (NR_OP_TAPS=1 with nr_net_set_debug): one tap per kernel output, named by plan position and kernel class
+  void op_tap(const char* kind, const Act& a) {
+    static const bool on = getenv("NR_OP_TAPS") != nullptr;
+    if (on && !dry && keep_all && !building_ctx) taps.push_back(Tap{"op" + std::to_string(ops.size()) + "." + kind, a.ptr, a.rows(), a.C, a.ld});
+  }
 
   struct GemmOpt {
     const float* bias = nullptr;
@@ -569,6 +579,7 @@ struct nr_net {
       std::shared_ptr<Buf> wsbuf;
       if (wsb) { wsbuf = new_tmp(wsb); ws = at<float>(wsbuf->off); }
       emit([p, ws](hipStream_t s) { LAUNCH_OK(nr_launch_igemm(&p, ws, s)); }, NR_PROF_IGEMM, 2.0 * p.M * (double)p.N * p.K, bytes, d);
+      op_tap(ksize == 3 ? "conv3" : (p.ln_c ? "lngemm" : "gemm"), out);
     }
     return out;
   }
@@ -588,9 +599,21 @@ struct nr_net {
     p.partial = at<float>(ws->off);
     Act out = new_act(x0.nimg, x0.H, x0.W, C);
     p.out = out.ptr; p.ldo = out.ld;
+    if (getenv("NR_OP_TAPS") && keep_all && !x1) {     // debug: what the GroupNorm's input looked like when it ran
+      Act snap = new_act(x0.nimg, x0.H, x0.W, x0.C);
+      const bf16* src = x0.ptr; bf16* dst = snap.ptr; const size_t nb = (size_t)x0.rows() * x0.C * sizeof(bf16);
+      if (x0.ld == x0.C) {
+        emit([=](hipStream_t s) {
+          const long long n16 = (long long)(nb / 16);
+          hipLaunchKernelGGL(copy16_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, n16);
+        });
+        op_tap("gn_input_snapshot", snap);
+      }
+    }
     emit([p](hipStream_t s) { NrGnParams q = p; LAUNCH_OK(nr_launch_groupnorm(&q, s)); }, NR_PROF_GROUPNORM,
          8.0 * (double)x0.rows() * C, 2.0 * 2.0 * (double)x0.rows() * C,
          "groupnorm nimg=" + std::to_string(x0.nimg) + " hw=" + std::to_string(x0.H * x0.W) + " C=" + std::to_string(C));
+    op_tap("gn", out);
     return out;
   }
 
@@ -603,6 +626,7 @@ struct nr_net {
     emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_layernorm(xp, ldx, op, ldo, M, C, g, b, 1e-5f, pe, hw, pe_F, s)); },
          NR_PROF_LAYERNORM, 8.0 * (double)M * C, 2.0 * 2.0 * (double)M * C,
          "layernorm M=" + std::to_string(M) + " C=" + std::to_string(C));
+    op_tap("ln", out);
     return out;
   }
 
@@ -641,6 +665,7 @@ struct nr_net {
       char d[160];
       snprintf(d, sizeof(d), "attention mode=%d nbatch=%d heads=%d d=%d Lq=%d Lk=%d", mode, p.nbatch, p.heads, p.d, p.Lq, p.Lk);
       emit([p](hipStream_t s) { LAUNCH_OK(nr_launch_attention(&p, s)); }, NR_PROF_ATTENTION, flops, bytes, d);
+      op_tap(mode == 2 ? "tattn" : (mode == 1 ? "xattn" : "sattn"), out);
     }
     return out;
   }
@@ -1787,21 +1812,27 @@ extern "C" nr_status nr_denoise_step_forward(nr_net* unet, nr_net* ctrl, nr_stre
     bool hit = ctrl->prefetch_valid && !ctrl->ctx_dirty && ctrl->prefetch_io == ic;
     for (int i = 0; hit && i < ctrl->B2; ++i) hit = ctrl->prefetch_t[i] == timesteps[i];
     ctrl->prefetch_valid = false;
+    static const int dbg_mode = getenv("NR_OVERLAP_DBG") ? atoi(getenv("NR_OVERLAP_DBG")) : 0;   // 1: eager launches on the two streams; 2: graphs, serialised
     if (!hit) {
       HIP_OK(hipStreamWaitEvent(ctrl->own_stream, unet->ev_in, 0));
       ctrl->set_timesteps(ctrl->own_stream, timesteps);
       ctrl->run_context(ctrl->own_stream);
-      for (int seg = 0; seg < 3; ++seg) ctrl->launch_segment(ctrl->own_stream, seg);
+      if (dbg_mode == 1) { for (auto& op : ctrl->ops) op(ctrl->own_stream); }
+      else for (int seg = 0; seg < 3; ++seg) ctrl->launch_segment(ctrl->own_stream, seg);
       HIP_OK(hipEventRecord(ctrl->ev_out, ctrl->own_stream));
     }
+    if (dbg_mode == 2) HIP_OK(hipStreamWaitEvent(unet->own_stream, ctrl->ev_out, 0));
     // ... concurrently with the U-Net's encoder + mid block; the residual adds wait for SparseCtrl
     unet->set_timesteps(unet->own_stream, timesteps);
     unet->run_context(unet->own_stream);
-    unet->launch_segment(unet->own_stream, 0);
+    if (dbg_mode == 1) { for (size_t i = 0; i < unet->split_op; ++i) unet->ops[i](unet->own_stream); }
+    else unet->launch_segment(unet->own_stream, 0);
     HIP_OK(hipStreamWaitEvent(unet->own_stream, ctrl->ev_out, 0));
-    unet->launch_segment(unet->own_stream, 1);
+    if (dbg_mode == 1) { for (size_t i = unet->split_op; i < unet->split_op2; ++i) unet->ops[i](unet->own_stream); }
+    else unet->launch_segment(unet->own_stream, 1);
     HIP_OK(hipEventRecord(unet->ev_adds, unet->own_stream));
-    unet->launch_segment(unet->own_stream, 2);
+    if (dbg_mode == 1) { for (size_t i = unet->split_op2; i < unet->ops.size(); ++i) unet->ops[i](unet->own_stream); }
+    else unet->launch_segment(unet->own_stream, 2);
     HIP_OK(hipEventRecord(unet->ev_out, unet->own_stream));
     HIP_OK(hipStreamWaitEvent(caller, unet->ev_out, 0));
     if (next_timesteps) {

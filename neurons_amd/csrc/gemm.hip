@@ -31,8 +31,19 @@ __device__ __attribute__((aligned(16))) const unsigned int nr_zero16[4] = {0u, 0
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// LDS-DMA as inline asm, hidden from the compiler: a BUILTIN global_load_lds is a pending LDS write to hipcc, which then places
+// s_waitcnt vmcnt(0) in front of the next ds_read that may alias it, i.e. behind every barrier of the main loop, so a ring deeper
+// than two stages never actually has more than one tile in flight.  With the asm form only the counted wait + barrier of the main
+// loop order the DMA against the fragment reads (cdna_hip_programming.md 5.7); M0 is written and restored in the same statement.
 __device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
+#ifdef NR_GLDS_BUILTIN
   __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+  return;
+#endif
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lptr_t)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
@@ -204,7 +215,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     // tile kt must have landed; the younger (NS-2) tiles may stay outstanding (vmcnt counts in issue order)
     if (kt + (NS - 2) < kt_end) wait_vmcnt<(NS - 2) * G>(); else wait_vmcnt<0>();
+#ifdef NR_GLDS_SYNC
+    __syncthreads();
+#else
     __builtin_amdgcn_s_barrier();            // everyone's pieces of tile kt landed; everyone left tile kt-1
+#endif
     const bf16* sA = smem + cur * TILE;
     const bf16* sB = sA + BM * BK;
     // fragment reads of k-step 0 go out FIRST, so their LDS latency is covered by the staging code below
@@ -225,6 +240,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
       const int nxt = kt + NS - 1;           // refill the buffer tile kt-1 occupied
       int nb = cur + NS - 1; if (nb >= NS) nb -= NS;
       if (nxt < kt_end) stage(nb);
+#ifdef NR_GLDS_POSTWAIT
+      wait_vmcnt<0>();
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

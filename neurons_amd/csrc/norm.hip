@@ -12,6 +12,7 @@
 // scale+shift held in LDS, streams the pixels).  Both accept a channel-concat of two sources so the
 // up-block skip concat (unet_blocks.py:634,740) is never materialised for the norm.
 #include "common.h"
+#include <cstdlib>
 
 
 namespace {
@@ -66,14 +67,20 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(NrGnParams p) {
   }
 }
 
-// grid (nchunk, nimg), block 256.  dynamic LDS: 2*C floats
+// grid (nchunk, nimg), block 256.  dynamic LDS: 2*C + 128 floats.
+// ALL LDS of this kernel is dynamic.  With a static __shared__ array next to the dynamic region, hipGraph-captured launches were
+// observed to get a workgroup LDS allocation that is short by the static part: the tail of `sh` then overlaps the LDS of whatever
+// workgroup the CU places behind it.  Harmless while the network's launches run one after another, but with SparseCtrl and the
+// U-Net encoder overlapped on two streams it gave run-to-run different results (2-3 % of the elements of a GroupNorm output, first
+// seen at down_blocks.0.resnets.0; tools/race_taps.py).  Same rule as gemm.hip's LayerNorm exchange buffer.
 __global__ __launch_bounds__(256) void gn_apply_kernel(NrGnParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int C = p.c0 + p.c1;
   const int CP = C >> 3;
   float* sc = lds;       // [C] scale
   float* sh = lds + C;   // [C] shift
-  __shared__ float gmean[64], grstd[64];
+  float* gmean = lds + 2 * C;        // [64]
+  float* grstd = lds + 2 * C + 64;   // [64]
   const int img = blockIdx.y, chunk = blockIdx.x;
   const int tid = threadIdx.x;
   const int cg = C / p.groups;
@@ -202,6 +209,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(NrGnParams p) {
 template <int MAXP>
 __global__ __launch_bounds__(256) void gn_fused_small_kernel(NrGnParams p) {
   __shared__ float red[2][4];
+  if (p.finalized == 77) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // experiment: drop this CU's L1 lines first
   const int C = p.c0 + p.c1;
   const int cg = C / p.groups;
   const int hp = cg >> 1;                       // bf16 pairs per pixel of this group
@@ -350,8 +358,11 @@ extern "C" int nr_launch_groupnorm(NrGnParams* pp, hipStream_t stream) {
     // small images: single fused launch (needs an even channels-per-group and an even split point of the concat)
     const int cg = C / p.groups;
     const long long pairs = (long long)p.hw * (cg / 2);
-    if (p.hw <= 64 && cg % 2 == 0 && p.c0 % 2 == 0 && pairs <= 256LL * 48) {
+    static const bool nofuse = getenv("NR_GN_NOFUSE") != nullptr;
+    if (!nofuse && p.hw <= 64 && cg % 2 == 0 && p.c0 % 2 == 0 && pairs <= 256LL * 48) {
       dim3 grid(p.groups, p.nimg);
+      static const bool acq = getenv("NR_GN_DBG") != nullptr;
+      if (acq) p.finalized = 77;
       if (pairs <= 256LL * 8) hipLaunchKernelGGL((gn_fused_small_kernel<8>), grid, dim3(256), 0, stream, p);
       else if (pairs <= 256LL * 16) hipLaunchKernelGGL((gn_fused_small_kernel<16>), grid, dim3(256), 0, stream, p);
       else hipLaunchKernelGGL((gn_fused_small_kernel<48>), grid, dim3(256), 0, stream, p);
@@ -362,7 +373,7 @@ extern "C" int nr_launch_groupnorm(NrGnParams* pp, hipStream_t stream) {
   const int CP = C / 8;
   const int PL = CP <= 256 ? 256 / CP : 1;
   const size_t shm_stats = (size_t)2 * PL * C * sizeof(float);
-  const size_t shm_apply = (size_t)2 * C * sizeof(float);
+  const size_t shm_apply = (size_t)(2 * C + 128) * sizeof(float);
   if (shm_stats > 60000 || shm_apply > 60000) return 3;
   dim3 grid(p.nchunk, p.nimg);
   p.finalized = p.nchunk > 16 ? 1 : 0;

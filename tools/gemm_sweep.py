@@ -25,6 +25,9 @@ CONFIGS = ["-1,-1,-1,2,-1,4", "128,128,1,2,-1,4", "128,128,1,2,-1,8", "128,64,1,
            "128,128,2,2,-1,8", "128,64,2,2,-1,4", "128,64,4,2,-1,4", "128,64,2,2,-1,8", "128,64,4,2,-1,8",
            "64,64,2,2,-1,4", "64,64,4,2,-1,4", "64,64,8,2,-1,4", "256,128,2,2,-1,8", "256,128,4,2,-1,8"]
 
+CONFIGS += ["128,128,1,4,-1,8", "128,64,1,4,-1,8", "128,64,1,4,-1,4", "64,64,1,4,-1,4", "256,128,1,3,-1,8", "128,160,1,3,-1,4", "128,128,1,3,-1,4",
+            "128,64,2,3,-1,8", "128,64,4,3,-1,8", "64,64,4,3,-1,4", "64,64,2,4,-1,4", "64,64,4,4,-1,4", "128,64,2,4,-1,4", "128,64,4,4,-1,4",
+            "256,128,2,3,-1,8", "128,160,2,3,-1,4", "128,160,4,3,-1,4", "128,160,8,3,-1,4", "128,160,4,2,-1,4", "128,160,8,2,-1,4"]
 if os.environ.get("SWEEP_CONFIGS"):      # e.g. SWEEP_CONFIGS="256,128,1,2,-1,4;256,160,1,2,-1,4"
     CONFIGS = ["-1,-1,-1,2,-1,4"] + os.environ["SWEEP_CONFIGS"].split(";")
 if os.environ.get("SWEEP_EXTRA"):        # extra shapes for the VAE: "conv:16,128,128,256,256,0;lin:8192,640,2560,1"
