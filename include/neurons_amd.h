@@ -234,6 +234,20 @@ typedef struct nr_profile {
  * launch, and reports per-kernel-class totals (bench.py's roofline object). */
 nr_status nr_net_profile_last(nr_net* h, nr_stream stream, nr_profile* out);
 
+/* ---- converted-weight exchange between handles (multi-GPU start-up) -----------------
+ * The reference shards clips over processes and every process loads the checkpoints itself (scripts/neuroclips_video.py:
+ * 94-138,238).  Here rank 0 loads + converts once (nr_net_load_tensor, nr_net_plan) and the converted bf16/fp32 device
+ * buffers travel as ONE packed arena, device to device (RCCL broadcast over xGMI); the receivers never see fp32 host weights.
+ *   nr_net_export_manifest  text description (state-dict key shapes + name/offset/bytes of every converted buffer); returns its
+ *                           length (call with buf = NULL to size), arena_bytes receives the packed size
+ *   nr_net_export_weights   packs the converted buffers into dst_dev (>= arena_bytes) on `stream`
+ *   nr_net_import_weights   fresh handle (nothing loaded): adopts the arena; a following nr_net_plan with the SAME shape as the
+ *                           exporter's finds every converted buffer and needs no host data */
+int64_t nr_net_export_manifest(nr_net* h, char* buf, int64_t capacity, int64_t* arena_bytes);
+nr_status nr_net_export_weights(nr_net* h, nr_stream stream, void* dst_dev, int64_t capacity);
+nr_status nr_net_import_weights(nr_net* h, nr_stream stream, const char* manifest, int64_t manifest_bytes, const void* src_dev,
+                                int64_t arena_bytes);
+
 /* ---- debug / test hooks (activation taps by reference module name) --------------------------- */
 nr_status nr_net_set_debug(nr_net* h, int32_t keep_all_activations);
 int32_t nr_net_num_taps(const nr_net* h);

@@ -201,7 +201,12 @@ struct nr_net {
   nr_net_config cfg;
   std::map<std::string, HostTensor> host;
   std::map<std::string, void*> dev;  // converted weights by derived name
+  std::map<std::string, size_t> dev_bytes;
   size_t weight_bytes = 0;
+  // converted weights received from another handle (nr_net_import_weights): ONE device allocation, dev[] points into it
+  char* import_base = nullptr;
+  size_t import_bytes = 0;
+  int device = -1;                   // HIP device the handle was created on
 
   // plan
   int B2 = 0, F = 0, H = 0, W = 0, ctx_len = 0;
@@ -253,7 +258,8 @@ struct nr_net {
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
 
   ~nr_net() {
-    for (auto& kv : dev) if (kv.second) (void)hipFree(kv.second);
+    for (auto& kv : dev) if (kv.second && !in_import(kv.second)) (void)hipFree(kv.second);
+    if (import_base) (void)hipFree(import_base);
     if (arena_base) (void)hipFree(arena_base);
     for (auto& g : gexec) if (g) (void)hipGraphExecDestroy(g);
     if (ev_in) (void)hipEventDestroy(ev_in);
@@ -261,6 +267,8 @@ struct nr_net {
     if (ev_adds) (void)hipEventDestroy(ev_adds);
     if (own_stream) (void)hipStreamDestroy(own_stream);
   }
+
+  bool in_import(const void* p) const { return import_base && (const char*)p >= import_base && (const char*)p < import_base + import_bytes; }
 
   // ------------------------------------------------------------------ weights
   const HostTensor& need(const std::string& key) const {
@@ -282,6 +290,7 @@ struct nr_net {
     HIP_OK(hipMalloc(&d, bytes));
     HIP_OK(hipMemcpy(d, data, bytes, hipMemcpyHostToDevice));
     dev[name] = d;
+    dev_bytes[name] = bytes;
     weight_bytes += bytes;
     return d;
   }
@@ -1622,6 +1631,7 @@ extern "C" nr_status nr_net_create(const nr_net_config* cfg, nr_net** out) {
     if (hipGetDevice(&dev) != hipSuccess) throw NrError(NR_ERR_HIP, "no HIP device available: libneurons_amd requires an MI355X (gfx950) GPU");
     nr_net* h = new nr_net();
     h->cfg = *cfg;
+    h->device = dev;
     *out = h;
     return NR_OK;
   }
@@ -1644,6 +1654,7 @@ extern "C" nr_status nr_net_create(const nr_net_config* cfg, nr_net** out) {
   if (hipGetDevice(&dev) != hipSuccess) throw NrError(NR_ERR_HIP, "no HIP device available: libneurons_amd requires an MI355X (gfx950) GPU");
   nr_net* h = new nr_net();
   h->cfg = *cfg;
+  h->device = dev;
   *out = h;
   NR_CATCH
 }
@@ -1662,7 +1673,8 @@ extern "C" nr_status nr_net_load_tensor(nr_net* h, const char* key, const float*
   for (auto it = h->dev.begin(); it != h->dev.end();) {
     if (it->first.find(key) != std::string::npos || it->first.rfind("temb", 0) == 0) {
       (void)hipDeviceSynchronize();
-      (void)hipFree(it->second);
+      if (!h->in_import(it->second)) (void)hipFree(it->second);
+      h->dev_bytes.erase(it->first);
       it = h->dev.erase(it);
       h->planned = false;
     } else ++it;
@@ -1670,10 +1682,108 @@ extern "C" nr_status nr_net_load_tensor(nr_net* h, const char* key, const float*
   NR_CATCH
 }
 
+// every entry point that allocates or launches runs on the CURRENT HIP device: it must be the one the handle was created on
+static void check_device(const nr_net* h) {
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != h->device)
+    throw NrError(NR_ERR_STATE, "handle was created on HIP device " + std::to_string(h->device) + " but device " + std::to_string(cur) +
+                                    " is current (hipSetDevice / torch.cuda.device before calling)");
+}
+
 extern "C" nr_status nr_net_plan(nr_net* h, int32_t batch, int32_t frames, int32_t lat_h, int32_t lat_w, int32_t ctx_len) {
   NR_TRY
   if (!h) throw NrError(NR_ERR_ARG, "null handle");
+  check_device(h);
   h->plan(batch, frames, lat_h, lat_w, ctx_len);
+  NR_CATCH
+}
+
+// ---- converted-weight exchange between handles (rank 0 converts once, the bf16 arena travels device to device) ----
+// Manifest: text, one record per line.  "H <state-dict key> <ndim> <dims...>" for every loaded tensor (shapes only),
+// "D <converted name> <offset> <bytes>" for every converted device buffer, offsets 256-byte aligned in name order.
+static std::string build_manifest(const nr_net* h, size_t* total) {
+  std::string m = "NRW1 " + std::to_string(h->cfg.kind) + "\n";
+  for (auto& kv : h->host) {
+    m += "H " + kv.first + " " + std::to_string(kv.second.shape.size());
+    for (auto d : kv.second.shape) m += " " + std::to_string(d);
+    m += "\n";
+  }
+  size_t off = 0;
+  for (auto& kv : h->dev) {
+    const size_t b = h->dev_bytes.at(kv.first);
+    m += "D " + kv.first + " " + std::to_string(off) + " " + std::to_string(b) + "\n";
+    off += (b + 255) & ~(size_t)255;
+  }
+  if (total) *total = off;
+  return m;
+}
+
+extern "C" int64_t nr_net_export_manifest(nr_net* h, char* buf, int64_t capacity, int64_t* arena_bytes) {
+  if (!h || !h->planned) { set_err("nr_net_export_manifest: plan first (the converted buffers are created by nr_net_plan)"); return -1; }
+  size_t total = 0;
+  const std::string m = build_manifest(h, &total);
+  if (arena_bytes) *arena_bytes = (int64_t)total;
+  if (buf && capacity >= (int64_t)m.size()) std::memcpy(buf, m.data(), m.size());
+  return (int64_t)m.size();
+}
+
+extern "C" nr_status nr_net_export_weights(nr_net* h, nr_stream stream, void* dst_dev, int64_t capacity) {
+  NR_TRY
+  if (!h || !dst_dev) throw NrError(NR_ERR_ARG, "null argument");
+  if (!h->planned) throw NrError(NR_ERR_STATE, "plan first");
+  check_device(h);
+  size_t total = 0;
+  (void)build_manifest(h, &total);
+  if ((size_t)capacity < total) throw NrError(NR_ERR_ARG, "export buffer too small");
+  size_t off = 0;
+  for (auto& kv : h->dev) {
+    const size_t b = h->dev_bytes.at(kv.first);
+    HIP_OK(hipMemcpyAsync((char*)dst_dev + off, kv.second, b, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    off += (b + 255) & ~(size_t)255;
+  }
+  NR_CATCH
+}
+
+extern "C" nr_status nr_net_import_weights(nr_net* h, nr_stream stream, const char* manifest, int64_t manifest_bytes, const void* src_dev,
+                                           int64_t arena_bytes) {
+  NR_TRY
+  if (!h || !manifest || !src_dev) throw NrError(NR_ERR_ARG, "null argument");
+  check_device(h);
+  if (!h->dev.empty() || !h->host.empty()) throw NrError(NR_ERR_STATE, "import into a fresh handle (no tensors loaded, not planned)");
+  const std::string m(manifest, (size_t)manifest_bytes);
+  size_t pos = 0;
+  auto next_line = [&](std::string& line) {
+    if (pos >= m.size()) return false;
+    const size_t e = m.find('\n', pos);
+    line = m.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
+    pos = e == std::string::npos ? m.size() : e + 1;
+    return true;
+  };
+  std::string line;
+  if (!next_line(line) || line.rfind("NRW1 ", 0) != 0) throw NrError(NR_ERR_ARG, "bad manifest header");
+  if (std::atoi(line.c_str() + 5) != h->cfg.kind) throw NrError(NR_ERR_ARG, "manifest is for a different network kind");
+  HIP_OK(hipMalloc((void**)&h->import_base, (size_t)arena_bytes));
+  h->import_bytes = (size_t)arena_bytes;
+  HIP_OK(hipMemcpyAsync(h->import_base, src_dev, (size_t)arena_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  while (next_line(line)) {
+    if (line.size() < 3) continue;
+    std::vector<std::string> tok;
+    size_t a = 0;
+    while (a < line.size()) { size_t b = line.find(' ', a); if (b == std::string::npos) b = line.size(); tok.push_back(line.substr(a, b - a)); a = b + 1; }
+    if (tok[0] == "H" && tok.size() >= 3) {
+      HostTensor t;                                   // shape only: the data never exists on this rank
+      const int nd = std::atoi(tok[2].c_str());
+      for (int i = 0; i < nd && 3 + i < (int)tok.size(); ++i) t.shape.push_back(std::atoll(tok[3 + i].c_str()));
+      h->host[tok[1]] = std::move(t);
+    } else if (tok[0] == "D" && tok.size() == 4) {
+      const size_t off = (size_t)std::atoll(tok[2].c_str()), b = (size_t)std::atoll(tok[3].c_str());
+      if (off + b > (size_t)arena_bytes) throw NrError(NR_ERR_ARG, "manifest entry beyond the arena: " + tok[1]);
+      h->dev[tok[1]] = h->import_base + off;
+      h->dev_bytes[tok[1]] = b;
+      h->weight_bytes += b;
+    } else throw NrError(NR_ERR_ARG, "bad manifest line: " + line);
+  }
+  HIP_OK(hipStreamSynchronize((hipStream_t)stream));
   NR_CATCH
 }
 
@@ -1725,6 +1835,7 @@ extern "C" nr_status nr_unet3d_forward(nr_net* h, nr_stream stream, const float*
   NR_TRY
   if (!h || h->cfg.kind != NR_KIND_UNET3D) throw NrError(NR_ERR_ARG, "handle is not a UNet3D");
   if (!h->planned) throw NrError(NR_ERR_STATE, "nr_net_plan() has not been called (or weights changed since)");
+  check_device(h);
   if (!sample_dev || !timesteps || !ctx_dev || !out_dev) throw NrError(NR_ERR_ARG, "null tensor argument");
   if (ctx_len != h->ctx_len) throw NrError(NR_ERR_ARG, "ctx_len differs from the planned value");
   if ((down_res_dev == nullptr) != (mid_res_dev == nullptr)) throw NrError(NR_ERR_ARG, "down/mid residuals must be given together");
@@ -1751,6 +1862,7 @@ extern "C" nr_status nr_sparsectrl_forward(nr_net* h, nr_stream stream, const fl
   NR_TRY
   if (!h || h->cfg.kind != NR_KIND_SPARSECTRL) throw NrError(NR_ERR_ARG, "handle is not a SparseCtrl");
   if (!h->planned) throw NrError(NR_ERR_STATE, "nr_net_plan() has not been called (or weights changed since)");
+  check_device(h);
   if (!timesteps || !ctx_dev || !cond_dev || !mask_dev || !out_down_dev || !out_mid_dev) throw NrError(NR_ERR_ARG, "null tensor argument");
   if (!h->cfg.set_noisy_sample_input_to_zero && !sample_dev) throw NrError(NR_ERR_ARG, "sample required");
   if (ctx_len != h->ctx_len) throw NrError(NR_ERR_ARG, "ctx_len differs from the planned value");
@@ -1776,6 +1888,7 @@ extern "C" nr_status nr_denoise_step_forward(nr_net* unet, nr_net* ctrl, nr_stre
   NR_TRY
   if (!unet || unet->cfg.kind != NR_KIND_UNET3D || !ctrl || ctrl->cfg.kind != NR_KIND_SPARSECTRL) throw NrError(NR_ERR_ARG, "need a UNet3D and a SparseCtrl handle");
   if (!unet->planned || !ctrl->planned) throw NrError(NR_ERR_STATE, "nr_net_plan() has not been called on both handles");
+  check_device(unet); check_device(ctrl);
   if (!sample_dev || !timesteps || !ctx_dev || !cond_dev || !mask_dev || !res_down_dev || !res_mid_dev || !out_dev) throw NrError(NR_ERR_ARG, "null tensor argument");
   if (ctx_len != unet->ctx_len || ctx_len != ctrl->ctx_len) throw NrError(NR_ERR_ARG, "ctx_len differs from the planned value");
   if (unet->n_res != ctrl->n_res || unet->B2 != ctrl->B2 || unet->F != ctrl->F || unet->H != ctrl->H || unet->W != ctrl->W)
@@ -1855,6 +1968,7 @@ extern "C" nr_status nr_sgm_unet_forward(nr_net* h, nr_stream stream, const floa
   NR_TRY
   if (!h || h->cfg.kind != NR_KIND_SGM_UNET) throw NrError(NR_ERR_ARG, "handle is not an sgm UNetModel");
   if (!h->planned) throw NrError(NR_ERR_STATE, "nr_net_plan() has not been called (or weights changed since)");
+  check_device(h);
   if (!x_dev || !timesteps || !ctx_dev || !y_dev || !out_dev) throw NrError(NR_ERR_ARG, "null tensor argument");
   if (ctx_len != h->ctx_len) throw NrError(NR_ERR_ARG, "ctx_len differs from the planned value");
   IO io;
@@ -1870,6 +1984,7 @@ extern "C" nr_status nr_vae_decode(nr_net* h, nr_stream stream, const float* z_d
   NR_TRY
   if (!h || h->cfg.kind != NR_KIND_VAE_DECODER) throw NrError(NR_ERR_ARG, "handle is not a VAE decoder");
   if (!h->planned) throw NrError(NR_ERR_STATE, "nr_net_plan() has not been called (or weights changed since)");
+  check_device(h);
   if (!z_dev || !out_dev) throw NrError(NR_ERR_ARG, "null tensor argument");
   IO io;
   std::memset(&io, 0, sizeof(io));
@@ -1884,6 +1999,7 @@ extern "C" nr_status nr_clip_text_forward(nr_net* h, nr_stream stream, const int
   NR_TRY
   if (!h || h->cfg.kind != NR_KIND_CLIP_TEXT) throw NrError(NR_ERR_ARG, "handle is not a CLIP text encoder");
   if (!h->planned) throw NrError(NR_ERR_STATE, "nr_net_plan() has not been called (or weights changed since)");
+  check_device(h);
   if (!ids_dev || !out_dev) throw NrError(NR_ERR_ARG, "null tensor argument");
   IO io;
   std::memset(&io, 0, sizeof(io));
@@ -1898,6 +2014,7 @@ extern "C" nr_status nr_vae_encode(nr_net* h, nr_stream stream, const float* x_d
   NR_TRY
   if (!h || h->cfg.kind != NR_KIND_VAE_ENCODER) throw NrError(NR_ERR_ARG, "handle is not a VAE encoder");
   if (!h->planned) throw NrError(NR_ERR_STATE, "nr_net_plan() has not been called (or weights changed since)");
+  check_device(h);
   if (!x_dev || !moments_dev) throw NrError(NR_ERR_ARG, "null tensor argument");
   IO io;
   std::memset(&io, 0, sizeof(io));

@@ -31,19 +31,20 @@ __device__ __attribute__((aligned(16))) const unsigned int nr_zero16[4] = {0u, 0
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// LDS-DMA as inline asm, hidden from the compiler: a BUILTIN global_load_lds is a pending LDS write to hipcc, which then places
+// LDS-DMA as inline asm (glds16_asm), hidden from the compiler: a BUILTIN global_load_lds is a pending LDS write to hipcc, which then places
 // s_waitcnt vmcnt(0) in front of the next ds_read that may alias it, i.e. behind every barrier of the main loop, so a ring deeper
 // than two stages never actually has more than one tile in flight.  With the asm form only the counted wait + barrier of the main
 // loop order the DMA against the fragment reads (cdna_hip_programming.md 5.7); M0 is written and restored in the same statement.
-__device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
-#ifdef NR_GLDS_BUILTIN
+// M0 (the LDS destination) is written in the same statement that reads it and declared clobbered, so nothing is saved or
+// restored per transfer (hipcc only warns that m0 is a reserved register; it keeps no value in it across the statement).
+__device__ __forceinline__ void glds16_asm(const void* src, unsigned lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_wave_base) : "memory", "m0");
+}
+__device__ __forceinline__ void glds16_builtin(const void* src, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
-  return;
-#endif
-  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lptr_t)lds_wave_base);
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lptr_t)p);
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
@@ -59,7 +60,10 @@ __device__ __forceinline__ size_t rowvec_row(const NrGemmParams& p, int m) {
 }
 
 // WGM x WGN = wave grid over the (M, N) tile; 64*WGM*WGN threads
-template <int BM, int BN, int NS, int WGM, int WGN, bool LNF = false>
+// ADMA: LDS-DMA issued from inline asm (tiles really stay in flight across the barrier; pays for long K) instead of the builtin
+// (the compiler then drains the DMA in front of the next fragment read: DMA and MFMA of a k-tile do not overlap, but its M0
+// handling is cheaper: measured faster for the short-K Linears of this workload).
+template <int BM, int BN, int NS, int WGM, int WGN, bool LNF = false, bool ADMA = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams p, int splitk, float* partial, int m_fast) {
   constexpr int BK = 64;
   constexpr int NW = WGM * WGN;
@@ -173,10 +177,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
   auto stage = [&](int buf) {
     bf16* sA = smem + buf * TILE;
     bf16* sB = sA + BM * BK;
+    if constexpr (ADMA) {
+      const unsigned la = lds_addr(sA + wave * GA * 8 * BK), lb = lds_addr(sB + wave * GB * 8 * BK);
 #pragma unroll
-    for (int j = 0; j < GA; ++j) glds16(ap[j], sA + (wave * GA + j) * 8 * BK);
+      for (int j = 0; j < GA; ++j) glds16_asm(ap[j], la + (unsigned)(j * 8 * BK * (int)sizeof(bf16)));
 #pragma unroll
-    for (int j = 0; j < GB; ++j) glds16(wp[j], sB + (wave * GB + j) * 8 * BK);
+      for (int j = 0; j < GB; ++j) glds16_asm(wp[j], lb + (unsigned)(j * 8 * BK * (int)sizeof(bf16)));
+    } else {
+#pragma unroll
+      for (int j = 0; j < GA; ++j) glds16_builtin(ap[j], sA + (wave * GA + j) * 8 * BK);
+#pragma unroll
+      for (int j = 0; j < GB; ++j) glds16_builtin(wp[j], sB + (wave * GB + j) * 8 * BK);
+    }
     // advance to the next k-tile
 #pragma unroll
     for (int j = 0; j < GB; ++j) wp[j] += winc[j];
@@ -215,11 +227,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     // tile kt must have landed; the younger (NS-2) tiles may stay outstanding (vmcnt counts in issue order)
     if (kt + (NS - 2) < kt_end) wait_vmcnt<(NS - 2) * G>(); else wait_vmcnt<0>();
-#ifdef NR_GLDS_SYNC
-    __syncthreads();
-#else
     __builtin_amdgcn_s_barrier();            // everyone's pieces of tile kt landed; everyone left tile kt-1
-#endif
     const bf16* sA = smem + cur * TILE;
     const bf16* sB = sA + BM * BK;
     // fragment reads of k-step 0 go out FIRST, so their LDS latency is covered by the staging code below
@@ -240,9 +248,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
       const int nxt = kt + NS - 1;           // refill the buffer tile kt-1 occupied
       int nb = cur + NS - 1; if (nb >= NS) nb -= NS;
       if (nxt < kt_end) stage(nb);
-#ifdef NR_GLDS_POSTWAIT
-      wait_vmcnt<0>();
-#endif
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -569,10 +574,18 @@ int launch_cfg(const NrGemmParams& p, unsigned grid, int splitk, float* partial,
     return 9;
   }
   static unsigned long long attr_set = 0;
-  if (attr_needed(attr_set))   // > 64 KiB of dynamic LDS needs the opt-in attribute (gfx950 has 160 KiB per CU), per device
-    (void)hipFuncSetAttribute((const void*)igemm_bf16_kernel<BM, BN, NS, WGM, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-  hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, NS, WGM, WGN>), dim3(grid), dim3(64 * WGM * WGN), shm, stream, p, splitk,
-                     partial, m_fast);
+  if (attr_needed(attr_set)) {  // > 64 KiB of dynamic LDS needs the opt-in attribute (gfx950 has 160 KiB per CU), per device
+    (void)hipFuncSetAttribute((const void*)igemm_bf16_kernel<BM, BN, NS, WGM, WGN, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    (void)hipFuncSetAttribute((const void*)igemm_bf16_kernel<BM, BN, NS, WGM, WGN, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+  }
+  static const int adma_min = getenv("NR_IGEMM_ADMA_MINK") ? atoi(getenv("NR_IGEMM_ADMA_MINK")) : 24;   // k-tiles per slice; A/B switch
+  const int nk_slice = (p.K / 64) / (splitk > 0 ? splitk : 1);
+  if (nk_slice >= adma_min)
+    hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, NS, WGM, WGN, false, true>), dim3(grid), dim3(64 * WGM * WGN), shm, stream, p, splitk,
+                       partial, m_fast);
+  else
+    hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, NS, WGM, WGN, false, false>), dim3(grid), dim3(64 * WGM * WGN), shm, stream, p, splitk,
+                       partial, m_fast);
   return 0;
 }
 

@@ -51,6 +51,30 @@ def broadcast_state_dict(schema: Dict[str, tuple], state_dict, src: int = 0, dev
     return out
 
 
+def broadcast_native_weights(net, src: int = 0):
+    """rank ``src`` has loaded + planned ``net`` (its converted bf16 weights exist on its GPU); every other rank holds a
+    FRESH network of the same config.  The manifest (a few hundred KB of text) goes through ``broadcast_object_list``, the packed
+    arena (2.55 GB U-Net / 0.99 GB SparseCtrl) through ONE device-to-device broadcast (RCCL over xGMI); receivers import it without
+    ever holding fp32 host weights or re-running the conversion."""
+    import torch.distributed as dist
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return net
+    rank = dist.get_rank()
+    if rank == src:
+        manifest, arena = net.export_weights()
+        meta = [manifest, int(arena.numel())]
+    else:
+        meta = [None, None]
+    dist.broadcast_object_list(meta, src=src)
+    manifest, nbytes = meta
+    if rank != src:
+        arena = torch.empty(nbytes, dtype=torch.uint8, device=net.device)
+    dist.broadcast(arena, src=src)
+    if rank != src:
+        net.import_weights(manifest, arena)
+    return net
+
+
 def max_over_ranks(value: float, device=None) -> float:
     """MAX all-reduce of a timing scalar (bench.py's elapsed time)."""
     import torch.distributed as dist

@@ -411,6 +411,34 @@ class _NativeNet:
             self._ctx_key, self._ctx_plan = key, self._plan_key
             self._ctx_ref = ctx     # keep it alive: its address cannot be recycled for different contents while cached
 
+    # -- converted-weight exchange (multi-GPU start-up: rank 0 converts once, the arena travels device to device) --------------
+    @_on_device
+    def export_weights(self):
+        """(manifest bytes, packed uint8 CUDA tensor) of every converted device buffer.  Call after the first forward / plan."""
+        lib = _lib.load()
+        h = self._handle()
+        nbytes = C.c_int64()
+        n = lib.nr_net_export_manifest(h, None, 0, C.byref(nbytes))
+        if n < 0:
+            _lib.check(1)
+        buf = C.create_string_buffer(int(n))
+        lib.nr_net_export_manifest(h, buf, n, C.byref(nbytes))
+        arena = torch.empty(int(nbytes.value), dtype=torch.uint8, device=self.device)
+        _lib.check(lib.nr_net_export_weights(h, torch.cuda.current_stream().cuda_stream, arena.data_ptr(), arena.numel()))
+        return bytes(buf.raw[:n]), arena
+
+    @_on_device
+    def import_weights(self, manifest: bytes, arena: torch.Tensor):
+        """Adopt another handle's converted weights (same config, same plan shape): no state dict is ever loaded on this side."""
+        if self._pending or self._loaded:
+            raise RuntimeError("import_weights needs a fresh network (no load_state_dict before it)")
+        if not arena.is_cuda or arena.dtype != torch.uint8:
+            raise ValueError("arena must be the uint8 CUDA tensor export_weights() returned")
+        _lib.check(_lib.load().nr_net_import_weights(self._handle(), torch.cuda.current_stream().cuda_stream, manifest, len(manifest),
+                                                     arena.data_ptr(), arena.numel()))
+        self._loaded = set(self._schema)
+        self._plan_key = None
+
     @_on_device
     def profile_last(self):
         """Per-kernel-class time / algorithmic work of the most recent forward (HIP events per launch)."""

@@ -236,3 +236,27 @@ def test_context_cache_tracks_content(cuda):
         ref = unet(sample, int(g["t"]), encoder_hidden_states=tmp.clone()).sample
         assert torch.equal(ref, unet(sample, int(g["t"]), encoder_hidden_states=tmp).sample)
         del tmp
+
+
+def test_export_import_weights_gives_bit_identical_forward(cuda):
+    """rank 0 converts once and the bf16 arena travels device to device (nr_net_export_weights /
+    nr_net_import_weights).  One process here: network A loads a state dict and plans; a FRESH network B imports A's arena
+    (never sees a state dict) and must produce bit-identical outputs; so must the overlapped step."""
+    g = np.load(os.path.join(GOLD, "tiny_networks.npz"))
+    unet, ctrl = _tiny()
+    sample, ctx = torch.from_numpy(g["sample"]).cuda(), torch.from_numpy(g["ctx"]).cuda()
+    cond, mask = torch.from_numpy(g["cond"]).cuda(), torch.from_numpy(g["mask"]).cuda()
+    want = unet.forward_with_controlnet(ctrl, sample, int(g["t"]), ctx, cond, mask, 1.0).sample
+    from neurons_amd import NativeSparseCtrl, NativeUNet3D
+    unet2, ctrl2 = NativeUNet3D(unet.config).to("cuda"), NativeSparseCtrl(ctrl.config).to("cuda")
+    for src, dst in ((unet, unet2), (ctrl, ctrl2)):
+        manifest, arena = src.export_weights()
+        assert manifest.startswith(b"NRW1 ") and arena.dtype == torch.uint8 and arena.numel() % 256 == 0
+        dst.import_weights(manifest, arena)
+        del arena
+    torch.cuda.empty_cache()
+    got = unet2.forward_with_controlnet(ctrl2, sample, int(g["t"]), ctx, cond, mask, 1.0).sample
+    assert torch.equal(want, got)
+    assert unet2.weight_bytes() == unet.weight_bytes()
+    with pytest.raises(RuntimeError, match="fresh network"):
+        unet2.import_weights(*unet.export_weights())
