@@ -234,6 +234,10 @@ typedef struct nr_profile {
  * launch, and reports per-kernel-class totals (bench.py's roofline object). */
 nr_status nr_net_profile_last(nr_net* h, nr_stream stream, nr_profile* out);
 
+/* BASELINE config 5: run the spatial self- and text cross-attention cores (motion_module_new.py:258-287) with OCP e4m3 MFMA
+ * operands (fp32 softmax statistics and accumulation).  Off by default (bf16); changing it invalidates the plan. */
+nr_status nr_net_set_attention_fp8(nr_net* h, int32_t enable);
+
 /* ---- converted-weight exchange between handles (multi-GPU start-up) -----------------
  * The reference shards clips over processes and every process loads the checkpoints itself (scripts/neuroclips_video.py:
  * 94-138,238).  Here rank 0 loads + converts once (nr_net_load_tensor, nr_net_plan) and the converted bf16/fp32 device
@@ -283,7 +287,7 @@ nr_status nr_op_layernorm(nr_stream stream, const void* x_dev, void* out_dev, in
                           const float* gamma_dev, const float* beta_dev, float eps, const float* pe_dev, int32_t pe_hw,
                           int32_t pe_F);
 /* mode 0: spatial self ([nimg][L][3C] fused qkv), 1: cross (q [nimg][L][C], kv [nb_kv][Lk][2C], kv_div),
- * 2: temporal self (fused qkv [(b f)][hw][3C], sequence over f) */
+ * 2: temporal self (fused qkv [(b f)][hw][3C], sequence over f); mode | 8: e4m3 MFMA operands (modes 0 and 1, L >= 48) */
 nr_status nr_op_attention(nr_stream stream, int32_t mode, const void* q_dev, const void* kv_dev, void* out_dev,
                           int32_t nimg, int32_t L, int32_t Lk, int32_t C, int32_t heads, int32_t frames, int32_t kv_div);
 

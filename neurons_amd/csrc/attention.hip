@@ -169,7 +169,29 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(NrAttnParams p) {
 // ------------------------------------------------------------------------------------------------
 constexpr int KT2 = 64;
 
-template <int DK, int DT>
+// OCP e4m3 operands for the fp8 variant (BASELINE config 5): 8 values -> one 64-bit MFMA operand (v_cvt_pk_fp8_f32; gfx950 = OCP)
+__device__ __forceinline__ long to_fp8x8(const bf16x8& v) {
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[0], (float)v[1], lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[2], (float)v[3], lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[4], (float)v[5], hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[6], (float)v[7], hi, true);
+  return (long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ long to_fp8x8(const float (&v)[8]) {
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+  return (long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+// FP8: both products (S^T = K Q^T and O^T = V^T P^T) on v_mfma_f32_16x16x32_fp8_fp8 with OCP e4m3 operands converted in
+// registers (Q, K, V from their bf16 tiles; P straight from its fp32 exponentials, scaled by 256 so the probabilities use the
+// e4m3 normal range, and the sum divided back in fp32); softmax statistics and accumulators stay fp32.  The non-scaled fp8 MFMA
+// issues at the bf16 rate (MI355X_MICROARCH.md), so this variant is about the numerics of config 5, not about speed.
+template <int DK, int DT, bool FP8 = false>
 __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p, int KS) {
   constexpr int CH = (DT + 1) / 2;            // 16-B chunks per thread per matrix per tile
   extern __shared__ __attribute__((aligned(16))) bf16 lds[];
@@ -197,6 +219,11 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p, in
     qf[ks] = dim0 < p.d ? *(const bf16x8*)(p.q + qbase + (long long)qrow_c * p.q_seq + dim0) : zero8;
   }
 
+  long qf8[DK];
+  if constexpr (FP8) {
+#pragma unroll
+    for (int ks = 0; ks < DK; ++ks) qf8[ks] = to_fp8x8(qf[ks]);
+  }
   const int cpk = p.d >> 3;                   // chunks per key row
   const int nchunk = KT2 * cpk;
   bf16x8 rk[CH], rv[CH];
@@ -254,7 +281,8 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p, in
       for (int ks = 0; ks < DK; ++ks) {
         const int dim0 = ks * 32 + g * 8;
         const bf16x8 kf = dim0 < p.d ? *(const bf16x8*)(sk + (16 * t + c) * KS + dim0) : zero8;
-        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
+        if constexpr (FP8) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(to_fp8x8(kf), qf8[ks], s[t], 0, 0, 0);
+        else s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
       }
     }
     // softmax in the log2 domain: exp(scale*s - m) = exp2(s*scale*log2(e) - m2); one v_exp per score, no extra mul.
@@ -284,14 +312,18 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p, in
     const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
     float rs = 0.f;
     bf16x8 pf[2];
+    float pe[2][8];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float e = __builtin_amdgcn_exp2f(s[t][r] - m_new);   // masked keys: exp2(-1e30 - m) = 0
         rs += e;
-        pf[t >> 1][(t & 1) * 4 + r] = (bf16)e;
+        if constexpr (FP8) pe[t >> 1][(t & 1) * 4 + r] = e * 256.0f;
+        else pf[t >> 1][(t & 1) * 4 + r] = (bf16)e;
       }
+    long pf8[2];
+    if constexpr (FP8) { pf8[0] = to_fp8x8(pe[0]); pf8[1] = to_fp8x8(pe[1]); }
     rs += __shfl_xor(rs, 16, 64);
     rs += __shfl_xor(rs, 32, 64);
     l_i = l_i * alpha + rs;
@@ -309,7 +341,8 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p, in
         bf16x8 vf;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u], acc[i], 0, 0, 0);
+        if constexpr (FP8) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(to_fp8x8(vf), pf8[u], acc[i], 0, 0, 0);
+        else acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u], acc[i], 0, 0, 0);
       }
     }
     if (it + 1 < ntile) write_lds((it + 1) & 1);
@@ -317,7 +350,7 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p, in
   }
 
   if (qrow < p.Lq) {
-    const float inv = 1.0f / l_i;
+    const float inv = (FP8 ? 1.0f / 256.0f : 1.0f) / l_i;
     bf16* op = p.out + obase + (long long)qrow * p.o_seq;
 #pragma unroll
     for (int i = 0; i < DT; ++i) {
@@ -340,14 +373,18 @@ int launch_attn(const NrAttnParams& p, hipStream_t stream) {
     if ((u & 1) == 0) u += 1;
     const int KS = u * 8;
     const size_t shm = (size_t)2 * 2 * KT2 * KS * sizeof(bf16) + 256;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)attn_fwd_shared_kernel<DK, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-      attr_set = true;
+    static unsigned long long attr_mask = 0;       // per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!(attr_mask >> (dev & 63) & 1ull)) {
+      (void)hipFuncSetAttribute((const void*)attn_fwd_shared_kernel<DK, DT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+      (void)hipFuncSetAttribute((const void*)attn_fwd_shared_kernel<DK, DT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+      attr_mask |= 1ull << (dev & 63);
     }
     const int qblocks = (p.Lq + 63) / 64;
     const unsigned blocks = (unsigned)((long long)p.nbatch * p.heads * qblocks);
-    hipLaunchKernelGGL((attn_fwd_shared_kernel<DK, DT>), dim3(blocks), dim3(256), shm, stream, p, KS);
+    if (p.fp8) hipLaunchKernelGGL((attn_fwd_shared_kernel<DK, DT, true>), dim3(blocks), dim3(256), shm, stream, p, KS);
+    else hipLaunchKernelGGL((attn_fwd_shared_kernel<DK, DT, false>), dim3(blocks), dim3(256), shm, stream, p, KS);
     return 0;
   }
   const int qtiles = (p.Lq + 15) / 16;

@@ -125,6 +125,7 @@ struct NrAttnParams {
   int nbatch, heads, d, Lq, Lk;
   float scale;
   int causal;      // 1: key j is visible to query i only if j <= i (CLIP text encoder)
+  int fp8;         // 1: OCP e4m3 MFMA operands in the block-shared (spatial / cross) kernel; bf16 is the default
 };
 
 // GroupNorm launch parameters (norm.hip)

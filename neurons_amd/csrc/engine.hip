@@ -230,6 +230,7 @@ struct nr_net {
   std::vector<OpMeta> op_meta;   // parallel to ops: kernel class + algorithmic work (for roofline reporting)
   std::vector<Tap> taps;
   bool keep_all = false;
+  bool attn_fp8 = false;         // nr_net_set_attention_fp8: spatial / cross attention on e4m3 MFMA operands (config 5)
   IO io;
   int n_res = 0;
   struct ResShape { int C, h, w; };
@@ -647,7 +648,7 @@ struct nr_net {
     const int d = C / heads;
     Act out = new_act(q.nimg, q.H, q.W, C);
     p.heads = heads; p.d = d; p.scale = 1.0f / std::sqrt((float)d);
-    p.out = out.ptr; p.causal = causal;
+    p.out = out.ptr; p.causal = causal; p.fp8 = (attn_fp8 && mode != 2) ? 1 : 0;
     if (mode == 0) {
       p.q = q.ptr; p.k = q.ptr + C; p.v = q.ptr + 2 * C;
       p.nbatch = q.nimg; p.Lq = hw; p.Lk = hw;
@@ -1810,6 +1811,13 @@ extern "C" nr_status nr_net_set_graph(nr_net* h, int32_t enable) {
   NR_CATCH
 }
 
+extern "C" nr_status nr_net_set_attention_fp8(nr_net* h, int32_t enable) {
+  NR_TRY
+  if (!h) throw NrError(NR_ERR_ARG, "null handle");
+  if (h->attn_fp8 != (enable != 0)) { h->attn_fp8 = enable != 0; h->planned = false; }
+  NR_CATCH
+}
+
 extern "C" nr_status nr_net_set_debug(nr_net* h, int32_t keep) {
   NR_TRY
   if (!h) throw NrError(NR_ERR_ARG, "null handle");
@@ -2186,6 +2194,8 @@ extern "C" nr_status nr_op_attention(nr_stream stream, int32_t mode, const void*
   NrAttnParams p;
   std::memset(&p, 0, sizeof(p));
   const bf16* q = (const bf16*)qp; const bf16* kv = (const bf16*)kvp;
+  const int fp8_flag = (mode & 8) ? 1 : 0;      // mode | 8: e4m3 MFMA operands (spatial / cross kernels)
+  mode &= 7;
   p.heads = heads; p.d = C / heads; p.scale = 1.0f / std::sqrt((float)p.d); p.out = (bf16*)outp;
   if (mode == 0) {
     const int ld = 3 * C;
@@ -2203,6 +2213,7 @@ extern "C" nr_status nr_op_attention(nr_stream stream, int32_t mode, const void*
     p.kv_outer = p.q_outer; p.kv_inner_stride = ld; p.kv_seq = p.q_seq;
     p.o_outer = (long long)F * hw * C; p.o_inner_stride = C; p.o_seq = (long long)hw * C;
   } else throw NrError(NR_ERR_ARG, "bad attention mode");
+  p.fp8 = fp8_flag;
   LAUNCH_OK(nr_launch_attention(&p, (hipStream_t)stream));
   NR_CATCH
 }

@@ -139,25 +139,25 @@ def layernorm(x, gamma, beta, eps=1e-5, pe=None, pe_hw=1, pe_F=1):
     return out
 
 
-def attention_self(qkv, heads):
-    """qkv: [nimg, L, 3C] fused; returns [nimg, L, C]."""
+def attention_self(qkv, heads, fp8=False):
+    """qkv: [nimg, L, 3C] fused; returns [nimg, L, C].  fp8: OCP e4m3 MFMA operands (L >= 48; BASELINE config 5)."""
     _chk_bf16(qkv)
     nimg, L, C3 = qkv.shape
     Cc = C3 // 3
     out = torch.empty(nimg, L, Cc, dtype=torch.bfloat16, device=qkv.device)
     lib = _lib.load()
-    _lib.check(lib.nr_op_attention(_stream(), 0, _ptr(qkv), None, _ptr(out), nimg, L, L, Cc, heads, 1, 1))
+    _lib.check(lib.nr_op_attention(_stream(), 8 if fp8 else 0, _ptr(qkv), None, _ptr(out), nimg, L, L, Cc, heads, 1, 1))
     return out
 
 
-def attention_cross(q, kv, heads, kv_div):
-    """q: [nimg, L, C]; kv: [nb, Lk, 2C] fused; image n attends to kv[n // kv_div]."""
+def attention_cross(q, kv, heads, kv_div, fp8=False):
+    """q: [nimg, L, C]; kv: [nb, Lk, 2C] fused; image n attends to kv[n // kv_div].  fp8 as in attention_self."""
     _chk_bf16(q, kv)
     nimg, L, Cc = q.shape
     Lk = kv.shape[1]
     out = torch.empty_like(q)
     lib = _lib.load()
-    _lib.check(lib.nr_op_attention(_stream(), 1, _ptr(q), _ptr(kv), _ptr(out), nimg, L, Lk, Cc, heads, 1, kv_div))
+    _lib.check(lib.nr_op_attention(_stream(), 9 if fp8 else 1, _ptr(q), _ptr(kv), _ptr(out), nimg, L, Lk, Cc, heads, 1, kv_div))
     return out
 
 

@@ -343,6 +343,13 @@ class _NativeNet:
             _lib.check(_lib.load().nr_net_set_graph(self._h, 1 if flag else 0))
         return self
 
+    def set_attention_fp8(self, flag=True):
+        """BASELINE config 5: spatial self- and text cross-attention with OCP e4m3 MFMA operands (fp32 softmax and accumulation).
+        bf16 stays the default; the next forward re-plans."""
+        _lib.check(_lib.load().nr_net_set_attention_fp8(self._handle(), 1 if flag else 0))
+        self._plan_key = None
+        return self
+
     def state_dict_keys(self):
         return list(self._schema.keys())
 
@@ -396,6 +403,7 @@ class _NativeNet:
             _lib.check(_lib.load().nr_net_plan(self._handle(), batch, frames, h, w, ctx_len))
             _lib.check(_lib.load().nr_net_release_host_weights(self._handle()))
             self._plan_key = key
+            self._ctx_key = None         # _on_plan allocates fresh staging buffers: the cached context must be copied again
             self._on_plan()
 
     def _on_plan(self):

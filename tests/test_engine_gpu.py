@@ -141,6 +141,32 @@ def test_wider_unet_vs_oracle(cuda, boc, F, hw, ctxd):
     assert rel < 2.5e-2 and psnr > 35
 
 
+def test_fp8_attention_flag_psnr_vs_fp32_oracle(cuda):
+    """BASELINE config 5: e4m3 spatial/cross attention behind nr_net_set_attention_fp8; bf16 stays the default.
+    Stated gate vs the fp32 oracle: PSNR >= 30 dB, rel-L2 <= 6e-2 (bf16 path: 35 dB / 2.5e-2)."""
+    from neurons_amd import _lib, NativeUNet3D
+    from neurons_amd.synth import randn
+    from neurons_amd.unet3d import UNet3DConfig, random_state_dict
+    from oracle import animatediff_oracle as O
+    cfg = UNet3DConfig(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768)
+    sd = random_state_dict(cfg, _lib.NR_KIND_UNET3D, seed=3)
+    unet = NativeUNet3D(cfg).to("cuda")
+    unet.load_state_dict(sd)
+    sample = randn("f8.sample", (2, 4, 2, 16, 16), 5).cuda()
+    ctx = randn("f8.ctx", (2, 77, 768), 6).cuda()
+    eps16 = unet(sample, 501, encoder_hidden_states=ctx).sample.clone()
+    unet.set_attention_fp8(True)
+    eps8 = unet(sample, 501, encoder_hidden_states=ctx).sample.clone()
+    unet.set_attention_fp8(False)
+    eps16b = unet(sample, 501, encoder_hidden_states=ctx).sample
+    assert torch.equal(eps16, eps16b) and not torch.equal(eps16, eps8)
+    with torch.no_grad():
+        ref = O.unet3d_forward({k: v.cuda() for k, v in sd.items()}, O.OracleConfig.from_native(cfg), sample, 501, ctx)
+    rel16, psnr16 = metrics("bf16 attention vs oracle", eps16, ref)
+    rel8, psnr8 = metrics("fp8 attention vs oracle", eps8, ref)
+    assert rel8 <= 6e-2 and psnr8 >= 30 and rel16 < 2.5e-2
+
+
 def test_batch_of_clips_equals_independent_clips(cuda):
     """BASELINE config 4 runs several clips per GPU.  The reference's SparseCtrl only broadcasts a batch-1 condition
     (sparse_controlnet.py:521); here B clips in one call must equal B independent B=1 calls bit-for-bit
