@@ -27,7 +27,8 @@ __device__ __forceinline__ bf16x8 bf16x8_zero() {
   return z;
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x); v_rcp_f32 (1 ulp) instead of the IEEE division sequence: the result is rounded to bf16 anyway
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // exact (erf) GELU, as torch F.gelu default (reference: animatediff/models/motion_module_new.py:508-518)
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 // Same function with erf from Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, i.e. far below the bf16

@@ -311,7 +311,39 @@ __global__ void bf16_to_f32_kernel(const bf16* __restrict__ a, float* __restrict
   if (i < n) out[i] = (float)a[i];
 }
 
+// Weight-conversion time only (not on the denoising path): two consecutive Linears with nothing but a residual add between them,
+//   out = x + b2 + W2 (t + b1 + W1 g)   (FeedForward.net.2 then proj_out; motion_module_new.py:441-471, attention.py:137-141)
+// are folded into ONE GEMM over the concatenated operand [t | g]:  Wc = [W2 | W2 W1] (bf16), bc = b2 + W2 b1 (fp32).
+// w2: [C][C], w1: [C][J] (both fp32, row-major); wc: [C][C + J].  grid (ceil((C + J) / 256), C).
+__global__ __launch_bounds__(256) void fold_linear_pair_kernel(const float* __restrict__ w2, const float* __restrict__ w1,
+                                                               const float* __restrict__ b2, const float* __restrict__ b1, int C, int J,
+                                                               bf16* __restrict__ wc, float* __restrict__ bc) {
+  const int n = blockIdx.y;
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  const float* w2r = w2 + (size_t)n * C;
+  if (col < C) {
+    wc[(size_t)n * (C + J) + col] = (bf16)w2r[col];
+  } else if (col < C + J) {
+    const int j = col - C;
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a = fmaf(w2r[c], w1[(size_t)c * J + j], a);
+    wc[(size_t)n * (C + J) + col] = (bf16)a;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float a = b2[n];
+    for (int c = 0; c < C; ++c) a = fmaf(w2r[c], b1[c], a);
+    bc[n] = a;
+  }
+}
+
 }  // namespace
+
+extern "C" int nr_launch_fold_linear_pair(const float* w2, const float* w1, const float* b2, const float* b1, int C, int J, bf16* wc,
+                                          float* bc, hipStream_t stream) {
+  hipLaunchKernelGGL(fold_linear_pair_kernel, dim3((unsigned)((C + J + 255) / 256), (unsigned)C), dim3(256), 0, stream, w2, w1, b2, b1, C, J,
+                     wc, bc);
+  return 0;
+}
 
 extern "C" int nr_launch_clip_embed(const int* ids, const float* tok, const float* pos, bf16* out, int M, int L, int C, int vocab,
                                     hipStream_t stream) {

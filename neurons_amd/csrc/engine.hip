@@ -57,6 +57,8 @@ int nr_launch_cfg_ddim_step(const float* eps, const float* x, float* x_out, long
                             float sqrt_at, float sqrt_1mat, float sqrt_ap, float sqrt_1map, hipStream_t stream);
 int nr_launch_add_bf16(const bf16* a, const bf16* b, bf16* out, long long n, hipStream_t stream);
 int nr_launch_f32_to_bf16(const float* a, bf16* out, long long n, hipStream_t stream);
+int nr_launch_fold_linear_pair(const float* w2, const float* w1, const float* b2, const float* b1, int C, int J, bf16* wc, float* bc,
+                               hipStream_t stream);
 }
 
 namespace {
@@ -419,6 +421,44 @@ struct nr_net {
       }
       return upload(name, rv.data(), rv.size() * 4);
     });
+  }
+  // FeedForward.net.2 followed by proj_out (only the residual add of the block between them) folded into one Linear over the
+  // concatenated operand [t | g]: Wc = [Wpo | Wpo Wff2] ([C][5C] bf16), bc = bpo + Wpo bff2.  The C x C x 4C product runs on the device
+  // in fp32 (fold_linear_pair_kernel), once per plan of new weights.
+  struct FoldW { const bf16* w; const float* b; };
+  FoldW w_fold_ff_proj(const std::string& ff2, const std::string& po, int C) {
+    const int J = 4 * C;
+    check_shape(ff2 + ".weight", need(ff2 + ".weight"), {C, J});
+    check_shape(ff2 + ".bias", need(ff2 + ".bias"), {C});
+    check_shape(po + ".weight", need(po + ".weight"), {C, C});
+    check_shape(po + ".bias", need(po + ".bias"), {C});
+    FoldW r{nullptr, nullptr};
+    if (dry) return r;
+    const std::string nw = "foldw:" + po + ".weight|" + po + ".bias|" + ff2 + ".weight|" + ff2 + ".bias";
+    const std::string nb = "foldb:" + po + ".weight|" + po + ".bias|" + ff2 + ".weight|" + ff2 + ".bias";
+    auto it = dev.find(nw);
+    if (it != dev.end()) { r.w = (const bf16*)it->second; r.b = (const float*)dev.at(nb); return r; }
+    const HostTensor& W2 = data_of(po + ".weight");
+    const HostTensor& B2 = data_of(po + ".bias");
+    const HostTensor& W1 = data_of(ff2 + ".weight");
+    const HostTensor& B1 = data_of(ff2 + ".bias");
+    float *dw2 = nullptr, *dw1 = nullptr, *db2 = nullptr, *db1 = nullptr;
+    void *dwc = nullptr, *dbc = nullptr;
+    const size_t wcb = (size_t)C * (C + J) * sizeof(bf16), bcb = (size_t)C * sizeof(float);
+    HIP_OK(hipMalloc(&dw2, W2.data.size() * 4)); HIP_OK(hipMalloc(&dw1, W1.data.size() * 4));
+    HIP_OK(hipMalloc(&db2, B2.data.size() * 4)); HIP_OK(hipMalloc(&db1, B1.data.size() * 4));
+    HIP_OK(hipMalloc(&dwc, wcb)); HIP_OK(hipMalloc(&dbc, bcb));
+    HIP_OK(hipMemcpy(dw2, W2.data.data(), W2.data.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dw1, W1.data.data(), W1.data.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(db2, B2.data.data(), B2.data.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(db1, B1.data.data(), B1.data.size() * 4, hipMemcpyHostToDevice));
+    LAUNCH_OK(nr_launch_fold_linear_pair(dw2, dw1, db2, db1, C, J, (bf16*)dwc, (float*)dbc, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    (void)hipFree(dw2); (void)hipFree(dw1); (void)hipFree(db2); (void)hipFree(db1);
+    dev[nw] = dwc; dev_bytes[nw] = wcb; dev[nb] = dbc; dev_bytes[nb] = bcb;
+    weight_bytes += wcb + bcb;
+    r.w = (const bf16*)dwc; r.b = (const float*)dbc;
+    return r;
   }
   // GEGLU projection [2*inner][K]: rows permuted so each 32-row group is 16 value rows then their 16 gate rows
   const bf16* w_geglu(const std::string& key, int inner, int K) {
@@ -789,6 +829,26 @@ struct nr_net {
     linear(hmid, w_linear(pre + ".net.2.weight", C, inner), C, o2);
   }
 
+  // The block's LAST FeedForward and the transformer's proj_out as one GEMM (w_fold_ff_proj): x + proj_out(t + FF(t)) =
+  // x + bc + [t | g] Wc^T with g = GEGLU(net.0(LN(t))).  Removes a launch and the write + read of the post-FF residual stream.
+  // Needs C % 64 == 0 (the operand switch falls on a k-tile boundary); NR_FOLD_PROJ_OUT=0 keeps the two GEMMs.
+  bool fold_proj_out(int C) const {
+    static const bool off = getenv("NR_FOLD_PROJ_OUT") && getenv("NR_FOLD_PROJ_OUT")[0] == '0';
+    return !off && C % 64 == 0;
+  }
+  Act feed_forward_proj_out(const Act& x, Act& t, const std::string& ln, const std::string& ff, const std::string& pre) {
+    const int C = t.C, inner = 4 * C;
+    if (!fold_proj_out(C)) {
+      feed_forward(t, ln, ff);
+      GemmOpt op; op.bias = w_f32(pre + ".proj_out.bias", C); op.res = &x;
+      return linear(t, w_linear(pre + ".proj_out.weight", C, C), C, op);
+    }
+    Act g = ln_linear(t, ln, {ff + ".net.0.proj.weight"}, {ff + ".net.0.proj.bias"}, inner, true, 0, false);
+    const FoldW fw = w_fold_ff_proj(ff + ".net.2", pre + ".proj_out", C);
+    GemmOpt op; op.bias = fw.b; op.res = &x;
+    return conv(t, &g, fw.w, C, 1, 1, 0, op);
+  }
+
   // Transformer3DModel.forward (attention.py:95-142) with one BasicTransformerBlock (:256-300); also sgm
   // SpatialTransformer.forward (sgm/modules/attention.py:702-723) with `depth` BasicTransformerBlocks (:551-572):
   // same arithmetic and parameter names (proj_in/out are nn.Linear there: same [C][C] matrix).
@@ -822,10 +882,10 @@ struct nr_net {
         GemmOpt oo; oo.bias = w_f32(b + ".attn2.to_out.0.bias", C); oo.res = &t; oo.out = &t;
         linear(a, w_linear(b + ".attn2.to_out.0.weight", C, C), C, oo);
       }
-      feed_forward(t, b + ".norm3", b + ".ff");
+      if (dd + 1 < depth) feed_forward(t, b + ".norm3", b + ".ff");
     }
-    GemmOpt op; op.bias = w_f32(pre + ".proj_out.bias", C); op.res = &x;
-    Act out = linear(t, w_linear(pre + ".proj_out.weight", C, C), C, op);
+    Act out = feed_forward_proj_out(x, t, pre + ".transformer_blocks." + std::to_string(depth - 1) + ".norm3",
+                                    pre + ".transformer_blocks." + std::to_string(depth - 1) + ".ff", pre);
     tap(pre, out);
     return out;
   }
@@ -852,9 +912,7 @@ struct nr_net {
       GemmOpt oo; oo.bias = w_f32(ab + ".to_out.0.bias", C); oo.res = &t; oo.out = &t;
       linear(a, w_linear(ab + ".to_out.0.weight", C, C), C, oo);
     }
-    feed_forward(t, b + ".ff_norm", b + ".ff");
-    GemmOpt op; op.bias = w_f32(pre + ".proj_out.bias", C); op.res = &x;
-    Act out = linear(t, w_linear(pre + ".proj_out.weight", C, C), C, op);
+    Act out = feed_forward_proj_out(x, t, b + ".ff_norm", b + ".ff", pre);
     tap(pre0, out);
     return out;
   }
@@ -1670,9 +1728,26 @@ extern "C" nr_status nr_net_load_tensor(nr_net* h, const char* key, const float*
   for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= shape[i]; }
   t.data.assign(host_data, host_data + n);
   h->host[key] = std::move(t);
-  // a reload invalidates converted copies derived from this key
+  // a reload invalidates the converted copies derived from exactly this key.  Converted names are "<tag>:<key>" or
+  // "<tag>:<key>|<key>|..." (keys contain neither ':' nor '|'); the stacked time-embedding projections ("temb...") are rebuilt
+  // when any time-embedding tensor changes.
+  const std::string k(key);
+  const bool is_temb_src = k.find("time_emb") != std::string::npos || k.find("label_emb") != std::string::npos;
+  auto derived_from = [&](const std::string& name) {
+    size_t b = 0;
+    while (b <= name.size()) {
+      size_t e = name.find_first_of(":|", b);
+      if (e == std::string::npos) e = name.size();
+      if (e - b == k.size() && name.compare(b, k.size(), k) == 0) return true;
+      // a norm enters a name by its prefix ("lnw:<prefix>|..." uses <prefix>.weight and <prefix>.bias)
+      if (e > b && k.size() > e - b && k.compare(0, e - b, name, b, e - b) == 0 && (k.compare(e - b, std::string::npos, ".weight") == 0 ||
+                                                                                   k.compare(e - b, std::string::npos, ".bias") == 0)) return true;
+      b = e + 1;
+    }
+    return false;
+  };
   for (auto it = h->dev.begin(); it != h->dev.end();) {
-    if (it->first.find(key) != std::string::npos || it->first.rfind("temb", 0) == 0) {
+    if (derived_from(it->first) || (is_temb_src && it->first.rfind("temb", 0) == 0)) {
       (void)hipDeviceSynchronize();
       if (!h->in_import(it->second)) (void)hipFree(it->second);
       h->dev_bytes.erase(it->first);

@@ -209,7 +209,6 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(NrGnParams p) {
 template <int MAXP>
 __global__ __launch_bounds__(256) void gn_fused_small_kernel(NrGnParams p) {
   __shared__ float red[2][4];
-  if (p.finalized == 77) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // experiment: drop this CU's L1 lines first
   const int C = p.c0 + p.c1;
   const int cg = C / p.groups;
   const int hp = cg >> 1;                       // bf16 pairs per pixel of this group
@@ -249,6 +248,121 @@ __global__ __launch_bounds__(256) void gn_fused_small_kernel(NrGnParams p) {
       if (p.silu) { a = silu_f(a); b = silu_f(b); }
       bf16x2 o; o[0] = (bf16)a; o[1] = (bf16)b;
       *(bf16x2*)(p.out + ((size_t)img * p.hw + px) * p.ldo + c) = o;
+    }
+  }
+}
+
+// GroupNorm(+SiLU) with ONE HBM read and ONE write (the 32x32 ... 4x4 levels of the denoisers): one 512- or 1024-thread workgroup per
+// (image, set of GS consecutive groups).  The set's hw x (GS*cg) slab (<= 16 B x NV x 512 = 240 KiB of registers per CU) is
+// read once as 16-byte chunks, reduced deterministically (fixed-order LDS tree, no atomics), normalised and written.
+// Thread t owns chunk column c = t % cpp of pixels plane + NPL*i, so its 8 channels, their (at most two, cg >= 8) groups
+// and gamma/beta are fixed: the statistics use v_dot2_f32_bf16 on the raw pairs (sum / sum of squares of all 8 elements, and
+// of the elements of the column's first group selected by a bit mask), the apply is one fma per element.
+// Workgroups of one image are placed on ONE XCD (its L2 then serves the partially used lines of the narrow slabs).
+template <int NV, int T>
+__global__ __launch_bounds__(T) void gn_slab_kernel(NrGnParams p, int GS) {
+  __shared__ float red[T][4];
+  __shared__ float colsum[64][4];
+  __shared__ float gstat[16][2];
+  const int C = p.c0 + p.c1;
+  const int cg = C / p.groups;
+  const int cpp = GS * cg / 8;                  // 16-byte chunks per pixel of this slab (<= 64)
+  const int NPL = T / cpp;                      // pixel lanes
+  const int sets = p.groups / GS;
+  int bid = blockIdx.x;
+  {
+    const int nb = gridDim.x;
+    if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);     // XCD x gets the contiguous range [x*nb/8, (x+1)*nb/8)
+  }
+  const int img = bid / sets, set = bid - img * sets;
+  const int tid = threadIdx.x;
+  const int c = tid % cpp, plane = tid / cpp;
+  const bool active = plane < NPL;
+  const int ch0 = set * GS * cg + c * 8;        // first of this thread's 8 channels
+  const bf16* src; int ld;
+  if (ch0 < p.c0) { src = p.x0 + ch0; ld = p.ld0; } else { src = p.x1 + (ch0 - p.c0); ld = p.ld1; }
+  src += (size_t)img * p.hw * ld;
+  bf16x8 v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int px = plane + NPL * i;
+    if (active && px < p.hw) v[i] = *(const bf16x8*)(src + (size_t)px * ld);
+    else v[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  // elements [0, nlo) of the chunk belong to the column's first group, the rest to the next one
+  const int g_first = (c * 8) / cg;
+  const int nlo = min(8, (g_first + 1) * cg - c * 8);
+  unsigned mask[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) mask[j] = (2 * j < nlo ? 0xFFFFu : 0u) | (2 * j + 1 < nlo ? 0xFFFF0000u : 0u);
+  const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
+  float s_all = 0.f, q_all = 0.f, s_lo = 0.f, q_lo = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const unsigned* w = reinterpret_cast<const unsigned*>(&v[i]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned um = w[j] & mask[j];
+      const bf16x2 x = __builtin_bit_cast(bf16x2, w[j]);
+      const bf16x2 xm = __builtin_bit_cast(bf16x2, um);
+      s_all = __builtin_amdgcn_fdot2_f32_bf16(x, one2, s_all, false);
+      q_all = __builtin_amdgcn_fdot2_f32_bf16(x, x, q_all, false);
+      s_lo = __builtin_amdgcn_fdot2_f32_bf16(xm, one2, s_lo, false);
+      q_lo = __builtin_amdgcn_fdot2_f32_bf16(xm, xm, q_lo, false);
+    }
+  }
+  red[tid][0] = s_lo; red[tid][1] = q_lo; red[tid][2] = s_all - s_lo; red[tid][3] = q_all - q_lo;
+  __syncthreads();
+  // column sums over the pixel lanes: 8 threads per column, fixed order
+  {
+    const int col = tid >> 3, r = tid & 7;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (col < cpp)
+      for (int pl = r; pl < NPL; pl += 8) {
+        const float* e = red[col + cpp * pl];
+        a[0] += e[0]; a[1] += e[1]; a[2] += e[2]; a[3] += e[3];
+      }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      a[k] += __shfl_xor(a[k], 1, 64); a[k] += __shfl_xor(a[k], 2, 64); a[k] += __shfl_xor(a[k], 4, 64);
+    }
+    if (col < cpp && r == 0) { colsum[col][0] = a[0]; colsum[col][1] = a[1]; colsum[col][2] = a[2]; colsum[col][3] = a[3]; }
+  }
+  __syncthreads();
+  if (tid < GS) {
+    float s = 0.f, q = 0.f;
+    for (int cc = 0; cc < cpp; ++cc) {
+      const int gf = (cc * 8) / cg;
+      if (gf == tid) { s += colsum[cc][0]; q += colsum[cc][1]; }
+      else if (gf + 1 == tid) { s += colsum[cc][2]; q += colsum[cc][3]; }      // zero when the chunk does not straddle
+    }
+    const float inv = 1.0f / ((float)cg * (float)p.hw);
+    const float mean = s * inv;
+    gstat[tid][0] = mean;
+    gstat[tid][1] = rsqrtf(fmaxf(q * inv - mean * mean, 0.f) + p.eps);
+  }
+  __syncthreads();
+  if (!active) return;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int g = e < nlo ? g_first : g_first + 1;
+    sc[e] = gstat[g][1] * p.gamma[ch0 + e];
+    sh[e] = p.beta[ch0 + e] - gstat[g][0] * sc[e];
+  }
+  bf16* dst = p.out + (size_t)img * p.hw * p.ldo + ch0;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int px = plane + NPL * i;
+    if (px < p.hw) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = (float)v[i][e] * sc[e] + sh[e];
+        if (p.silu) f = silu_f(f);
+        o[e] = (bf16)f;
+      }
+      *(bf16x8*)(dst + (size_t)px * p.ldo) = o;
     }
   }
 }
@@ -355,14 +469,50 @@ extern "C" int nr_launch_groupnorm(NrGnParams* pp, hipStream_t stream) {
   if (C % 8 != 0 || C % p.groups != 0 || p.groups > 64) return 1;
   if (p.x1 && p.c0 % 8 != 0) return 2;
   {
+    // register-resident slab version: one read + one write (see gn_slab_kernel).  Needs >= 8 channels per group (a 16-byte chunk
+    // then touches at most two groups), 16-byte aligned slabs and concat split, and a slab of <= 512 x 32 chunks.
+    const int cg = C / p.groups;
+    static const bool noslab = getenv("NR_GN_SLAB") != nullptr && atoi(getenv("NR_GN_SLAB")) == 0;
+    if (!noslab && cg >= 8 && cg % 2 == 0 && p.c0 % 8 == 0 && p.ld0 % 8 == 0 && (p.c1 == 0 || p.ld1 % 8 == 0) && p.ldo % 8 == 0) {
+      int GS = 0;
+      for (int g = 1; g <= 8 && g <= p.groups; g *= 2) {            // smallest set whose span is a whole number of chunks
+        if (p.groups % g == 0 && (g * cg) % 8 == 0 && g * cg / 8 <= 64) { GS = g; break; }
+      }
+      // widen the slab (better line use) while the chip stays filled and the registers suffice
+      while (GS && GS * 2 <= 8 && p.groups % (GS * 2) == 0 && GS * 2 * cg / 8 <= 64 &&
+             (long long)p.nimg * (p.groups / (GS * 2)) >= 256 &&
+             ((long long)p.hw + (512 / (GS * 2 * cg / 8)) - 1) / (512 / (GS * 2 * cg / 8)) <= 32) GS *= 2;
+      if (GS && p.hw > 64) {       // hw <= 64: the one-workgroup-per-group kernel below is as fast or faster (measured, tools/gn_ab.sh)
+        const int cpp = GS * cg / 8;
+        static const int tforce = getenv("NR_GN_T") ? atoi(getenv("NR_GN_T")) : 0;
+        // 1024 threads (4 waves per SIMD) when a 512-thread workgroup would hold more than 4 chunks per thread
+        const int T = tforce ? tforce : ((p.hw + 512 / cpp - 1) / (512 / cpp) > 4 ? 1024 : 512);
+        const int NPL = T / cpp;
+        const int nv = (p.hw + NPL - 1) / NPL;
+        const unsigned grid = (unsigned)(p.nimg * (p.groups / GS));
+#define NR_GN_SLAB(NVV)                                                                                                  \
+  do {                                                                                                                   \
+    if (T == 1024) hipLaunchKernelGGL((gn_slab_kernel<NVV, 1024>), dim3(grid), dim3(1024), 0, stream, p, GS);            \
+    else hipLaunchKernelGGL((gn_slab_kernel<NVV, 512>), dim3(grid), dim3(512), 0, stream, p, GS);                        \
+    return 0;                                                                                                            \
+  } while (0)
+        if (nv <= 2) NR_GN_SLAB(2);
+        else if (nv <= 4) NR_GN_SLAB(4);
+        else if (nv <= 8) NR_GN_SLAB(8);
+        else if (nv <= 12) NR_GN_SLAB(12);
+        else if (nv <= 16) NR_GN_SLAB(16);
+        else if (nv <= 24 && T == 512) NR_GN_SLAB(24);
+        else if (nv <= 32 && T == 512) NR_GN_SLAB(32);
+#undef NR_GN_SLAB
+      }
+    }
+  }
+  {
     // small images: single fused launch (needs an even channels-per-group and an even split point of the concat)
     const int cg = C / p.groups;
     const long long pairs = (long long)p.hw * (cg / 2);
-    static const bool nofuse = getenv("NR_GN_NOFUSE") != nullptr;
-    if (!nofuse && p.hw <= 64 && cg % 2 == 0 && p.c0 % 2 == 0 && pairs <= 256LL * 48) {
+    if (p.hw <= 64 && cg % 2 == 0 && p.c0 % 2 == 0 && pairs <= 256LL * 48) {
       dim3 grid(p.groups, p.nimg);
-      static const bool acq = getenv("NR_GN_DBG") != nullptr;
-      if (acq) p.finalized = 77;
       if (pairs <= 256LL * 8) hipLaunchKernelGGL((gn_fused_small_kernel<8>), grid, dim3(256), 0, stream, p);
       else if (pairs <= 256LL * 16) hipLaunchKernelGGL((gn_fused_small_kernel<16>), grid, dim3(256), 0, stream, p);
       else hipLaunchKernelGGL((gn_fused_small_kernel<48>), grid, dim3(256), 0, stream, p);

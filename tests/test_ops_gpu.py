@@ -95,7 +95,13 @@ def test_conv3x3_concat_temb_res(cuda):
 
 @pytest.mark.parametrize("nimg,H,W,c0,c1,silu,eps", [
     (4, 32, 32, 320, 0, True, 1e-5), (4, 8, 8, 1280, 640, True, 1e-5), (2, 4, 4, 1280, 1280, False, 1e-6),
-    (3, 6, 10, 64, 0, False, 1e-6), (2, 16, 16, 640, 320, True, 1e-5), (3, 2, 2, 128, 64, True, 1e-5)])
+    (3, 6, 10, 64, 0, False, 1e-6), (2, 16, 16, 640, 320, True, 1e-5), (3, 2, 2, 128, 64, True, 1e-5),
+    # the register-resident slab kernel at the shapes of BASELINE config 2 (32 images): 10/20/30/40/60/80 channels per group,
+    # concat split inside a slab (1280+640, 640+320), and shapes beyond its register budget (64x64 x 2 images: chunked path)
+    (32, 32, 32, 320, 0, True, 1e-5), (32, 32, 32, 640, 320, True, 1e-5), (32, 32, 32, 320, 320, True, 1e-5),
+    (32, 16, 16, 640, 0, True, 1e-5), (32, 16, 16, 1280, 640, True, 1e-5), (32, 16, 16, 320, 0, False, 1e-5),
+    (32, 8, 8, 1280, 1280, True, 1e-5), (32, 4, 4, 1280, 0, True, 1e-6), (2, 64, 64, 320, 0, True, 1e-5), (5, 24, 24, 640, 0, True, 1e-5),
+    (7, 12, 12, 1280, 0, False, 1e-5)])
 def test_groupnorm(cuda, nimg, H, W, c0, c1, silu, eps):
     from neurons_amd import ops
     torch.manual_seed(4)
