@@ -514,6 +514,12 @@ Plan choose_plan(const NrGemmParams& p) {
     pl.bm = 128; pl.bn = 160; pl.splitk = 2;
     return pl;
   }
+  // folded FeedForward.net.2 + proj_out GEMMs (K = 5C = 6400) at the 8x8 level: same as the long-K convs above (tools/sweep_ff.sh:
+  // 46.6 vs 55.2 us)
+  if (!p.geglu && p.ksize == 1 && p.M <= 2048 && p.M > 512 && nk >= 96 && p.N % 160 == 0) {
+    pl.bm = 128; pl.bn = 160; pl.splitk = 4;
+    return pl;
+  }
   const bool n128 = p.N % 128 == 0 || p.N >= 960;          // <= 6 % padded columns otherwise
   if (!p.geglu && p.N % 160 == 0 && p.N < 960 && p.N % 128 != 0 && nk >= 20 && nblk(128, 160) >= 256) { pl.bm = 128; pl.bn = 160; }
   else if (n128 && nblk(128, 128) >= 400) { pl.bm = 128; pl.bn = 128; pl.waves = 8; }
@@ -527,6 +533,10 @@ Plan choose_plan(const NrGemmParams& p) {
   static const bool smallm_rule = !(getenv("NR_IGEMM_SMALLM") && getenv("NR_IGEMM_SMALLM")[0] == '0');   // A/B switch
   if (smallm_rule && p.ksize == 1 && p.M <= 512 && nk >= 8) {
     pl.bm = 64; pl.bn = p.geglu ? 64 : 32; pl.waves = 4; pl.stages = 4;
+    // wide GEGLU projections (N = 10240): enough 128x128 tiles for the chip, 22.4 vs 29.9 us; K = 6400 (folded net.2 + proj_out):
+    // 64x64 tiles with four K slices, 23.1 vs 29.6 us (tools/sweep_ff.sh)
+    if (p.geglu && p.N >= 8192 && p.M >= 256) { pl.bm = 128; pl.bn = 128; pl.waves = 8; pl.stages = 2; }
+    else if (!p.geglu && nk >= 96 && !p.ln_c) { pl.bm = 64; pl.bn = 64; pl.stages = 2; pl.splitk = 4; return pl; }
   }
   if (!p.geglu) {
     const long long tiles = nblk(pl.bm, pl.bn);

@@ -485,8 +485,8 @@ extern "C" int nr_launch_groupnorm(NrGnParams* pp, hipStream_t stream) {
       if (GS && p.hw > 64) {       // hw <= 64: the one-workgroup-per-group kernel below is as fast or faster (measured, tools/gn_ab.sh)
         const int cpp = GS * cg / 8;
         static const int tforce = getenv("NR_GN_T") ? atoi(getenv("NR_GN_T")) : 0;
-        // 1024 threads (4 waves per SIMD) when a 512-thread workgroup would hold more than 4 chunks per thread
-        const int T = tforce ? tforce : ((p.hw + 512 / cpp - 1) / (512 / cpp) > 4 ? 1024 : 512);
+        // 512 threads (2 waves per SIMD); NR_GN_T=1024 measured 3-6 % slower at every shape of config 2 (tools/gn_ab.sh)
+        const int T = tforce == 1024 ? 1024 : 512;
         const int NPL = T / cpp;
         const int nv = (p.hw + NPL - 1) / NPL;
         const unsigned grid = (unsigned)(p.nimg * (p.groups / GS));

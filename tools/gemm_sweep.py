@@ -28,6 +28,9 @@ CONFIGS = ["-1,-1,-1,2,-1,4", "128,128,1,2,-1,4", "128,128,1,2,-1,8", "128,64,1,
 CONFIGS += ["128,128,1,4,-1,8", "128,64,1,4,-1,8", "128,64,1,4,-1,4", "64,64,1,4,-1,4", "256,128,1,3,-1,8", "128,160,1,3,-1,4", "128,128,1,3,-1,4",
             "128,64,2,3,-1,8", "128,64,4,3,-1,8", "64,64,4,3,-1,4", "64,64,2,4,-1,4", "64,64,4,4,-1,4", "128,64,2,4,-1,4", "128,64,4,4,-1,4",
             "256,128,2,3,-1,8", "128,160,2,3,-1,4", "128,160,4,3,-1,4", "128,160,8,3,-1,4", "128,160,4,2,-1,4", "128,160,8,2,-1,4"]
+if os.environ.get("SWEEP_SET") == "ff":   # GEGLU projections and the folded net.2 + proj_out GEMMs (K = 5C)
+    SHAPES = [("geglu", 32768, 2560, 320, False), ("geglu", 8192, 5120, 640, False), ("geglu", 2048, 10240, 1280, False), ("geglu", 512, 10240, 1280, False),
+              ("lin", 32768, 320, 1600, True), ("lin", 8192, 640, 3200, True), ("lin", 2048, 1280, 6400, True), ("lin", 512, 1280, 6400, True)]
 if os.environ.get("SWEEP_CONFIGS"):      # e.g. SWEEP_CONFIGS="256,128,1,2,-1,4;256,160,1,2,-1,4"
     CONFIGS = ["-1,-1,-1,2,-1,4"] + os.environ["SWEEP_CONFIGS"].split(";")
 if os.environ.get("SWEEP_EXTRA"):        # extra shapes for the VAE: "conv:16,128,128,256,256,0;lin:8192,640,2560,1"
@@ -53,15 +56,16 @@ def bench(fn, iters=20):
 
 for sh in SHAPES:
     kind = sh[0]
-    if kind == "lin":
+    if kind in ("lin", "geglu"):
         _, M, N, K, res = sh
         a = torch.randn(M, K, device=dev).to(torch.bfloat16)
         w = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
         b = torch.randn(N, device=dev)
         r = torch.randn(M, N, device=dev).to(torch.bfloat16) if res else None
-        fn = lambda: ops.gemm(a, w, b, r)
+        gg = kind == "geglu"
+        fn = lambda: ops.gemm(a, w, b, r, geglu=gg)
         flops = 2.0 * M * N * K
-        name = f"lin  M={M} N={N} K={K} res={int(res)}"
+        name = f"{kind:5s}M={M} N={N} K={K} res={int(res)}"
     else:
         _, (nimg, H, W), N, Cin, res = sh
         x = torch.randn(nimg, H, W, Cin, device=dev).to(torch.bfloat16)

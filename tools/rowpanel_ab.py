@@ -32,12 +32,16 @@ def main():
         a = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16)
         gamma, beta = torch.ones(K, device=dev), torch.zeros(K, device=dev)
         for name, N, ln, geglu, res in (("square+res", 320, False, False, True), ("square", 320, False, False, False), ("q (ln)", 320, True, False, False),
-                                        ("qkv (ln)", 960, True, False, False), ("ff1 geglu (ln)", 2560, True, True, False)):
+                                        ("qkv (ln)", 960, True, False, False), ("qkv", 960, False, False, False),
+                                        ("ff1 geglu (ln)", 2560, True, True, False), ("ff1 geglu", 2560, False, True, False)):
             w = (torch.randn(N, K, generator=g, device=dev) * K ** -0.5)
             wb = w.to(torch.bfloat16)
             bias = torch.randn(N, device=dev)
             r = torch.randn(M, N, generator=g, device=dev).to(torch.bfloat16) if res else None
-            if geglu:
+            if geglu and not ln:
+                wp, bp = ops.geglu_permute(wb, bias)
+                fn = lambda: ops.gemm(a, wp, bp, geglu=True)
+            elif geglu:
                 wp, bp = ops.geglu_permute(wb, bias)
                 if rp:
                     # folded LN on the permuted weight
