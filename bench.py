@@ -33,6 +33,9 @@ PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
 
+CURRENT_ROUND = "r02"      # a committed traffic file of an earlier round is reported as historical
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,7 +133,8 @@ def keyframe_main(args):
         sd[k] = z.cpu()
     net = NativeSGMUNet(cfg).to(dev)
     net.load_state_dict(sd)
-    del sd
+    if args.no_cpu_baseline:
+        del sd
     L = args.keyframe_latent
     sampler = EulerEDMSampler(num_steps=args.keyframe_steps, scale=5.0)
     items = []
@@ -148,7 +152,25 @@ def keyframe_main(args):
     el = time.perf_counter() - t1
     p = net.profile_last()
     ig = p["igemm"]
-    print(json.dumps({
+    cpu = None
+    if not args.no_cpu_baseline:
+        # the oracle's UNetModel forward (fp32, eager) on the host cores: ONE full Euler step of this configuration (CFG batch of 2),
+        # scaled by the step count only
+        from oracle import sgm_oracle as S
+        it = items[-1]
+        x2 = torch.cat([it["z"], it["z"]]).cpu()
+        ctx2 = torch.cat([it["uc"]["crossattn"], it["c"]["crossattn"]]).cpu()
+        y2 = torch.cat([it["uc"]["vector"], it["c"]["vector"]]).cpu()
+        ts = torch.full((2,), 500.0)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            S.unet_forward(sd, cfg, x2, ts, ctx2, y2)
+            dt = time.perf_counter() - t0
+        cpu = {"value": round(1.0 / (dt * args.keyframe_steps), 5), "unit": "keyframes/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"one full Euler step (oracle/sgm_oracle.py unet_forward, CFG batch 2, ({L},{L}) latent, context 256x1664) = {dt:.1f} s, "
+                         f"x {args.keyframe_steps} steps"}
+        del sd
+    res = {
         "metric": "unCLIP keyframes/sec (sgm UNetModel, Euler-EDM, CFG 5.0)", "value": round(args.steps / el, 4), "unit": "keyframes/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -158,7 +180,12 @@ def keyframe_main(args):
         "roofline": {"bound": "mfma", "kernel": "igemm_bf16_kernel", "achieved": round(ig["flops"] / (ig["ms"] * 1e-3) / 1e12, 2),
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ig["flops"] / (ig["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                      "traffic": None, "per_class_ms_per_step": {k: round(v["ms"], 3) for k, v in p.items()},
-                     "algorithmic_tflop_per_step": round(sum(v["flops"] for v in p.values()) / 1e12, 3)}}))
+                     "launches_per_step": int(sum(v["launches"] for v in p.values())),
+                     "algorithmic_gbytes_per_step": round(sum(v["bytes"] for v in p.values()) / 1e9, 2),
+                     "algorithmic_tflop_per_step": round(sum(v["flops"] for v in p.values()) / 1e12, 3)}}
+    if cpu:
+        res["cpu_baseline"] = cpu
+    print(json.dumps(res))
 
 
 from neurons_amd.synth import gpu_random_state_dict  # noqa: E402
@@ -293,6 +320,7 @@ def main():
                          "traffic_detail": pmc_traffic() if headline else None,
                          "algorithmic_gbytes_per_ddim_step": round((pu["igemm"]["bytes"] + pc["igemm"]["bytes"]) / 1e9, 2),
                          "launches_per_ddim_step": ig_n, "ms_per_ddim_step": round(ig_ms, 3),
+                         "whole_step_launches": int(sum(pu[k]["launches"] + pc[k]["launches"] for k in pu)),
                          "algorithmic_tflop_per_ddim_step": round(ig_fl / 1e12, 3),
                          "per_class_ms_per_ddim_step": breakdown,
                          "whole_step_algorithmic": {"tflop": round(step_flops / 1e12, 3), "gbytes": round(step_bytes / 1e9, 2)}},
@@ -379,7 +407,7 @@ def pmc_traffic():
     name = os.path.basename(files[-1])
     return {"igemm_hbm_gbytes_per_ddim_step": round(d["igemm_hbm_bytes_per_ddim_step"] / 1e9, 2),
             "whole_step_hbm_gbytes": round(d["whole_step_hbm_bytes"] / 1e9, 2), "source": name,
-            "traffic_source_round": name.split("_")[0], "historical": True}
+            "traffic_source_round": name.split("_")[0], "historical": name.split("_")[0] != CURRENT_ROUND}
 
 
 def cpu_baseline(host_sd, ucfg, ccfg, args):

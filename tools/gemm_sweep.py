@@ -31,6 +31,13 @@ CONFIGS += ["128,128,1,4,-1,8", "128,64,1,4,-1,8", "128,64,1,4,-1,4", "64,64,1,4
 if os.environ.get("SWEEP_SET") == "ff":   # GEGLU projections and the folded net.2 + proj_out GEMMs (K = 5C)
     SHAPES = [("geglu", 32768, 2560, 320, False), ("geglu", 8192, 5120, 640, False), ("geglu", 2048, 10240, 1280, False), ("geglu", 512, 10240, 1280, False),
               ("lin", 32768, 320, 1600, True), ("lin", 8192, 640, 3200, True), ("lin", 2048, 1280, 6400, True), ("lin", 512, 1280, 6400, True)]
+if os.environ.get("SWEEP_SET") == "order":   # tile-order sweep (5th field: 0 n-fastest, 1 m-fastest, G >= 2 grouped) on the shapes whose weights exceed one L2
+    SHAPES = [("geglu", 8192, 5120, 640, False), ("lin", 8192, 1920, 640, False), ("lin", 8192, 640, 3200, True), ("lin", 8192, 640, 640, True),
+              ("geglu", 2048, 10240, 1280, False), ("lin", 2048, 3840, 1280, False), ("lin", 2048, 1280, 1280, True), ("lin", 2048, 1280, 6400, True),
+              ("geglu", 32768, 2560, 320, False), ("lin", 32768, 320, 1600, True),
+              ("conv", (32, 32, 32), 320, 320, True), ("conv", (32, 16, 16), 640, 640, True), ("conv", (32, 8, 8), 1280, 1280, True),
+              ("conv", (32, 16, 16), 640, 1920, False), ("conv", (32, 32, 32), 320, 960, False)]
+    CONFIGS = ["-1,-1,-1,-1,-1,-1"] + [f"-1,-1,-1,-1,{o},-1" for o in (0, 1, 2, 4, 8, 16)]
 if os.environ.get("SWEEP_CONFIGS"):      # e.g. SWEEP_CONFIGS="256,128,1,2,-1,4;256,160,1,2,-1,4"
     CONFIGS = ["-1,-1,-1,2,-1,4"] + os.environ["SWEEP_CONFIGS"].split(";")
 if os.environ.get("SWEEP_EXTRA"):        # extra shapes for the VAE: "conv:16,128,128,256,256,0;lin:8192,640,2560,1"
@@ -90,5 +97,5 @@ for sh in SHAPES:
     os.environ.pop("NR_IGEMM_FORCE", None)
     base = bench(fn)
     results.sort()
-    best = ", ".join(f"[{c}] {ms*1e3:.1f}us {flops/ms/1e9:.0f}TF" for ms, c in results[:4])
+    best = ", ".join(f"[{c}] {ms*1e3:.1f}us {flops/ms/1e9:.0f}TF" for ms, c in results[:8])
     print(f"{name:42s} heuristic {base*1e3:7.1f}us {flops/base/1e9:5.0f}TF | best: {best}", flush=True)
