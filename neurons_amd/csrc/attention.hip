@@ -191,15 +191,38 @@ __device__ __forceinline__ long to_fp8x8(const float (&v)[8]) {
 // registers (Q, K, V from their bf16 tiles; P straight from its fp32 exponentials, scaled by 256 so the probabilities use the
 // e4m3 normal range, and the sum divided back in fp32); softmax statistics and accumulators stay fp32.  The non-scaled fp8 MFMA
 // issues at the bf16 rate (MI355X_MICROARCH.md), so this variant is about the numerics of config 5, not about speed.
+// max / sum over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) on the VALU: v_permlane16_swap exchanges the odd rows of
+// its first operand with the even rows of its second, v_permlane32_swap the upper half of the first with the lower half of the second;
+// with both operands = v every lane gets {own, partner} in the two results (a ds_bpermute round trip through the LDS otherwise).
+__device__ __forceinline__ float rows_max(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows_sum(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// LDS images of a 64-key tile.  K (d <= 64): [64][64] bf16, 128-byte rows with the 16-byte chunk index XOR-swizzled by (key & 7): the
+// b128 fragment reads (lane = key 16t + c, chunk 4ks + g) are conflict-free, the layout gemm.hip uses for its operand tiles; larger
+// heads keep padded rows of 32 DK + 8 elements.  V: rows of KSV elements with KSV = 16 (mod 32), so the 8 rows a half-wave touches in
+// one ds_read_b64_tr_b16 start 8 banks apart (conflict-free transpose reads).  Pad columns are zero (written once).
 template <int DK, int DT, bool FP8 = false>
-__global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p, int KS) {
+__global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p) {
+  constexpr bool KSWZ = DK <= 2;
+  constexpr int KSK = KSWZ ? 64 : DK * 32 + 8;
+  constexpr int KSV = (DT * 16) % 32 == 16 ? DT * 16 : DT * 16 + 16;
   constexpr int CH = (DT + 1) / 2;            // 16-B chunks per thread per matrix per tile
   extern __shared__ __attribute__((aligned(16))) bf16 lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const int TILE = KT2 * KS;                  // elements per matrix per buffer
+  constexpr int TILEK = KT2 * KSK, TILEV = KT2 * KSV, TILE2 = TILEK + TILEV;   // elements per buffer
   const int qblocks = (p.Lq + 63) >> 6;
   const int qb = blockIdx.x % qblocks;
   const int h = (blockIdx.x / qblocks) % p.heads;
@@ -227,32 +250,48 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p, in
   const int cpk = p.d >> 3;                   // chunks per key row
   const int nchunk = KT2 * cpk;
   bf16x8 rk[CH], rv[CH];
-  auto load_regs = [&](int k0) {
+  // staging addresses: each thread owns CH fixed (key-in-tile, 16-byte chunk) slots, so its K / V source pointers just advance by one
+  // tile per iteration; only the last, partial tile clamps the key (the clamped rows are finite data that the softmax masks out)
+  int s_kk[CH];
+  const bf16* s_kp[CH];
+  const bf16* s_vp[CH];
+  int s_lok[CH], s_lov[CH];                   // LDS element offsets of the slot in the K / V image
 #pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int id = tid + 256 * i;
-      rk[i] = zero8; rv[i] = zero8;
-      if (id < nchunk) {
-        const int kk = id / cpk, x0 = (id - kk * cpk) << 3;
-        const int key = k0 + kk;
-        if (key < p.Lk) {
-          const long long off = kbase + (long long)key * p.kv_seq + x0;
-          rk[i] = *(const bf16x8*)(p.k + off);
-          rv[i] = *(const bf16x8*)(p.v + off);
-        }
+  for (int i = 0; i < CH; ++i) {
+    const int id = min(tid + 256 * i, nchunk - 1);
+    const int kk = id / cpk, x0 = (id - kk * cpk) << 3;
+    s_kk[i] = kk;
+    s_lok[i] = KSWZ ? kk * KSK + ((((x0 >> 3) ^ (kk & 7))) << 3) : kk * KSK + x0;
+    s_lov[i] = kk * KSV + x0;
+    const long long off = kbase + (long long)kk * p.kv_seq + x0;
+    s_kp[i] = p.k + off;
+    s_vp[i] = p.v + off;
+  }
+  const long long tile_step = (long long)KT2 * p.kv_seq;
+  auto load_regs = [&](int k0) {
+    if (k0 + KT2 <= p.Lk) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        rk[i] = *(const bf16x8*)(s_kp[i] + (long long)(k0 / KT2) * tile_step);
+        rv[i] = *(const bf16x8*)(s_vp[i] + (long long)(k0 / KT2) * tile_step);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const long long back = (long long)max(k0 + s_kk[i] - (p.Lk - 1), 0) * p.kv_seq;
+        rk[i] = *(const bf16x8*)(s_kp[i] + (long long)(k0 / KT2) * tile_step - back);
+        rv[i] = *(const bf16x8*)(s_vp[i] + (long long)(k0 / KT2) * tile_step - back);
       }
     }
   };
   auto write_lds = [&](int buf) {
-    bf16* sk = lds + buf * 2 * TILE;
-    bf16* sv = sk + TILE;
+    bf16* sk = lds + buf * TILE2;
+    bf16* sv = sk + TILEK;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-      const int id = tid + 256 * i;
-      if (id < nchunk) {
-        const int kk = id / cpk, x0 = (id - kk * cpk) << 3;
-        *(bf16x8*)(sk + kk * KS + x0) = rk[i];
-        *(bf16x8*)(sv + kk * KS + x0) = rv[i];
+      if (tid + 256 * i < nchunk) {
+        *(bf16x8*)(sk + s_lok[i]) = rk[i];
+        *(bf16x8*)(sv + s_lov[i]) = rv[i];
       }
     }
   };
@@ -262,54 +301,61 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p, in
   for (int i = 0; i < DT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_i = -1e30f, l_i = 0.f;
 
+  // every pad column of the K / V images is zero in both buffers (whole images cleared once, the staging only writes the d data
+  // columns): the fragment reads below need no head-dim predicate (a predicated 16-byte LDS read costs an exec-mask branch each)
+  for (int id = tid; id < 2 * TILE2 / 8; id += 256) *(bf16x8*)(lds + id * 8) = zero8;
+  __syncthreads();
   const int ntile = (p.Lk + KT2 - 1) / KT2;
   load_regs(0);
   write_lds(0);
   __syncthreads();
+  // a zero accumulator the compiler cannot rematerialise: it stays in 4 registers instead of 16 v_mov per key tile
+  f32x4 zacc = f32x4{0.f, 0.f, 0.f, 0.f};
+  asm volatile("" : "+v"(zacc));
   const int tq = c >> 2, tp = c & 3;          // transpose-read role inside the 16-lane group
   for (int it = 0; it < ntile; ++it) {
     const int k0 = it * KT2;
     if (it + 1 < ntile) load_regs(k0 + KT2);
-    const bf16* sk = lds + (it & 1) * 2 * TILE;
-    const bf16* sv = sk + TILE;
+    const bf16* sk = lds + (it & 1) * TILE2;
+    const bf16* sv = sk + TILEK;
     // ---- S^T = K Q^T for four 16-key tiles ----
     f32x4 s[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      s[t] = zacc;
 #pragma unroll
       for (int ks = 0; ks < DK; ++ks) {
-        const int dim0 = ks * 32 + g * 8;
-        const bf16x8 kf = dim0 < p.d ? *(const bf16x8*)(sk + (16 * t + c) * KS + dim0) : zero8;
+        const bf16x8 kf = KSWZ ? *(const bf16x8*)(sk + (16 * t + c) * KSK + (((ks * 4 + g) ^ (c & 7)) << 3))
+                               : *(const bf16x8*)(sk + (16 * t + c) * KSK + ks * 32 + g * 8);
         if constexpr (FP8) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(to_fp8x8(kf), qf8[ks], s[t], 0, 0, 0);
         else s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
       }
     }
-    // softmax in the log2 domain: exp(scale*s - m) = exp2(s*scale*log2(e) - m2); one v_exp per score, no extra mul.
+    // softmax in the log2 domain: exp(scale*s - m) = exp2(fma(s, scale*log2(e), -m2)): one fma + one v_exp per score.
     // Full tiles (all 64 keys valid) skip the key-mask selects.
     const float sl2 = p.scale * 1.4426950408889634f;
     const bool full = k0 + KT2 <= p.Lk;
     float mx = -1e30f;
     if (full) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { s[t][r] *= sl2; mx = fmaxf(mx, s[t][r]); }
+      for (int t = 0; t < 4; ++t) mx = fmaxf(fmaxf(mx, fmaxf(s[t][0], s[t][1])), fmaxf(s[t][2], s[t][3]));
     } else {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = k0 + 16 * t + 4 * g + r;
-          const float v = key < p.Lk ? s[t][r] * sl2 : -1e30f;
+          const float v = key < p.Lk ? s[t][r] : -1e30f;
           s[t][r] = v;
           mx = fmaxf(mx, v);
         }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_i, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
+    mx = rows_max(mx) * sl2;                   // sl2 > 0: the max of the scaled scores
+    // Lazy running maximum: the reference maximum of a query only moves when the tile's maximum exceeds it by more than 2^8, so the
+    // probabilities stay <= 256 (exact in the fp32 sums, in range for bf16 / scaled e4m3) and the accumulator rescale, which costs a
+    // register round trip of the whole O tile, runs on the first tile and then almost never (wave-uniform skip).
+    constexpr float LAZY = FP8 ? 0.0f : 8.0f;  // e4m3 probabilities keep the exact running maximum (P <= 1, scaled by 256 below)
+    const float m_new = mx > m_i + LAZY ? mx : m_i;
     float rs = 0.f;
     bf16x8 pf[2];
     float pe[2][8];
@@ -317,27 +363,30 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p, in
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = __builtin_amdgcn_exp2f(s[t][r] - m_new);   // masked keys: exp2(-1e30 - m) = 0
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], sl2, -m_new));   // masked keys: exp2(-huge) = 0
         rs += e;
         if constexpr (FP8) pe[t >> 1][(t & 1) * 4 + r] = e * 256.0f;
         else pf[t >> 1][(t & 1) * 4 + r] = (bf16)e;
       }
     long pf8[2];
     if constexpr (FP8) { pf8[0] = to_fp8x8(pe[0]); pf8[1] = to_fp8x8(pe[1]); }
-    rs += __shfl_xor(rs, 16, 64);
-    rs += __shfl_xor(rs, 32, 64);
-    l_i = l_i * alpha + rs;
-    m_i = m_new;
+    // l_i stays a per-lane partial sum (this lane's 16 keys of every tile); the four rows are added once after the loop
+    if (__builtin_amdgcn_ballot_w64(m_new != m_i) != 0ull) {
+      const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
+      l_i *= alpha;
 #pragma unroll
-    for (int i = 0; i < DT; ++i) acc[i] *= alpha;
+      for (int i = 0; i < DT; ++i) acc[i] *= alpha;
+      m_i = m_new;
+    }
+    l_i += rs;
     // ---- O^T += V^T P^T ; k-slot j of step u -> key 32u + (j<4 ? 4g+j : 16+4g+j-4) ----
 #pragma unroll
     for (int i = 0; i < DT; ++i) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const bf16* a0 = sv + (32 * u + 4 * g + tq) * KS + 16 * i + 4 * tp;
+        const bf16* a0 = sv + (32 * u + 4 * g + tq) * KSV + 16 * i + 4 * tp;
         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a0);
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0 + 16 * KS));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0 + 16 * KSV));
         bf16x8 vf;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
@@ -349,8 +398,9 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p, in
     __syncthreads();
   }
 
+  const float l_all = rows_sum(l_i);          // all lanes active here
   if (qrow < p.Lq) {
-    const float inv = (FP8 ? 1.0f / 256.0f : 1.0f) / l_i;
+    const float inv = (FP8 ? 1.0f / 256.0f : 1.0f) / l_all;
     bf16* op = p.out + obase + (long long)qrow * p.o_seq;
 #pragma unroll
     for (int i = 0; i < DT; ++i) {
@@ -369,10 +419,9 @@ template <int DK, int DT>
 int launch_attn(const NrAttnParams& p, hipStream_t stream) {
   if (p.Lq >= 48 && p.inner == 1 && !p.causal) {   // causal masking lives in the per-wave kernel only
     // long sequences: block-shared K/V tiles
-    int u = p.d / 8;                       // row stride in 16-byte units, forced odd (bank-conflict-free b128 reads)
-    if ((u & 1) == 0) u += 1;
-    const int KS = u * 8;
-    const size_t shm = (size_t)2 * 2 * KT2 * KS * sizeof(bf16) + 256;
+    constexpr int KSK = DK <= 2 ? 64 : DK * 32 + 8;                              // as in the kernel
+    constexpr int KSV = (DT * 16) % 32 == 16 ? DT * 16 : DT * 16 + 16;
+    const size_t shm = (size_t)2 * KT2 * (KSK + KSV) * sizeof(bf16);
     static unsigned long long attr_mask = 0;       // per device
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -383,8 +432,8 @@ int launch_attn(const NrAttnParams& p, hipStream_t stream) {
     }
     const int qblocks = (p.Lq + 63) / 64;
     const unsigned blocks = (unsigned)((long long)p.nbatch * p.heads * qblocks);
-    if (p.fp8) hipLaunchKernelGGL((attn_fwd_shared_kernel<DK, DT, true>), dim3(blocks), dim3(256), shm, stream, p, KS);
-    else hipLaunchKernelGGL((attn_fwd_shared_kernel<DK, DT, false>), dim3(blocks), dim3(256), shm, stream, p, KS);
+    if (p.fp8) hipLaunchKernelGGL((attn_fwd_shared_kernel<DK, DT, true>), dim3(blocks), dim3(256), shm, stream, p);
+    else hipLaunchKernelGGL((attn_fwd_shared_kernel<DK, DT, false>), dim3(blocks), dim3(256), shm, stream, p);
     return 0;
   }
   const int qtiles = (p.Lq + 15) / 16;
