@@ -234,6 +234,23 @@ typedef struct nr_profile {
  * launch, and reports per-kernel-class totals (bench.py's roofline object). */
 nr_status nr_net_profile_last(nr_net* h, nr_stream stream, nr_profile* out);
 
+/* ---- grouped SparseCtrl schedule (pipeline_neuroclips.py:460-475 evaluated G steps at a time) --------------------------------------
+ * With set_noisy_sample_input_to_zero (sparse_controlnet.py:469-470: the NEURONS configuration) SparseCtrl sees the timestep, the text
+ * context and the condition, nothing of the denoising state, so its evaluations for G consecutive DDIM steps can run as ONE forward on a
+ * handle planned for G x (CFG batch) samples, ahead of the U-Net steps that consume them.
+ * nr_sparsectrl_forward_async: like nr_sparsectrl_forward (no `sample`), but on the handle's own stream and NOT joined to `stream`: it
+ *   starts after the work already enqueued on `stream` and records its completion in event slot `slot` (0 or 1).  timesteps: one per
+ *   planned sample.  The output buffers must stay untouched until a consumer has waited for the slot.
+ * nr_unet3d_forward_after: nr_unet3d_forward with residuals, whose residual adds wait for slot `slot` of `ctrl`; the encoder and mid
+ *   block run while the SparseCtrl evaluation is still pending.  down_res_dev / mid_res_dev: the slices of the group's outputs that
+ *   belong to this step (batch-major buffers: step p of the group starts at sample p x CFG batch). */
+nr_status nr_sparsectrl_forward_async(nr_net* ctrl, nr_stream stream, const float* timesteps, const float* ctx_dev, int32_t ctx_len,
+                                      const float* cond_dev, const float* mask_dev, int32_t cond_batch, float scale,
+                                      void* const* out_down_dev, void* out_mid_dev, int32_t slot);
+nr_status nr_unet3d_forward_after(nr_net* unet, nr_net* ctrl, int32_t slot, nr_stream stream, const float* sample_dev,
+                                  const float* timesteps, const float* ctx_dev, int32_t ctx_len, const void* const* down_res_dev,
+                                  const void* mid_res_dev, float* out_dev);
+
 /* BASELINE config 5: run the spatial self- and text cross-attention cores (motion_module_new.py:258-287) with OCP e4m3 MFMA
  * operands (fp32 softmax statistics and accumulation).  Off by default (bf16); changing it invalidates the plan. */
 nr_status nr_net_set_attention_fp8(nr_net* h, int32_t enable);

@@ -76,6 +76,8 @@ SYMBOLS = {
     "nr_unet3d_forward": (_I32, [_VP, _VP, _VP, _FP, _VP, _I32, C.POINTER(_VP), _VP, _VP]),
     "nr_sparsectrl_forward": (_I32, [_VP, _VP, _VP, _FP, _VP, _I32, _VP, _VP, _I32, C.c_float, C.POINTER(_VP), _VP]),
     "nr_denoise_step_forward": (_I32, [_VP, _VP, _VP, _VP, _FP, _VP, _I32, _VP, _VP, _I32, C.c_float, C.POINTER(_VP), _VP, _VP, _FP]),
+    "nr_sparsectrl_forward_async": (_I32, [_VP, _VP, _FP, _VP, _I32, _VP, _VP, _I32, C.c_float, C.POINTER(_VP), _VP, _I32]),
+    "nr_unet3d_forward_after": (_I32, [_VP, _VP, _I32, _VP, _VP, _FP, _VP, _I32, C.POINTER(_VP), _VP, _VP]),
     "nr_sgm_unet_forward": (_I32, [_VP, _VP, _VP, C.c_float, _FP, _VP, _I32, _VP, _VP]),
     "nr_vae_decode": (_I32, [_VP, _VP, _VP, C.c_float, C.c_float, C.c_float, _I32, _VP]),
     "nr_clip_text_forward": (_I32, [_VP, _VP, _VP, _VP]),

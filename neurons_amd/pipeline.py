@@ -61,9 +61,14 @@ class NeuroclipsPipeline:
         self._progress_bar_config = {}
         self._device = torch.device("cpu")
         self.overlap_controlnet = True   # run SparseCtrl concurrently with the U-Net encoder (nr_denoise_step_forward)
-        # issue step i+1's SparseCtrl evaluation during step i's decoder (results identical).  Measured neutral on
-        # MI355X (14.00 vs 13.97 frames/s: the CUs are already saturated by the encoder overlap), so off by default
+        # issue step i+1's SparseCtrl evaluation during step i's decoder (results identical).  Measured +0.2 % (round 1: 14.00 vs
+        # 13.97 frames/s) and +0.5 % (round 2: 16.15 / 16.17 vs 16.08) on MI355X: the CUs are already saturated by the encoder
+        # overlap, so off by default (NR_PREFETCH=1 turns it on)
         self.prefetch_controlnet = os.environ.get("NR_PREFETCH") == "1"
+        # SparseCtrl evaluations of `controlnet_group` consecutive DDIM steps run as ONE forward on a `group` x larger batch, one group
+        # ahead of the U-Net steps that consume them (the network sees timestep, context and condition only, not the latents:
+        # set_noisy_sample_input_to_zero).  Same 50 evaluations, better GEMM shapes; 1 = one evaluation per step (nr_denoise_step_forward)
+        self.controlnet_group = int(os.environ.get("NR_CTRL_GROUP", "4"))
 
     # ---- DiffusionPipeline surface used by the scripts (SURVEY §8c "Python harness rows") ----
     def register_modules(self, **kwargs):
@@ -260,14 +265,38 @@ class NeuroclipsPipeline:
 
         lib = _lib.load()
         n_lat = latents.numel()
+        fused = use_ctrl and hasattr(self.unet, "forward_with_controlnet") and \
+            getattr(self.controlnet, "set_noisy_sample_input_to_zero", False) and self.overlap_controlnet
+        # grouped schedule: G steps per SparseCtrl evaluation, at most 16 samples per evaluation (engine limit)
+        b2 = latents.shape[0] * (2 if do_classifier_free_guidance else 1)
+        G = max(1, min(self.controlnet_group, 16 // b2, len(timesteps_host))) if (fused and hasattr(self.controlnet, "forward_async")) else 1
+        pending = {}
+
+        def launch_group(g):
+            # timesteps of steps g*G .. g*G+G-1 (the tail of the last group repeats the final step: evaluated, never consumed)
+            ts = []
+            for p_ in range(G):
+                tt = timesteps_host[min(g * G + p_, len(timesteps_host) - 1)]
+                ts += [float(tt)] * b2
+            pending[g] = self.controlnet.forward_async(ts, ctx_group, controlnet_cond, controlnet_conditioning_mask,
+                                                       controlnet_conditioning_scale, slot=g % 2)
+
+        if G > 1:
+            ctx_group = text_embeddings.repeat(G, 1, 1)
+            launch_group(0)
         with self.progress_bar(total=num_inference_steps) as progress_bar:
             for i, t in enumerate(timesteps_host):
                 latent_model_input = torch.cat([latents] * 2) if do_classifier_free_guidance else latents
                 latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)
                 down_res = mid_res = None
-                fused = use_ctrl and hasattr(self.unet, "forward_with_controlnet") and \
-                    getattr(self.controlnet, "set_noisy_sample_input_to_zero", False) and self.overlap_controlnet
-                if fused:
+                if G > 1:
+                    g, p_ = divmod(i, G)
+                    if p_ == 0 and (g + 1) * G < len(timesteps_host):
+                        launch_group(g + 1)          # runs beside this group's U-Net steps; its buffers were last read in step i - 1
+                        pending.pop(g - 1, None)
+                    noise_pred = self.unet.forward_after(self.controlnet, g % 2, pending[g], p_ * b2, latent_model_input, t,
+                                                         text_embeddings).sample
+                elif fused:
                     # same two network evaluations (:460-475), issued as one library call that overlaps them
                     # the next step's SparseCtrl evaluation (independent of the latents) is issued early
                     t_next = timesteps_host[i + 1] if (i + 1 < len(timesteps_host) and self.prefetch_controlnet) else None
@@ -280,7 +309,7 @@ class NeuroclipsPipeline:
                         latent_model_input, t, encoder_hidden_states=text_embeddings, controlnet_cond=controlnet_cond,
                         conditioning_mask=controlnet_conditioning_mask, conditioning_scale=controlnet_conditioning_scale,
                         guess_mode=False, return_dict=False, **zc)
-                if not fused:
+                if not fused and G == 1:
                     noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=text_embeddings,
                                            down_block_additional_residuals=down_res,
                                            mid_block_additional_residual=mid_res).sample

@@ -128,3 +128,50 @@ class NativeSparseCtrl(_NativeNet):
         return SparseControlNetOutput(down_block_res_samples=down, mid_block_res_sample=mid)
 
     __call__ = forward
+
+    # ---- grouped schedule (C ABI nr_sparsectrl_forward_async; pipeline.py owns the schedule) ---------------------------------------
+    def _residual_set(self, slot):
+        """Output buffers of evaluation slot 0 / 1 (slot 0 = the buffers of the synchronous forward)."""
+        if slot == 0:
+            return self._out_bufs, self._out_ptrs
+        if getattr(self, "_out_bufs2_plan", None) != self._plan_key:
+            self._out_bufs2 = [torch.empty_like(t) for t in self._out_bufs]
+            n = len(self._out_bufs2) - 1
+            self._out_ptrs2 = (C.c_void_p * n)(*[t.data_ptr() for t in self._out_bufs2[:n]])
+            self._out_bufs2_plan = self._plan_key
+        return self._out_bufs2, self._out_ptrs2
+
+    @_on_device
+    def forward_async(self, timesteps, encoder_hidden_states, controlnet_cond, conditioning_mask, conditioning_scale: float = 1.0,
+                      slot: int = 0, frames=None):
+        """Evaluate SparseCtrl for ``len(timesteps)`` samples (several DDIM steps x the CFG batch) on the engine's own stream, without
+        joining the caller's stream.  Valid only with ``set_noisy_sample_input_to_zero`` (the evaluation does not see the latents).
+        Returns the slot's channels-last output buffers ``[(b, f, h, w, C)] * n + [mid]``; consumers wait through
+        ``NativeUNet3D.forward_after(..., slot=slot)``."""
+        if not self.config.set_noisy_sample_input_to_zero:
+            raise NotImplementedError("forward_async requires set_noisy_sample_input_to_zero=True")
+        ctx = encoder_hidden_states
+        b = len(timesteps)
+        cb, _, f, h, w = controlnet_cond.shape
+        if ctx.shape[0] != b or b % cb != 0 or conditioning_mask.shape[0] != cb:
+            raise ValueError("forward_async: context batch must equal len(timesteps); the condition batch must divide it")
+        self._ensure_plan(b, f, h, w, ctx.shape[1])
+        self._set_context(ctx)
+        if self._io_cond is None or self._io_cond.shape[0] != cb:
+            self._io_cond = torch.empty(cb, self.config.conditioning_channels, f, h, w, dtype=torch.float32, device=ctx.device)
+            self._io_mask = torch.empty(cb, 1, f, h, w, dtype=torch.float32, device=ctx.device)
+            self._cond_key = None
+        ckey = (controlnet_cond.data_ptr(), controlnet_cond._version, conditioning_mask.data_ptr(), conditioning_mask._version,
+                tuple(controlnet_cond.shape), self._plan_key)
+        if getattr(self, "_cond_key", None) != ckey:      # staged once per clip: an evaluation in flight may be reading it
+            self._io_cond.copy_(controlnet_cond)
+            self._io_mask.copy_(conditioning_mask)
+            self._cond_key = ckey
+            self._cond_ref = (controlnet_cond, conditioning_mask)
+        bufs, ptrs = self._residual_set(slot)
+        ts = (C.c_float * b)(*[float(t) for t in timesteps])
+        n = len(bufs) - 1
+        _lib.check(_lib.load().nr_sparsectrl_forward_async(
+            self._h, torch.cuda.current_stream().cuda_stream, ts, self._io_ctx.data_ptr(), ctx.shape[1], self._io_cond.data_ptr(),
+            self._io_mask.data_ptr(), cb, float(conditioning_scale), ptrs, bufs[n].data_ptr(), int(slot)))
+        return bufs

@@ -637,6 +637,32 @@ class NativeUNet3D(_NativeNet):
                                                controlnet._out_bufs[n].data_ptr(), self._io_out.data_ptr(), ts_next))
         return UNet3DConditionOutput(sample=self._io_out.clone())
 
+    @_on_device
+    def forward_after(self, controlnet, slot, residual_bufs, sample_index, sample, timestep, encoder_hidden_states):
+        """U-Net evaluation that consumes samples ``[sample_index, sample_index + b)`` of the SparseCtrl evaluation pending in ``slot``
+        (``NativeSparseCtrl.forward_async``): C ABI ``nr_unet3d_forward_after``.  The encoder overlaps the pending evaluation; the
+        residual adds wait for it."""
+        if not sample.is_cuda:
+            raise RuntimeError("forward_after: CUDA (ROCm) tensors required; there is no CPU fallback")
+        b, c, f, h, w = sample.shape
+        ctx = encoder_hidden_states
+        if ctx.shape[0] != b:
+            raise ValueError("encoder_hidden_states batch must equal the sample batch")
+        L = ctx.shape[1]
+        self._ensure_plan(b, f, h, w, L)
+        self._io_sample.copy_(sample)
+        self._set_context(ctx)
+        n = len(residual_bufs) - 1
+        views = [t[sample_index:sample_index + b] for t in residual_bufs]
+        if views[0].shape[0] != b:
+            raise ValueError("the pending SparseCtrl evaluation does not contain the requested samples")
+        ptrs = (C.c_void_p * n)(*[v.data_ptr() for v in views[:n]])
+        ts = self._timesteps_host(timestep, b)
+        _lib.check(_lib.load().nr_unet3d_forward_after(self._h, controlnet._h, int(slot), torch.cuda.current_stream().cuda_stream,
+                                                       self._io_sample.data_ptr(), ts, self._io_ctx.data_ptr(), L, ptrs,
+                                                       views[n].data_ptr(), self._io_out.data_ptr()))
+        return UNet3DConditionOutput(sample=self._io_out.clone())
+
     def _on_plan(self):
         b, f, h, w, L = self._plan_key
         dev = self.device
