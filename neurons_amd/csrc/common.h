@@ -143,3 +143,11 @@ struct NrGnParams {
   int silu;
   bf16* out; int ldo;               // [nimg*hw][ldo]
 };
+
+// in-place residual adds dst[i] += src[i] of up to 16 tensors in ONE launch (the ControlNet residuals, unet.py:422-439)
+struct NrAddMulti {
+  bf16* dst[16];
+  const bf16* src[16];
+  long long n8_end[16];    // exclusive prefix sums of the tensors' sizes in 16-byte units
+  int count;
+};

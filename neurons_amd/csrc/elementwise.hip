@@ -282,6 +282,20 @@ __global__ void add_bf16_kernel(const bf16* __restrict__ a, const bf16* __restri
   ((bf16x8*)out)[i] = o;
 }
 
+__global__ __launch_bounds__(256) void add_bf16_multi_kernel(NrAddMulti p) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.n8_end[p.count - 1]) return;
+  int t = 0;
+#pragma unroll
+  for (int k = 0; k < 15; ++k) t += (k < p.count - 1 && i >= p.n8_end[k]) ? 1 : 0;
+  const long long j = i - (t ? p.n8_end[t - 1] : 0);
+  const bf16x8 va = ((const bf16x8*)p.dst[t])[j], vb = ((const bf16x8*)p.src[t])[j];
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)va[e] + (float)vb[e]);
+  ((bf16x8*)p.dst[t])[j] = o;
+}
+
 // fp32 [rows][C] -> bf16 [rows][C]
 __global__ void f32_to_bf16_kernel(const float* __restrict__ a, bf16* __restrict__ out, long long n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -448,6 +462,13 @@ extern "C" int nr_launch_add_bf16(const bf16* a, const bf16* b, bf16* out, long 
   if (n % 8 != 0) return 1;
   const long long n8 = n / 8;
   hipLaunchKernelGGL(add_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, stream, a, b, out, n8);
+  return 0;
+}
+
+extern "C" int nr_launch_add_bf16_multi(const NrAddMulti* p, hipStream_t stream) {
+  if (p->count <= 0 || p->count > 16) return 1;
+  const long long total = p->n8_end[p->count - 1];
+  hipLaunchKernelGGL(add_bf16_multi_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, *p);
   return 0;
 }
 

@@ -57,6 +57,7 @@ int nr_launch_cfg_ddim_step(const float* eps, const float* x, float* x_out, long
                             float sqrt_at, float sqrt_1mat, float sqrt_ap, float sqrt_1map, hipStream_t stream);
 int nr_launch_add_bf16(const bf16* a, const bf16* b, bf16* out, long long n, hipStream_t stream);
 int nr_launch_f32_to_bf16(const float* a, bf16* out, long long n, hipStream_t stream);
+int nr_launch_add_bf16_multi(const NrAddMulti* p, hipStream_t stream);
 int nr_launch_fold_linear_pair(const float* w2, const float* w1, const float* b2, const float* b1, int C, int J, bf16* wc, float* bc,
                                hipStream_t stream);
 }
@@ -293,7 +294,8 @@ struct nr_net {
   const HostTensor& data_of(const std::string& key) const {
     const HostTensor& t = need(key);
     if ((int64_t)t.data.size() != t.numel())
-      throw NrError(NR_ERR_STATE, "host copy of " + key + " was released; load the state dict again before re-converting");
+      throw NrError(NR_ERR_STATE, "host copy of " + key + " was released after the first plan and this shape needs a conversion that plan did not make; "
+                                  "load the state dict again (or keep the host copies: auto_release_host_weights = False)");
     return t;
   }
 
@@ -1499,22 +1501,41 @@ struct nr_net {
     // so segment 0 can run concurrently with it (nr_denoise_step_forward) ----
     split_op = ops.size();
     {
-      std::vector<Act> added(skips.size());
-      for (int i = 0; i < n_res; ++i) {
-        // all skips but the last have already been consumed by their successor layer -> add in place;
-        // the last one is also the mid-block input, which must stay un-added: it was consumed above, so in place is safe too.
-        const Act s = skips[i];
-        const long long n = (long long)s.rows() * s.C;
-        bf16* sp = s.ptr;
-        emit([this, sp, n, i](hipStream_t st) {
-          if (io.has_res) LAUNCH_OK(nr_launch_add_bf16(sp, (const bf16*)io.down_res[i], sp, n, st));
+      // all skips but the last have already been consumed by their successor layer -> add in place; the last one is also the
+      // mid-block input, which must stay un-added: it was consumed above, so in place is safe too.  One launch for all of them
+      // (12 skips + the mid-block output) when every size is a multiple of 8 elements, else one launch each.
+      struct AddT { bf16* dst; long long n; };
+      std::vector<AddT> adds;
+      for (int i = 0; i < n_res; ++i) adds.push_back(AddT{skips[i].ptr, (long long)skips[i].rows() * skips[i].C});
+      adds.push_back(AddT{x.ptr, (long long)x.rows() * x.C});
+      bool multi = (int)adds.size() <= 16;
+      for (auto& a : adds) multi = multi && a.n % 8 == 0;
+      if (multi) {
+        NrAddMulti am;
+        std::memset(&am, 0, sizeof(am));
+        long long acc = 0;
+        for (size_t i = 0; i < adds.size(); ++i) { am.dst[i] = adds[i].dst; acc += adds[i].n / 8; am.n8_end[i] = acc; }
+        am.count = (int)adds.size();
+        const int nr = n_res;
+        emit([this, am, nr](hipStream_t st) {
+          if (!io.has_res) return;
+          NrAddMulti q = am;
+          for (int i = 0; i < nr; ++i) q.src[i] = (const bf16*)io.down_res[i];
+          q.src[nr] = (const bf16*)io.mid_res;
+          LAUNCH_OK(nr_launch_add_bf16_multi(&q, st));
+        });
+      } else {
+        for (int i = 0; i < n_res; ++i) {
+          bf16* sp = adds[i].dst; const long long n = adds[i].n;
+          emit([this, sp, n, i](hipStream_t st) {
+            if (io.has_res) LAUNCH_OK(nr_launch_add_bf16(sp, (const bf16*)io.down_res[i], sp, n, st));
+          });
+        }
+        bf16* xp = x.ptr; const long long n = adds.back().n;
+        emit([this, xp, n](hipStream_t st) {
+          if (io.has_res) LAUNCH_OK(nr_launch_add_bf16(xp, (const bf16*)io.mid_res, xp, n, st));
         });
       }
-      const long long n = (long long)x.rows() * x.C;
-      bf16* xp = x.ptr;
-      emit([this, xp, n](hipStream_t st) {
-        if (io.has_res) LAUNCH_OK(nr_launch_add_bf16(xp, (const bf16*)io.mid_res, xp, n, st));
-      });
     }
     split_op2 = ops.size();
 

@@ -401,7 +401,11 @@ class _NativeNet:
         key = (batch, frames, h, w, ctx_len)
         if key != self._plan_key:
             _lib.check(_lib.load().nr_net_plan(self._handle(), batch, frames, h, w, ctx_len))
-            _lib.check(_lib.load().nr_net_release_host_weights(self._handle()))
+            # the fp32 host copies (5 GB for the U-Net) are dropped once converted.  A later plan for a DIFFERENT shape may need
+            # conversions this one did not make (the LayerNorm folding is chosen per GEMM shape): set auto_release_host_weights = False
+            # on a handle that will be driven at several batch sizes, or load the state dict again
+            if getattr(self, "auto_release_host_weights", True):
+                _lib.check(_lib.load().nr_net_release_host_weights(self._handle()))
             self._plan_key = key
             self._ctx_key = None         # _on_plan allocates fresh staging buffers: the cached context must be copied again
             self._on_plan()

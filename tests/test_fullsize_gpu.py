@@ -47,6 +47,8 @@ def c2(cuda):
     usd = gpu_random_state_dict(state_dict_schema(ucfg, _lib.NR_KIND_UNET3D), 1, cuda)
     csd = gpu_random_state_dict(state_dict_schema(ccfg, _lib.NR_KIND_SPARSECTRL), 2, cuda)
     unet, ctrl = NativeUNet3D(ucfg).to(cuda), NativeSparseCtrl(ccfg).to(cuda)
+    # this fixture drives ONE SparseCtrl handle at two batch sizes (grouped pipeline schedule, then single evaluations)
+    ctrl.auto_release_host_weights = False
     unet.load_state_dict({k: v.cpu() for k, v in usd.items()})
     ctrl.load_state_dict({k: v.cpu() for k, v in csd.items()})
     sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
