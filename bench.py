@@ -415,7 +415,7 @@ def pmc_traffic():
     WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): bench.py cannot
     run the profiler itself, so it reports the most recent committed measurement, or null."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_pmc.json")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_pmc.json")) if "keyframe" not in os.path.basename(f))
     if not files:
         return None
     with open(files[-1]) as f:

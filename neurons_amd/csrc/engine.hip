@@ -249,7 +249,7 @@ struct nr_net {
   // captured graphs per segment, keyed by the IO block they were captured with (pointers are baked into the kernel nodes): the grouped
   // SparseCtrl schedule alternates between a few residual-buffer sets, each gets its own executable graph (small LRU)
   struct GraphSlot { IO io; hipGraphExec_t exec = nullptr; unsigned long long used = 0; };
-  static constexpr int NR_GRAPH_SLOTS = 20;
+  static constexpr int NR_GRAPH_SLOTS = 64;     // the sgm Euler loop bakes c_in(sigma) into its graphs: one per step of a 38 / 50-step schedule
   std::vector<GraphSlot> gcache[3];
   unsigned long long gclock = 0;
   hipEvent_t ev_slot[2] = {nullptr, nullptr};   // completion of nr_sparsectrl_forward_async evaluations (two in flight at most)
