@@ -297,6 +297,10 @@ nr_status nr_op_gemm_ex(nr_stream stream, const void* a_dev, int32_t lda, const 
 nr_status nr_op_conv3x3(nr_stream stream, const void* x0_dev, int32_t c0, const void* x1_dev, int32_t c1, int32_t nimg,
                         int32_t H, int32_t W, int32_t stride, int32_t ups, const void* w_dev, const float* bias_dev,
                         const float* rowvec_dev, int32_t rowvec_div, const void* res_dev, void* out_dev, int32_t Cout);
+/* nr_op_conv3x3 for stride 1 / no upsample / one source, weight pre-arranged as [Cout][Cin/64][3][3][64] (the engine's layout for the
+ * ResnetBlock convs: the K loop walks 64-channel chunks with the 9 taps innermost) */
+nr_status nr_op_conv3x3_tap_inner(nr_stream stream, const void* x0, int32_t c0, int32_t nimg, int32_t H, int32_t W, const void* w,
+                                  const float* bias, const float* rowvec, int32_t rowvec_div, const void* res, void* out, int32_t Cout);
 nr_status nr_op_groupnorm(nr_stream stream, const void* x0_dev, int32_t c0, const void* x1_dev, int32_t c1, int32_t nimg,
                           int32_t hw, int32_t groups, const float* gamma_dev, const float* beta_dev, float eps,
                           int32_t silu, float* partial_ws_dev, void* out_dev);

@@ -99,6 +99,7 @@ SYMBOLS = {
     "nr_op_gemm_ex": (_I32, [_VP, _VP, _I32, _VP, _VP, _VP, C.c_float, _VP, _I32, _I32, _I32, _VP, _I32, _VP, _I32, _I32, _I32, _I32, _I32, _I32,
                              C.c_float]),
     "nr_op_conv3x3": (_I32, [_VP, _VP, _I32, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _I32, _VP, _VP, _I32]),
+    "nr_op_conv3x3_tap_inner": (_I32, [_VP, _VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _I32, _VP, _VP, _I32]),
     "nr_op_groupnorm": (_I32, [_VP, _VP, _I32, _VP, _I32, _I32, _I32, _I32, _VP, _VP, C.c_float, _I32, _VP, _VP]),
     "nr_op_layernorm": (_I32, [_VP, _VP, _VP, _I32, _I32, _VP, _VP, C.c_float, _VP, _I32, _I32]),
     "nr_op_attention": (_I32, [_VP, _I32, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32]),

@@ -96,6 +96,9 @@ struct NrGemmParams {
   int act;             // 0 none; 1 quick_gelu x*sigmoid(1.702x) (CLIP MLP), applied after bias/scale, before the residual
   int pad_tl0;         // 3x3 only: 1 = no top/left padding (bottom/right zero) — the VAE Downsample's F.pad (0,1,0,1)
   float* out_f32;      // non-null: write the raw fp32 accumulators to out_f32[M][N] and skip the epilogue (attention scores)
+  int tap_inner;       // 3x3, stride 1, single source: K walks (64-channel chunk, tap) with the TAP fastest; weights [N][Cin/64][9][64].
+                       // The 9 re-reads of an activation row segment then fall into 9 consecutive k-tiles (L2 hits) instead of being
+                       // spread over the whole K loop (tap-major order: the working set of the tiles in flight exceeds the 4 MiB L2)
 };
 
 // Row-panel GEMM (rowpanel.hip): out = epilogue(a . w^T), K = 320, the 256-row panel held in registers

@@ -500,6 +500,25 @@ struct nr_net {
     });
   }
   // conv weight [Cout][Cin][3][3] -> bf16 [Cout][ky][kx][Cin]
+  // 3x3 conv weight in the tap-inner K order of the igemm (NrGemmParams::tap_inner): [Cout][Cin/64][ky][kx][64]
+  static bool conv_tap_inner() {
+    static const bool on = !(getenv("NR_CONV_TAP_INNER") && getenv("NR_CONV_TAP_INNER")[0] == '0');
+    return on;
+  }
+  const bf16* w_conv3_tap_inner(const std::string& key, int Cout, int Cin) {
+    const HostTensor& t = need(key);
+    check_shape(key, t, {Cout, Cin, 3, 3});
+    if (Cin % 64 != 0) throw NrError(NR_ERR_UNSUPPORTED, "tap-inner conv layout needs Cin % 64 == 0: " + key);
+    return (const bf16*)cached("conv3t:" + key, [&]() {
+      (void)data_of(key);
+      std::vector<uint16_t> h((size_t)Cout * 9 * Cin);
+      for (int o = 0; o < Cout; ++o)
+        for (int c = 0; c < Cin; ++c)
+          for (int k = 0; k < 9; ++k)
+            h[(size_t)o * 9 * Cin + (size_t)(c / 64) * 9 * 64 + (size_t)k * 64 + (c % 64)] = f2bf_host(t.data[((size_t)o * Cin + c) * 9 + k]);
+      return upload("conv3t:" + key, h.data(), h.size() * 2);
+    });
+  }
   const bf16* w_conv3(const std::string& key, int Cout, int Cin) {
     const HostTensor& t = need(key);
     check_shape(key, t, {Cout, Cin, 3, 3});
@@ -602,6 +621,7 @@ struct nr_net {
     int pad_tl0 = 0;         // 3x3: no top/left padding (VAE Downsample)
     int act = 0;             // 1: quick_gelu
     const float* ln_c = nullptr;   // LayerNorm folded into this GEMM (see w_ln_linear)
+    int tap_inner = 0;       // 3x3 stride 1 single source: weights in the tap-inner layout of w_conv3_tap_inner
   };
 
   // generic conv / linear.  x1: optional channel-concat second source.
@@ -621,6 +641,7 @@ struct nr_net {
     p.M = x0.nimg * OH * OW; p.N = Cout; p.K = ksize * ksize * (p.c0 + p.c1);
     p.bias = o.bias; p.rowvec = o.rowvec; p.rowvec_div = o.rowvec_div; p.rowvec_ld = o.rowvec_ld; p.rowvec_mod = o.rowvec_mod;
     p.out_scale = o.scale; p.geglu = o.geglu; p.pad_tl0 = o.pad_tl0; p.act = o.act; p.ln_c = o.ln_c; p.ln_eps = 1e-5f;
+    p.tap_inner = o.tap_inner;
     const int outC = o.geglu ? Cout / 2 : Cout;
     Act out = o.out ? *o.out : new_act(x0.nimg, OH, OW, outC);
     if (out.C != outC || out.rows() != p.M) throw NrError(NR_ERR_STATE, "conv: output shape mismatch");
@@ -766,7 +787,9 @@ struct nr_net {
     if (cfg.kind != NR_KIND_VAE_DECODER && cfg.kind != NR_KIND_VAE_ENCODER) {   // the VAE's ResnetBlock runs with temb = None (model.py:138-139,727)
       o1.rowvec = temb_for(pre, Cout); o1.rowvec_div = F * hw; o1.rowvec_ld = temb_total;
     }
-    Act h1 = conv(h, nullptr, w_conv3(k.conv1 + ".weight", Cout, Cin), Cout, 3, 1, 0, o1);
+    const bool ti1 = conv_tap_inner() && Cin % 64 == 0, ti2 = conv_tap_inner() && Cout % 64 == 0;
+    o1.tap_inner = ti1 ? 1 : 0;
+    Act h1 = conv(h, nullptr, ti1 ? w_conv3_tap_inner(k.conv1 + ".weight", Cout, Cin) : w_conv3(k.conv1 + ".weight", Cout, Cin), Cout, 3, 1, 0, o1);
     h = Act();
     Act h2 = groupnorm(h1, nullptr, k.norm2, cfg.norm_eps, 1);
     h1 = Act();
@@ -782,7 +805,8 @@ struct nr_net {
     GemmOpt o2;
     o2.bias = w_f32(k.conv2 + ".bias", Cout);
     o2.res = &sc;
-    Act out = conv(h2, nullptr, w_conv3(k.conv2 + ".weight", Cout, Cout), Cout, 3, 1, 0, o2);
+    o2.tap_inner = ti2 ? 1 : 0;
+    Act out = conv(h2, nullptr, ti2 ? w_conv3_tap_inner(k.conv2 + ".weight", Cout, Cout) : w_conv3(k.conv2 + ".weight", Cout, Cout), Cout, 3, 1, 0, o2);
     tap(pre, out);
     return out;
   }
@@ -2373,6 +2397,22 @@ extern "C" nr_status nr_op_conv3x3(nr_stream stream, const void* x0, int32_t c0,
   if (stride == 2) { OH = (OH - 1) / 2 + 1; OW = (OW - 1) / 2 + 1; }
   p.OH = OH; p.OW = OW; p.ksize = 3; p.stride = stride; p.ups = ups;
   p.w = (const bf16*)w; p.M = nimg * OH * OW; p.N = Cout; p.K = 9 * (p.c0 + p.c1);
+  p.bias = bias; p.rowvec = rowvec; p.rowvec_div = rowvec_div > 0 ? rowvec_div : 1; p.rowvec_ld = Cout;
+  p.res = (const bf16*)res; p.ldr = Cout; p.out = (bf16*)out; p.ldo = Cout; p.out_scale = 1.f;
+  LAUNCH_OK(nr_launch_igemm(&p, op_workspace(p), (hipStream_t)stream));
+  NR_CATCH
+}
+
+// as nr_op_conv3x3 (stride 1, no upsample, single source) with the weight in the tap-inner layout [Cout][Cin/64][3][3][64]
+extern "C" nr_status nr_op_conv3x3_tap_inner(nr_stream stream, const void* x0, int32_t c0, int32_t nimg, int32_t H, int32_t W, const void* w,
+                                             const float* bias, const float* rowvec, int32_t rowvec_div, const void* res, void* out,
+                                             int32_t Cout) {
+  NR_TRY
+  NrGemmParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.a0 = (const bf16*)x0; p.c0 = c0; p.lda0 = c0;
+  p.H = H; p.W = W; p.OH = H; p.OW = W; p.ksize = 3; p.stride = 1; p.tap_inner = 1;
+  p.w = (const bf16*)w; p.M = nimg * H * W; p.N = Cout; p.K = 9 * c0;
   p.bias = bias; p.rowvec = rowvec; p.rowvec_div = rowvec_div > 0 ? rowvec_div : 1; p.rowvec_ld = Cout;
   p.res = (const bf16*)res; p.ldr = Cout; p.out = (bf16*)out; p.ldo = Cout; p.out_scale = 1.f;
   LAUNCH_OK(nr_launch_igemm(&p, op_workspace(p), (hipStream_t)stream));

@@ -131,6 +131,22 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
     }
   }
   const bf16* zsrc = (const bf16*)nr_zero16;
+  // tap-inner K order (p.tap_inner): per row the byte offset of the centre pixel and a 9-bit mask of the taps that stay inside the image
+  long long a_cbyte[GA];
+  unsigned a_tapmask[GA];
+  if (p.tap_inner) {
+#pragma unroll
+    for (int j = 0; j < GA; ++j) {
+      a_cbyte[j] = (((long long)a_pix[j] * p.H + a_oy[j]) * p.W + a_ox[j]) * p.lda0 * (long long)sizeof(bf16);
+      unsigned msk = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = a_oy[j] + t / 3 - 1, ix = a_ox[j] + t % 3 - 1;
+        if (a_ok[j] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) msk |= 1u << t;
+      }
+      a_tapmask[j] = msk;
+    }
+  }
 
   const int nk_total = p.K / BK;
   const int kt_begin = (int)(((long long)nk_total * slice) / splitk);
@@ -148,8 +164,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
   int st_tap, st_c;
   {
     const int kbase = kt_begin * BK;
-    st_tap = p.ksize == 3 ? kbase / Cin : 0;
-    st_c = kbase - st_tap * Cin;
+    if (p.tap_inner) { st_tap = kt_begin % 9; st_c = (kt_begin / 9) * BK; }
+    else { st_tap = p.ksize == 3 ? kbase / Cin : 0; st_c = kbase - st_tap * Cin; }
 #pragma unroll
     for (int j = 0; j < GB; ++j) {
       const int n = n0 + 8 * (wave * GB + j) + lr;
@@ -158,7 +174,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
       winc[j] = ok ? BK : 0;
     }
   }
+  // tap-inner: every k-tile is another tap of the same 64 channels: pointer = centre + (wave-uniform) tap offset, or the zero word
+  auto setup_rows_tap_inner = [&]() {
+    const int ky = st_tap / 3, kx = st_tap - ky * 3;
+    const long long delta = ((long long)(ky - 1) * p.W + (kx - 1)) * p.lda0 * (long long)sizeof(bf16);
+    const char* base = reinterpret_cast<const char*>(p.a0 + st_c + lchunk) + delta;
+#pragma unroll
+    for (int j = 0; j < GA; ++j) {
+      const bool ok = (a_tapmask[j] >> st_tap) & 1u;
+      ap[j] = ok ? reinterpret_cast<const bf16*>(base + a_cbyte[j]) : zsrc;
+    }
+  };
   auto setup_rows = [&]() {
+    if (p.tap_inner) { setup_rows_tap_inner(); return; }
     const bf16* src; int ld;
     if (st_c < p.c0) { src = p.a0 + st_c; ld = p.lda0; } else { src = p.a1 + (st_c - p.c0); ld = p.lda1; }
     src += lchunk;
@@ -203,6 +231,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
     // advance to the next k-tile
 #pragma unroll
     for (int j = 0; j < GB; ++j) wp[j] += winc[j];
+    if (p.tap_inner) {
+      st_tap += 1;
+      if (st_tap == 9) { st_tap = 0; st_c += BK; }
+      setup_rows_tap_inner();
+      return;
+    }
     st_c += BK;
     bool resetup = false;
     if (st_c == Cin) { st_c = 0; st_tap += 1; resetup = true; }
@@ -672,6 +706,7 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
   if (p.a1 && (p.c0 % 64 != 0)) return 2;
   if (p.K != p.ksize * p.ksize * Cin) return 3;
   if (p.ksize != 1 && p.ksize != 3) return 4;
+  if (p.tap_inner && (p.ksize != 3 || p.stride != 1 || p.ups || p.pad_tl0 || p.a1)) return 5;
   Plan pl = choose_plan(p);
   const double w_elems = (double)p.N * p.K;
   const double a_elems = (double)p.M * Cin * (p.ksize == 3 ? (p.stride == 2 ? 4.0 : (p.ups ? 0.25 : 1.0)) : 1.0);

@@ -99,11 +99,21 @@ def geglu_permute(w, b):
     return w[src].contiguous(), (None if b is None else b[src].contiguous())
 
 
-def conv3x3(x0, w, bias=None, x1=None, stride=1, ups=False, rowvec=None, rowvec_div=1, res=None):
-    """x0/x1: [nimg, H, W, C] bf16; w: [Cout, 3, 3, Cin] bf16 (tap-major); returns [nimg, OH, OW, Cout]."""
+def conv3x3(x0, w, bias=None, x1=None, stride=1, ups=False, rowvec=None, rowvec_div=1, res=None, tap_inner=False):
+    """x0/x1: [nimg, H, W, C] bf16; w: [Cout, 3, 3, Cin] bf16 (tap-major); returns [nimg, OH, OW, Cout].
+    tap_inner: run the engine's ResnetBlock form (stride 1, one source): the weight is re-arranged here to [Cout][Cin/64][3][3][64]."""
     _chk_bf16(x0, x1, w, res)
     _chk_f32(bias, rowvec)
     nimg, H, W, c0 = x0.shape
+    if tap_inner:
+        if x1 is not None or stride != 1 or ups or c0 % 64 != 0:
+            raise ValueError("tap_inner: stride 1, no upsample, one source, Cin % 64 == 0")
+        Cout = w.shape[0]
+        wt = w.reshape(Cout, 9, c0 // 64, 64).permute(0, 2, 1, 3).contiguous()
+        out = torch.empty(nimg, H, W, Cout, dtype=torch.bfloat16, device=x0.device)
+        _lib.check(_lib.load().nr_op_conv3x3_tap_inner(_stream(), _ptr(x0), c0, nimg, H, W, _ptr(wt), _ptr(bias), _ptr(rowvec), rowvec_div,
+                                                        _ptr(res), _ptr(out), Cout))
+        return out
     c1 = 0 if x1 is None else x1.shape[3]
     Cout = w.shape[0]
     OH, OW = (2 * H, 2 * W) if ups else (H, W)

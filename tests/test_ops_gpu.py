@@ -78,6 +78,27 @@ def test_conv3x3(cuda, nimg, H, W, Cin, Cout, stride, ups):
     _cmp(f"conv3x3 {nimg}x{H}x{W} {Cin}->{Cout} s{stride} u{int(ups)}", out, _conv_ref(x, w, bias, stride, ups))
 
 
+@pytest.mark.parametrize("nimg,H,W,Cin,Cout", [
+    (4, 32, 32, 320, 320), (32, 32, 32, 960, 320), (8, 16, 16, 640, 640), (32, 8, 8, 2560, 1280), (32, 4, 4, 1280, 1280), (3, 6, 10, 64, 128),
+    (2, 5, 7, 128, 96), (1, 1, 1, 64, 64)])
+def test_conv3x3_tap_inner_order(cuda, nimg, H, W, Cin, Cout):
+    """The ResnetBlock form of the igemm: K walks 64-channel chunks with the 9 taps innermost (weights [Cout][Cin/64][3][3][64]).
+    Same arithmetic as the tap-major order up to fp32 summation order; borders, M / N tails, split-K shapes, + time-embedding row
+    vector + residual."""
+    from neurons_amd import ops
+    torch.manual_seed(12)
+    x = _bf(nimg, H, W, Cin)
+    w = _bf(Cout, 3, 3, Cin, scale=(9 * Cin) ** -0.5)
+    bias = torch.randn(Cout, device=cuda)
+    temb = torch.randn(nimg, Cout, device=cuda)
+    res = _bf(nimg, H, W, Cout)
+    out = ops.conv3x3(x, w, bias, rowvec=temb, rowvec_div=H * W, res=res, tap_inner=True)
+    ref = _conv_ref(x, w, bias) + temb[:, None, None, :] + res.float()
+    _cmp(f"conv3x3 tap-inner {nimg}x{H}x{W} {Cin}->{Cout}", out, ref)
+    out2 = ops.conv3x3(x, w, bias, rowvec=temb, rowvec_div=H * W, res=res, tap_inner=True)
+    assert torch.equal(out, out2)
+
+
 def test_conv3x3_concat_temb_res(cuda):
     from neurons_amd import ops
     torch.manual_seed(3)
