@@ -224,9 +224,18 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p) {
   const int c = lane & 15, g = lane >> 4;
   constexpr int TILEK = KT2 * KSK, TILEV = KT2 * KSV, TILE2 = TILEK + TILEV;   // elements per buffer
   const int qblocks = (p.Lq + 63) >> 6;
-  const int qb = blockIdx.x % qblocks;
-  const int h = (blockIdx.x / qblocks) % p.heads;
-  const int nb = blockIdx.x / (qblocks * p.heads);
+  // XCD-aware remap (bijective, as in gemm.hip): workgroups are dealt round-robin over the 8 XCDs, so give each XCD a CONTIGUOUS range
+  // of (image, head, query-block) ids: the 16 query blocks of a head, and the heads that share its 128-byte lines of the fused q|k|v
+  // rows, then read their K/V through ONE L2 instead of fetching them into up to eight
+  int bid;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7, local = orig >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  const int qb = bid % qblocks;
+  const int h = (bid / qblocks) % p.heads;
+  const int nb = bid / (qblocks * p.heads);
   const int nbkv = nb / p.kv_div;
   const long long qbase = (long long)(nb / p.inner) * p.q_outer + (long long)(nb % p.inner) * p.q_inner_stride + (long long)h * p.d;
   const long long obase = (long long)(nb / p.inner) * p.o_outer + (long long)(nb % p.inner) * p.o_inner_stride + (long long)h * p.d;
