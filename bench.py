@@ -245,7 +245,9 @@ def main():
             net.load_state_dict(sd)
             host_sd[kind] = sd
             if world > 1:
-                net._ensure_plan(2 * args.batch, F, L, L, 77)      # converts the weights for the shape every rank will run
+                # converts the weights for the shape every rank will run: SparseCtrl is evaluated `grp` DDIM steps at a time (pipeline.py)
+                grp0 = max(1, min(int(os.environ.get("NR_CTRL_GROUP", "4")), 16 // (2 * args.batch), args.ddim_steps))
+                net._ensure_plan(2 * args.batch * (grp0 if kind == _lib.NR_KIND_SPARSECTRL else 1), F, L, L, 77)
         if world > 1:
             broadcast_native_weights(net, src=0)
     torch.cuda.empty_cache()
