@@ -19,7 +19,9 @@
 namespace {
 
 constexpr int KT = 32;        // keys per iteration
-constexpr int VT_LD = 36;     // LDS row stride (elements) of the transposed V tile: 72 B, conflict-free b64 reads
+// LDS row stride (elements) of a wave's V tile [32 keys][d]: 16 (mod 32) so the 8 rows a half-wave touches in one
+// ds_read_b64_tr_b16 start 8 banks apart (as KSV of the block-shared kernel below)
+__host__ __device__ constexpr int vt_stride(int DT) { return (DT * 16) % 32 == 16 ? DT * 16 : DT * 16 + 16; }
 
 // DK = ceil(d/32) k-steps for QK^T;  DT = ceil(d/16) row tiles of O^T
 template <int DK, int DT>
@@ -27,8 +29,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(NrAttnParams p) {
   extern __shared__ __attribute__((aligned(16))) bf16 vt_all[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  bf16* vt = vt_all + (size_t)wave * (DT * 16) * VT_LD;   // [DT*16][VT_LD]
+  constexpr int VS = vt_stride(DT);
+  bf16* vt = vt_all + (size_t)wave * KT * VS;             // this wave's private V tile, row-major [key][dim]
   const int c = lane & 15, g = lane >> 4;
+  const int tq = c >> 2, tp = c & 3;                      // transpose-read role inside the 16-lane group
 
   const int qtiles = (p.Lq + 15) >> 4;
   const long long total = (long long)p.nbatch * p.heads * qtiles;
@@ -64,18 +68,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(NrAttnParams p) {
 
   const int chunks_per_key = p.d >> 3;
   const int vchunks = KT * chunks_per_key;
+  // the tile is wave-private and a wave's LDS operations execute in order, so no workgroup barrier is needed around it; the pad
+  // columns [d, 16 DT) are cleared once (they only feed output rows that are never stored, but must be finite)
+  for (int id = lane; id < KT * (VS >> 3); id += 64) *(bf16x8*)(vt + id * 8) = zero8;
 
   for (int k0 = 0; k0 < p.Lk; k0 += KT) {
-    // ---- stage V tile transposed: vt[dv][key - k0] ----
-    __syncthreads();   // previous iteration's fragment reads are done
+    // ---- stage the V tile row-major with 16-byte stores: vt[key - k0][dim]; the MFMA A operand (V^T) is read transposed ----
+    __builtin_amdgcn_wave_barrier();
     for (int id = lane; id < vchunks; id += 64) {
       const int kk = id / chunks_per_key;
       const int x0 = (id - kk * chunks_per_key) << 3;
       const int key = k0 + kk;
       bf16x8 vv = zero8;
       if (key < p.Lk) vv = *(const bf16x8*)(p.v + kbase + (long long)key * p.kv_seq + x0);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) vt[(x0 + e) * VT_LD + kk] = vv[e];
+      *(bf16x8*)(vt + kk * VS + x0) = vv;
     }
 
     // ---- S^T = K Q^T for two 16-key tiles ----
@@ -126,18 +132,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(NrAttnParams p) {
 #pragma unroll
     for (int i = 0; i < DT; ++i) acc[i] *= alpha;
 
-    __syncthreads();   // V tile visible
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // the wave's own stores are ordered before its transposed reads
     // ---- O^T += V^T P^T : A = V^T rows dv = 16*i + c, k-slot j -> key (j<4: 4g+j ; j>=4: 16+4g+j-4) ----
 #pragma unroll
     for (int i = 0; i < DT; ++i) {
-      const int dv = i * 16 + c;
-      bf16x8 vf = zero8;
-      if (dv < p.d) {
-        const bf16x4 lo = *(const bf16x4*)(vt + dv * VT_LD + 4 * g);
-        const bf16x4 hi = *(const bf16x4*)(vt + dv * VT_LD + 16 + 4 * g);
+      const bf16* a0 = vt + (4 * g + tq) * VS + 16 * i + 4 * tp;
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a0);
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0 + 16 * VS));
+      bf16x8 vf;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
-      }
+      for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
       acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, acc[i], 0, 0, 0);
     }
   }
@@ -448,7 +453,7 @@ int launch_attn(const NrAttnParams& p, hipStream_t stream) {
   const int qtiles = (p.Lq + 15) / 16;
   const long long total = (long long)p.nbatch * p.heads * qtiles;
   const unsigned blocks = (unsigned)((total + 3) / 4);
-  const size_t shm = (size_t)4 * (DT * 16) * VT_LD * sizeof(bf16);
+  const size_t shm = (size_t)4 * KT * vt_stride(DT) * sizeof(bf16);
   hipLaunchKernelGGL((attn_fwd_kernel<DK, DT>), dim3(blocks), dim3(256), shm, stream, p);
   return 0;
 }
