@@ -42,6 +42,25 @@ class _NullBar:
         pass
 
 
+def controlnet_group_plan(timesteps, group):
+    """Grouped SparseCtrl schedule as plain data (host logic, unit-tested on CPU).  Returns ``(groups, steps)``:
+    ``groups[g]`` = the timesteps evaluated by group g (``group`` of them; the tail of the last group repeats the final timestep: those
+    samples are evaluated and never consumed) and its event/buffer slot ``g % 2``;
+    ``steps[i]`` = ``(launch, g, phase)``: before step i's U-Net forward issue the evaluation of group ``launch`` (``None``: nothing to
+    issue), then consume samples ``phase`` of group ``g``.  Group 0 is issued before the loop; group g + 1 is issued at the first step
+    of group g, i.e. one group ahead, into the slot whose last reader was step ``g * group - 1``."""
+    n = len(timesteps)
+    group = max(1, min(int(group), n))
+    ngroups = (n + group - 1) // group
+    groups = [dict(timesteps=[timesteps[min(g * group + p, n - 1)] for p in range(group)], slot=g % 2) for g in range(ngroups)]
+    steps = []
+    for i in range(n):
+        g, p = divmod(i, group)
+        launch = g + 1 if (p == 0 and g + 1 < ngroups) else None
+        steps.append((launch, g, p))
+    return groups, steps
+
+
 class NeuroclipsPipeline:
     _optional_components = []
 
@@ -273,15 +292,14 @@ class NeuroclipsPipeline:
         pending = {}
 
         def launch_group(g):
-            # timesteps of steps g*G .. g*G+G-1 (the tail of the last group repeats the final step: evaluated, never consumed)
             ts = []
-            for p_ in range(G):
-                tt = timesteps_host[min(g * G + p_, len(timesteps_host) - 1)]
+            for tt in groups[g]["timesteps"]:
                 ts += [float(tt)] * b2
             pending[g] = self.controlnet.forward_async(ts, ctx_group, controlnet_cond, controlnet_conditioning_mask,
-                                                       controlnet_conditioning_scale, slot=g % 2)
+                                                       controlnet_conditioning_scale, slot=groups[g]["slot"])
 
         if G > 1:
+            groups, plan = controlnet_group_plan(list(timesteps_host), G)
             ctx_group = text_embeddings.repeat(G, 1, 1)
             launch_group(0)
         with self.progress_bar(total=num_inference_steps) as progress_bar:
@@ -290,11 +308,11 @@ class NeuroclipsPipeline:
                 latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)
                 down_res = mid_res = None
                 if G > 1:
-                    g, p_ = divmod(i, G)
-                    if p_ == 0 and (g + 1) * G < len(timesteps_host):
-                        launch_group(g + 1)          # runs beside this group's U-Net steps; its buffers were last read in step i - 1
+                    launch, g, p_ = plan[i]
+                    if launch is not None:
+                        launch_group(launch)         # runs beside this group's U-Net steps; its buffers were last read in step i - 1
                         pending.pop(g - 1, None)
-                    noise_pred = self.unet.forward_after(self.controlnet, g % 2, pending[g], p_ * b2, latent_model_input, t,
+                    noise_pred = self.unet.forward_after(self.controlnet, groups[g]["slot"], pending[g], p_ * b2, latent_model_input, t,
                                                          text_embeddings).sample
                 elif fused:
                     # same two network evaluations (:460-475), issued as one library call that overlaps them

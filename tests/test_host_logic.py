@@ -193,3 +193,32 @@ def test_synth_is_deterministic_and_normal():
     assert torch.equal(a, b) and not torch.equal(a, randn("x.z", (257, 3), 5))
     z = randn("big", (200000,), 1)
     assert abs(z.mean().item()) < 0.01 and abs(z.std().item() - 1) < 0.01
+
+
+def test_controlnet_group_plan_invariants():
+    """Grouped SparseCtrl schedule (pipeline.controlnet_group_plan): every step consumes an evaluation that was issued earlier, at most
+    one group ahead, into a slot no pending group still owns; group timesteps are the steps' timesteps (tail repeated)."""
+    from neurons_amd.pipeline import controlnet_group_plan
+    for n in (1, 2, 3, 7, 10, 25, 38, 50):
+        ts = [1000 - 13 * i for i in range(n)]
+        for G in (1, 2, 3, 4, 8, 64):
+            groups, steps = controlnet_group_plan(ts, G)
+            g_eff = max(1, min(G, n))
+            assert len(steps) == n and len(groups) == (n + g_eff - 1) // g_eff
+            issued = {0}                                  # group 0 goes out before the loop
+            live_slots = {groups[0]["slot"]: 0}
+            for i, (launch, g, p) in enumerate(steps):
+                assert (g, p) == divmod(i, g_eff)
+                if launch is not None:
+                    assert launch == g + 1 and p == 0 and launch not in issued
+                    # its slot was last read by group g - 1 (finished with step i - 1), never by the group being consumed now
+                    assert groups[launch]["slot"] != groups[g]["slot"]
+                    assert live_slots.get(groups[launch]["slot"], launch - 2) == launch - 2 or launch - 2 < 0
+                    live_slots[groups[launch]["slot"]] = launch
+                    issued.add(launch)
+                assert g in issued and live_slots[groups[g]["slot"]] == g
+                assert groups[g]["timesteps"][p] == ts[i]
+            assert issued == set(range(len(groups)))
+            for g, grp in enumerate(groups):
+                assert len(grp["timesteps"]) == g_eff and grp["slot"] == g % 2
+                assert grp["timesteps"] == [ts[min(g * g_eff + p, n - 1)] for p in range(g_eff)]
