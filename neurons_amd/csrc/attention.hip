@@ -267,8 +267,7 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p) {
   // staging addresses: each thread owns CH fixed (key-in-tile, 16-byte chunk) slots, so its K / V source pointers just advance by one
   // tile per iteration; only the last, partial tile clamps the key (the clamped rows are finite data that the softmax masks out)
   int s_kk[CH];
-  const bf16* s_kp[CH];
-  const bf16* s_vp[CH];
+  int s_off[CH];                              // element offset of the slot inside one (batch, head) K / V sequence (fits 32 bits)
   int s_lok[CH], s_lov[CH];                   // LDS element offsets of the slot in the K / V image
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
@@ -277,24 +276,27 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p) {
     s_kk[i] = kk;
     s_lok[i] = KSWZ ? kk * KSK + ((((x0 >> 3) ^ (kk & 7))) << 3) : kk * KSK + x0;
     s_lov[i] = kk * KSV + x0;
-    const long long off = kbase + (long long)kk * p.kv_seq + x0;
-    s_kp[i] = p.k + off;
-    s_vp[i] = p.v + off;
+    s_off[i] = kk * p.kv_seq + x0;
   }
+  // workgroup-uniform bases (scalar registers) + 32-bit lane offsets: two VGPRs per slot instead of two 64-bit pointers
+  const bf16* kb = p.k + kbase;
+  const bf16* vb = p.v + kbase;
   const long long tile_step = (long long)KT2 * p.kv_seq;
   auto load_regs = [&](int k0) {
+    const bf16* kt = kb + (long long)(k0 / KT2) * tile_step;
+    const bf16* vtp = vb + (long long)(k0 / KT2) * tile_step;
     if (k0 + KT2 <= p.Lk) {
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
-        rk[i] = *(const bf16x8*)(s_kp[i] + (long long)(k0 / KT2) * tile_step);
-        rv[i] = *(const bf16x8*)(s_vp[i] + (long long)(k0 / KT2) * tile_step);
+        rk[i] = *(const bf16x8*)(kt + s_off[i]);
+        rv[i] = *(const bf16x8*)(vtp + s_off[i]);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
-        const long long back = (long long)max(k0 + s_kk[i] - (p.Lk - 1), 0) * p.kv_seq;
-        rk[i] = *(const bf16x8*)(s_kp[i] + (long long)(k0 / KT2) * tile_step - back);
-        rv[i] = *(const bf16x8*)(s_vp[i] + (long long)(k0 / KT2) * tile_step - back);
+        const int back = max(k0 + s_kk[i] - (p.Lk - 1), 0) * p.kv_seq;
+        rk[i] = *(const bf16x8*)(kt + (s_off[i] - back));
+        rv[i] = *(const bf16x8*)(vtp + (s_off[i] - back));
       }
     }
   };
