@@ -31,19 +31,18 @@ __device__ __forceinline__ bf16x8 bf16x8_zero() {
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // exact (erf) GELU, as torch F.gelu default (reference: animatediff/models/motion_module_new.py:508-518)
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-// Same function with erf from Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, i.e. far below the bf16
-// output rounding): one exp + one rcp + 6 FMAs instead of libm erff in the GEGLU GEMM epilogue.
+// Same function with erf from Abramowitz-Stegun 7.1.25 (3-term, |erf error| <= 2.5e-5: two orders below the bf16 rounding of the
+// product), sign handled through |x|: 11 plain VALU ops + v_rcp + v_exp per element.  The GEGLU epilogues are VALU-bound (K is short:
+// 5-20 MFMA k-tiles per output tile), so the gate is kept as short as the output precision allows.
 __device__ __forceinline__ float gelu_erf_fast(float x) {
   const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-  float poly = 1.061405429f;
-  poly = poly * t - 1.453152027f;
-  poly = poly * t + 1.421413741f;
-  poly = poly * t - 0.284496736f;
-  poly = poly * t + 0.254829592f;
-  const float erf_abs = 1.0f - poly * t * __expf(-z * z);
-  const float erf = x < 0.f ? -erf_abs : erf_abs;
-  return 0.5f * x * (1.0f + erf);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(z, 0.47047f, 1.0f));
+  float poly = __builtin_fmaf(t, 0.7478556f, -0.0958798f);
+  poly = __builtin_fmaf(poly, t, 0.3480242f) * t;
+  const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
+  const float q = __builtin_fmaf(-poly, e, 1.0f);          // erf(|x| / sqrt 2)
+  const float h = 0.5f * x;
+  return __builtin_fmaf(fabsf(h), q, h);                   // 0.5 x (1 + sign(x) erf(|x| / sqrt 2))
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

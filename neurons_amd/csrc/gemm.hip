@@ -132,9 +132,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
   }
   const bf16* zsrc = (const bf16*)nr_zero16;
   // tap-inner K order (p.tap_inner): per row the byte offset of the centre pixel and a 9-bit mask of the taps that stay inside the image
+  // (compiled out of the LayerNorm-fused instantiations, which only ever run 1x1: their 8-wave tiles must stay within 128 VGPRs to keep
+  // two workgroups per CU)
+  const bool tap_inner = !LNF && p.tap_inner != 0;
   long long a_cbyte[GA];
   unsigned a_tapmask[GA];
-  if (p.tap_inner) {
+  if (tap_inner) {
 #pragma unroll
     for (int j = 0; j < GA; ++j) {
       a_cbyte[j] = (((long long)a_pix[j] * p.H + a_oy[j]) * p.W + a_ox[j]) * p.lda0 * (long long)sizeof(bf16);
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
   int st_tap, st_c;
   {
     const int kbase = kt_begin * BK;
-    if (p.tap_inner) { st_tap = kt_begin % 9; st_c = (kt_begin / 9) * BK; }
+    if (tap_inner) { st_tap = kt_begin % 9; st_c = (kt_begin / 9) * BK; }
     else { st_tap = p.ksize == 3 ? kbase / Cin : 0; st_c = kbase - st_tap * Cin; }
 #pragma unroll
     for (int j = 0; j < GB; ++j) {
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
     }
   };
   auto setup_rows = [&]() {
-    if (p.tap_inner) { setup_rows_tap_inner(); return; }
+    if (tap_inner) { setup_rows_tap_inner(); return; }
     const bf16* src; int ld;
     if (st_c < p.c0) { src = p.a0 + st_c; ld = p.lda0; } else { src = p.a1 + (st_c - p.c0); ld = p.lda1; }
     src += lchunk;
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
     // advance to the next k-tile
 #pragma unroll
     for (int j = 0; j < GB; ++j) wp[j] += winc[j];
-    if (p.tap_inner) {
+    if (tap_inner) {
       st_tap += 1;
       if (st_tap == 9) { st_tap = 0; st_c += BK; }
       setup_rows_tap_inner();

@@ -75,19 +75,8 @@ constexpr int RP_ROWS = 256;          // rows per workgroup (8 waves x 32)
 constexpr int RP_NS = 3;              // W ring depth (chunks)
 constexpr unsigned RP_OOB = 0x7fffff00u;   // byte offset beyond any buffer: the range check drops the lane
 
-// GEGLU gate: x -> gelu_erf(x) with erf from Abramowitz-Stegun 7.1.25 (|erf error| <= 2.5e-5, two orders below the bf16
-// rounding of the product): 11 plain VALU ops + rcp + exp per element.  The epilogue is what bounds this kernel (K is only 320:
-// 10 MFMA k-steps per output element), so the gate is kept as short as the output precision allows.
-__device__ __forceinline__ float gelu_gate(float x) {
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(z, 0.47047f, 1.0f));
-  float poly = __builtin_fmaf(t, 0.7478556f, -0.0958798f);
-  poly = __builtin_fmaf(poly, t, 0.3480242f) * t;
-  const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
-  const float q = __builtin_fmaf(-poly, e, 1.0f);          // erf(|x| / sqrt 2)
-  const float h = 0.5f * x;
-  return __builtin_fmaf(fabsf(h), q, h);                   // 0.5 x (1 + sign(x) erf(|x| / sqrt 2))
-}
+// GEGLU gate: gelu_erf_fast of common.h (A&S 7.1.25; the epilogue is what bounds this kernel at K = 320)
+__device__ __forceinline__ float gelu_gate(float x) { return gelu_erf_fast(x); }
 
 // LN: LayerNorm folded (p.ln_c); RV: fp32 row-vector term (p.rowvec); RES: residual add (p.res); GEGLU: value * gelu(gate) epilogue
 template <int C, bool LN, bool RV, bool RES, bool GEGLU>
