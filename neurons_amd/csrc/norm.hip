@@ -501,9 +501,10 @@ extern "C" int nr_launch_groupnorm(NrGnParams* pp, hipStream_t stream) {
         else if (nv <= 8) NR_GN_SLAB(8);
         else if (nv <= 12) NR_GN_SLAB(12);
         else if (nv <= 16) NR_GN_SLAB(16);
-        else if (nv <= 24 && T == 512) NR_GN_SLAB(24);
-        else if (nv <= 32 && T == 512) NR_GN_SLAB(32);
 #undef NR_GN_SLAB
+        // 24 / 32 chunks per thread only with 512 threads (at 1024 threads the 128-VGPR budget would spill)
+        else if (nv <= 24 && T == 512) { hipLaunchKernelGGL((gn_slab_kernel<24, 512>), dim3(grid), dim3(512), 0, stream, p, GS); return 0; }
+        else if (nv <= 32 && T == 512) { hipLaunchKernelGGL((gn_slab_kernel<32, 512>), dim3(grid), dim3(512), 0, stream, p, GS); return 0; }
       }
     }
   }
