@@ -337,7 +337,9 @@ def main():
                          "traffic_detail": pmc_traffic() if headline else None,
                          "algorithmic_gbytes_per_ddim_step": round((pu["igemm"]["bytes"] + pc["igemm"]["bytes"]) / 1e9, 2),
                          "launches_per_ddim_step": round(ig_n, 1), "ms_per_ddim_step": round(ig_ms, 3),
-                         "whole_step_launches": round(sum(pu[k]["launches"] + pc[k]["launches"] for k in pu), 1),
+                         # kernels enqueued per DDIM step, both networks (split-K reduces, multi-pass norms and the time-embedding MLP counted
+                         # per kernel; + set_timesteps and the CFG/DDIM update; SparseCtrl's share is 1/grp of an evaluation)
+                         "whole_step_launches": round(sum(pu[k]["launches"] + pc[k]["launches"] for k in pu) + 2 + 1.0 / grp, 1),
                          "sparsectrl_steps_per_evaluation": grp,
                          "algorithmic_tflop_per_ddim_step": round(ig_fl / 1e12, 3),
                          "per_class_ms_per_ddim_step": breakdown,

@@ -58,6 +58,7 @@ int nr_launch_cfg_ddim_step(const float* eps, const float* x, float* x_out, long
 int nr_launch_add_bf16(const bf16* a, const bf16* b, bf16* out, long long n, hipStream_t stream);
 int nr_launch_f32_to_bf16(const float* a, bf16* out, long long n, hipStream_t stream);
 int nr_launch_add_bf16_multi(const NrAddMulti* p, hipStream_t stream);
+int nr_groupnorm_launches(const NrGnParams* p);
 int nr_launch_fold_linear_pair(const float* w2, const float* w1, const float* b2, const float* b1, int C, int J, bf16* wc, float* bc,
                                hipStream_t stream);
 }
@@ -229,7 +230,7 @@ struct nr_net {
   std::vector<Act> ctx_persist;      // K|V buffers that must survive between forwards
   bool building_ctx = false;
   bool ctx_dirty = true;
-  struct OpMeta { int kind; double flops, bytes; std::string desc; };
+  struct OpMeta { int kind; double flops, bytes; std::string desc; int launches = 1; };   // launches: kernels this op enqueues
   std::vector<OpMeta> op_meta;   // parallel to ops: kernel class + algorithmic work (for roofline reporting)
   std::vector<Tap> taps;
   bool keep_all = false;
@@ -602,6 +603,7 @@ struct nr_net {
     ops.push_back(std::move(fn));
     op_meta.push_back(OpMeta{kind, flops, bytes, desc});
   }
+  void last_op_launches(int n) { if (!dry && !building_ctx && !op_meta.empty()) op_meta.back().launches = n; }
   void tap(const std::string& name, const Act& a) {
     if (!dry && keep_all) taps.push_back(Tap{name, a.ptr, a.rows(), a.C, a.ld});
   }
@@ -661,6 +663,7 @@ struct nr_net {
       std::shared_ptr<Buf> wsbuf;
       if (wsb) { wsbuf = new_tmp(wsb); ws = at<float>(wsbuf->off); }
       emit([p, ws](hipStream_t s) { LAUNCH_OK(nr_launch_igemm(&p, ws, s)); }, NR_PROF_IGEMM, 2.0 * p.M * (double)p.N * p.K, bytes, d);
+      if (wsb) last_op_launches(2);          // split-K: the igemm + its reduce kernel
       op_tap(ksize == 3 ? "conv3" : (p.ln_c ? "lngemm" : "gemm"), out);
     }
     return out;
@@ -695,6 +698,7 @@ struct nr_net {
     emit([p](hipStream_t s) { NrGnParams q = p; LAUNCH_OK(nr_launch_groupnorm(&q, s)); }, NR_PROF_GROUPNORM,
          8.0 * (double)x0.rows() * C, 2.0 * 2.0 * (double)x0.rows() * C,
          "groupnorm nimg=" + std::to_string(x0.nimg) + " hw=" + std::to_string(x0.H * x0.W) + " C=" + std::to_string(C));
+    { NrGnParams q = p; last_op_launches(nr_groupnorm_launches(&q)); }
     op_tap("gn", out);
     return out;
   }
@@ -1062,6 +1066,7 @@ struct nr_net {
         LAUNCH_OK(nr_launch_linear_small(y1, b2n, temb_dim, wy2, by2, temb_dim, 0, 1, emb, et, s));   // SiLU(time + label)
         LAUNCH_OK(nr_launch_linear_small(emb, b2n, temb_dim, wp, bp, tt, 0, 0, ta, nullptr, s));
       });
+      last_op_launches(6);
     }
     // ---- context fp32 -> bf16 ----
     Act ctx_bf = new_act_persistent(1, 1, B2 * ctx_len, cfg.cross_attention_dim);
@@ -1414,6 +1419,7 @@ struct nr_net {
         LAUNCH_OK(nr_launch_linear_small(emb1, b2n, temb_dim, w2, b2, temb_dim, 0, 1, emb, nullptr, s)); // SiLU(emb)
         LAUNCH_OK(nr_launch_linear_small(emb, b2n, temb_dim, wp, bp, tt, 0, 0, ta, nullptr, s));         // Linear(SiLU(emb)) for all resnets
       });
+      last_op_launches(4);
     }
 
     // ---- text context fp32 -> bf16 [B2*ctx_len][cross_dim] ----
@@ -1729,7 +1735,7 @@ static void profile_last(nr_net* h, hipStream_t s, nr_profile* out, const char* 
     float ms = 0.f;
     HIP_OK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
     const auto& m = h->op_meta[i];
-    out->ms[m.kind] += ms; out->flops[m.kind] += m.flops; out->bytes[m.kind] += m.bytes; out->launches[m.kind] += 1;
+    out->ms[m.kind] += ms; out->flops[m.kind] += m.flops; out->bytes[m.kind] += m.bytes; out->launches[m.kind] += m.launches;
     if (f) fprintf(f, "%zu,%d,%.4f,%.3f,%.3f,%s\n", i, m.kind, ms, m.flops / 1e9, m.bytes / 1e6, m.desc.c_str());
   }
   if (f) fclose(f);

@@ -463,7 +463,16 @@ extern "C" int nr_gn_workspace_floats(int nimg, int hw, int groups, int* pix_per
   return nimg * nchunk * groups * 2 + nimg * groups * 2;
 }
 
-extern "C" int nr_launch_groupnorm(NrGnParams* pp, hipStream_t stream) {
+static int gn_launch_impl(NrGnParams* pp, hipStream_t stream, bool count_only, int* nlaunch);
+extern "C" int nr_launch_groupnorm(NrGnParams* pp, hipStream_t stream) { int n = 0; return gn_launch_impl(pp, stream, false, &n); }
+// kernels nr_launch_groupnorm enqueues for this shape (1 slab / per-group kernel, 2-3 for the chunked passes): launch accounting only
+extern "C" int nr_groupnorm_launches(const NrGnParams* pp) {
+  NrGnParams q = *pp;
+  int n = 0;
+  return gn_launch_impl(&q, nullptr, true, &n) == 0 ? n : 1;
+}
+#define GNL(...) do { ++*nlaunch; if (!count_only) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+static int gn_launch_impl(NrGnParams* pp, hipStream_t stream, bool count_only, int* nlaunch) {
   NrGnParams p = *pp;
   const int C = p.c0 + p.c1;
   if (C % 8 != 0 || C % p.groups != 0 || p.groups > 64) return 1;
@@ -492,8 +501,8 @@ extern "C" int nr_launch_groupnorm(NrGnParams* pp, hipStream_t stream) {
         const unsigned grid = (unsigned)(p.nimg * (p.groups / GS));
 #define NR_GN_SLAB(NVV)                                                                                                  \
   do {                                                                                                                   \
-    if (T == 1024) hipLaunchKernelGGL((gn_slab_kernel<NVV, 1024>), dim3(grid), dim3(1024), 0, stream, p, GS);            \
-    else hipLaunchKernelGGL((gn_slab_kernel<NVV, 512>), dim3(grid), dim3(512), 0, stream, p, GS);                        \
+    if (T == 1024) GNL((gn_slab_kernel<NVV, 1024>), dim3(grid), dim3(1024), 0, stream, p, GS);            \
+    else GNL((gn_slab_kernel<NVV, 512>), dim3(grid), dim3(512), 0, stream, p, GS);                        \
     return 0;                                                                                                            \
   } while (0)
         if (nv <= 2) NR_GN_SLAB(2);
@@ -503,8 +512,8 @@ extern "C" int nr_launch_groupnorm(NrGnParams* pp, hipStream_t stream) {
         else if (nv <= 16) NR_GN_SLAB(16);
 #undef NR_GN_SLAB
         // 24 / 32 chunks per thread only with 512 threads (at 1024 threads the 128-VGPR budget would spill)
-        else if (nv <= 24 && T == 512) { hipLaunchKernelGGL((gn_slab_kernel<24, 512>), dim3(grid), dim3(512), 0, stream, p, GS); return 0; }
-        else if (nv <= 32 && T == 512) { hipLaunchKernelGGL((gn_slab_kernel<32, 512>), dim3(grid), dim3(512), 0, stream, p, GS); return 0; }
+        else if (nv <= 24 && T == 512) { GNL((gn_slab_kernel<24, 512>), dim3(grid), dim3(512), 0, stream, p, GS); return 0; }
+        else if (nv <= 32 && T == 512) { GNL((gn_slab_kernel<32, 512>), dim3(grid), dim3(512), 0, stream, p, GS); return 0; }
       }
     }
   }
@@ -514,9 +523,9 @@ extern "C" int nr_launch_groupnorm(NrGnParams* pp, hipStream_t stream) {
     const long long pairs = (long long)p.hw * (cg / 2);
     if (p.hw <= 64 && cg % 2 == 0 && p.c0 % 2 == 0 && pairs <= 256LL * 48) {
       dim3 grid(p.groups, p.nimg);
-      if (pairs <= 256LL * 8) hipLaunchKernelGGL((gn_fused_small_kernel<8>), grid, dim3(256), 0, stream, p);
-      else if (pairs <= 256LL * 16) hipLaunchKernelGGL((gn_fused_small_kernel<16>), grid, dim3(256), 0, stream, p);
-      else hipLaunchKernelGGL((gn_fused_small_kernel<48>), grid, dim3(256), 0, stream, p);
+      if (pairs <= 256LL * 8) GNL((gn_fused_small_kernel<8>), grid, dim3(256), 0, stream, p);
+      else if (pairs <= 256LL * 16) GNL((gn_fused_small_kernel<16>), grid, dim3(256), 0, stream, p);
+      else GNL((gn_fused_small_kernel<48>), grid, dim3(256), 0, stream, p);
       return 0;
     }
   }
@@ -528,11 +537,12 @@ extern "C" int nr_launch_groupnorm(NrGnParams* pp, hipStream_t stream) {
   if (shm_stats > 60000 || shm_apply > 60000) return 3;
   dim3 grid(p.nchunk, p.nimg);
   p.finalized = p.nchunk > 16 ? 1 : 0;
-  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), shm_stats, stream, p);
-  if (p.finalized) hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.groups, p.nimg), dim3(256), 0, stream, p);
-  hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), shm_apply, stream, p);
+  GNL(gn_stats_kernel, grid, dim3(256), shm_stats, stream, p);
+  if (p.finalized) GNL(gn_finalize_kernel, dim3(p.groups, p.nimg), dim3(256), 0, stream, p);
+  GNL(gn_apply_kernel, grid, dim3(256), shm_apply, stream, p);
   return 0;
 }
+#undef GNL
 
 extern "C" int nr_launch_layernorm(const bf16* x, int ldx, bf16* out, int ldo, int M, int C, const float* gamma,
                                    const float* beta, float eps, const float* pe, int pe_hw, int pe_F,
