@@ -1807,7 +1807,9 @@ extern "C" nr_status nr_net_load_tensor(nr_net* h, const char* key, const float*
   // "<tag>:<key>|<key>|..." (keys contain neither ':' nor '|'); the stacked time-embedding projections ("temb...") are rebuilt
   // when any time-embedding tensor changes.
   const std::string k(key);
-  const bool is_temb_src = k.find("time_emb") != std::string::npos || k.find("label_emb") != std::string::npos;
+  // (the sgm ResBlocks call theirs "<block>.emb_layers.1": openaimodel.py:283-289)
+  const bool is_temb_src = k.find("time_emb") != std::string::npos || k.find("label_emb") != std::string::npos ||
+                           k.find("emb_layers") != std::string::npos;
   auto derived_from = [&](const std::string& name) {
     size_t b = 0;
     while (b <= name.size()) {

@@ -3,9 +3,13 @@
   NativeSGMUNet            ~ sgm.modules.diffusionmodules.openaimodel.UNetModel (:472; forward :816-853) behind
                              OpenAIWrapper (wrappers.py:23-34); every FLOP runs in libneurons_amd.so
   LegacyDDPMDiscretization ~ discretizer.py:42-69 (+ make_beta_schedule util.py:20-33, append_zero sgm/util.py:188)
-  DiscreteDenoiser         ~ denoiser.py:42-75 with EpsScaling denoiser_scaling.py:29-37 (host scalars only)
-  EulerEDMSampler          ~ sampling.py:41-62,98-135,216-220 with VanillaCFG guiders.py:24-42; the per-element
-                             update (c_out/c_skip, CFG, to_d, Euler step) is the HIP kernel nr_edm_cfg_euler_step
+  NativeOpenAIWrapper      ~ wrappers.py:23-34: ``model(x, t, {"crossattn":…, "vector":…})``
+  DiscreteDenoiser         ~ denoiser.py:23-75 with EpsScaling denoiser_scaling.py:29-37: ``denoiser(network, x, sigma, cond)``
+  EulerEDMSampler          ~ sampling.py:41-62,98-135,216-220 with VanillaCFG guiders.py:24-42: ``sampler(denoiser_fn, x, cond=, uc=)``;
+                             on a native denoiser the per-element update (c_out/c_skip, CFG, to_d, Euler step) is the HIP kernel
+                             nr_edm_cfg_euler_step; a foreign closure gets the reference's loop, statement for statement
+  NativeDiffusionEngine    ~ sgm/models/diffusion.py DiffusionEngine, the attributes utils.unclip_recon (utils.py:302-350) and
+                             recon_keyframe_neurons_enhance.py:300-324 touch: the drop-in boundary of the keyframe path
   unclip_sample            ~ the sampling part of utils.unclip_recon (:308-340), on explicit z / noise tensors
 """
 import ctypes as C
@@ -238,36 +242,213 @@ class LegacyDDPMDiscretization:
         return sigmas.to(device)
 
 
+class EpsScaling:
+    """denoiser_scaling.py:29-37: (c_skip, c_out, c_in, c_noise) = (1, -sigma, 1 / sqrt(sigma^2 + 1), sigma)."""
+
+    def __call__(self, sigma: torch.Tensor):
+        c_skip = torch.ones_like(sigma, device=sigma.device)
+        c_out = -sigma
+        c_in = 1 / (sigma ** 2 + 1.0) ** 0.5
+        c_noise = sigma.clone()
+        return c_skip, c_out, c_in, c_noise
+
+
+def append_dims(x: torch.Tensor, target_dims: int) -> torch.Tensor:
+    """sgm/util.py:192-199."""
+    dims_to_append = target_dims - x.ndim
+    if dims_to_append < 0:
+        raise ValueError(f"input has {x.ndim} dims but target_dims is {target_dims}, which is less")
+    return x[(...,) + (None,) * dims_to_append]
+
+
 class DiscreteDenoiser:
-    """EpsScaling + sigma quantisation: the scalars the network call needs (denoiser.py:23-39,61-75)."""
+    """``DiscreteDenoiser`` (denoiser.py:42-75) with ``EpsScaling``: callable exactly like the reference module —
+    ``denoiser(network, input, sigma, cond)`` with a per-sample ``sigma`` tensor (``Denoiser.forward`` :23-39) — plus the host-scalar
+    view (``scalars``) the fused sampler path uses.  ``network`` is any callable ``network(x, c_noise, cond_dict)``; when it is a
+    ``NativeOpenAIWrapper`` and the batch shares one sigma (always the case under the EDM sampler) ``c_in`` rides into the HIP
+    boundary conv as ``in_scale`` instead of a separate elementwise pass."""
 
-    def __init__(self, num_idx=1000, discretization: Optional[LegacyDDPMDiscretization] = None):
+    def __init__(self, num_idx=1000, discretization: Optional[LegacyDDPMDiscretization] = None, do_append_zero=False,
+                 quantize_c_noise=True, flip=True):
         self.discretization = discretization or LegacyDDPMDiscretization()
-        self.sigmas = self.discretization(num_idx, do_append_zero=False, flip=True)     # ascending table
+        self.sigmas = self.discretization(num_idx, do_append_zero=do_append_zero, flip=flip)     # ascending table (flip=True)
+        self.quantize_c_noise = quantize_c_noise
         self.num_idx = num_idx
+        self.scaling = EpsScaling()
+        self._sig_dev = {}
 
-    def sigma_to_idx(self, sigma: float) -> int:
-        return int((torch.as_tensor(sigma, dtype=torch.float32) - self.sigmas).abs().argmin())
+    # ---- reference tensor surface (denoiser.py:61-75) ----
+    def _table(self, device):
+        t = self._sig_dev.get(device)
+        if t is None:
+            t = self._sig_dev[device] = self.sigmas.to(device)
+        return t
 
+    def sigma_to_idx(self, sigma):
+        if not torch.is_tensor(sigma):
+            return int((torch.as_tensor(sigma, dtype=torch.float32) - self.sigmas).abs().argmin())
+        dists = sigma - self._table(sigma.device)[:, None]
+        return dists.abs().argmin(dim=0).view(sigma.shape)
+
+    def idx_to_sigma(self, idx):
+        return self._table(idx.device)[idx] if torch.is_tensor(idx) else self.sigmas[idx]
+
+    def possibly_quantize_sigma(self, sigma):
+        return self.idx_to_sigma(self.sigma_to_idx(sigma))
+
+    def possibly_quantize_c_noise(self, c_noise):
+        return self.sigma_to_idx(c_noise) if self.quantize_c_noise else c_noise
+
+    def forward(self, network, input: torch.Tensor, sigma: torch.Tensor, cond: Dict, **additional_model_inputs) -> torch.Tensor:
+        sigma = self.possibly_quantize_sigma(sigma)
+        sigma_shape = sigma.shape
+        sigma = append_dims(sigma, input.ndim)
+        c_skip, c_out, c_in, c_noise = self.scaling(sigma)
+        c_noise = self.possibly_quantize_c_noise(c_noise.reshape(sigma_shape))
+        if isinstance(network, NativeOpenAIWrapper) and not additional_model_inputs and bool((sigma == sigma.reshape(-1)[0]).all()):
+            net = network(input, c_noise, cond, in_scale=float(c_in.reshape(-1)[0]))
+        else:
+            net = network(input * c_in, c_noise, cond, **additional_model_inputs)
+        return net * c_out + input * c_skip
+
+    __call__ = forward
+
+    # ---- host scalars for the fused HIP update (nr_edm_cfg_euler_step) ----
     def scalars(self, sigma: float):
         """-> (sigma_quantised, c_in, c_noise index)"""
-        idx = self.sigma_to_idx(sigma)
+        idx = self.sigma_to_idx(float(sigma))
         sq = float(self.sigmas[idx])
         c_in = float(1.0 / (torch.tensor(sq, dtype=torch.float32) ** 2 + 1.0) ** 0.5)
         return sq, c_in, idx
 
 
-class EulerEDMSampler:
-    """EulerEDMSampler(s_churn=0) + VanillaCFG on the native network."""
+class VanillaCFG:
+    """guiders.py:24-42."""
 
-    def __init__(self, num_steps=38, scale=5.0, discretization: Optional[LegacyDDPMDiscretization] = None):
-        self.num_steps = num_steps
+    def __init__(self, scale: float):
         self.scale = scale
-        self.discretization = discretization or LegacyDDPMDiscretization()
-        self.denoiser = DiscreteDenoiser(discretization=self.discretization)
 
-    def __call__(self, network: NativeSGMUNet, x, cond: Dict[str, torch.Tensor], uc: Optional[Dict[str, torch.Tensor]] = None,
+    def __call__(self, x: torch.Tensor, sigma: torch.Tensor) -> torch.Tensor:
+        x_u, x_c = x.chunk(2)
+        return x_u + self.scale * (x_c - x_u)
+
+    def prepare_inputs(self, x, s, c, uc):
+        c_out = dict()
+        for k in c:
+            if k in ["vector", "crossattn", "concat"]:
+                c_out[k] = torch.cat((uc[k], c[k]), 0)
+            else:
+                assert c[k] == uc[k]
+                c_out[k] = c[k]
+        return torch.cat([x] * 2), torch.cat([s] * 2), c_out
+
+
+class NativeOpenAIWrapper:
+    """``OpenAIWrapper`` (wrappers.py:23-34) around a ``NativeSGMUNet``: ``model(x, t, c_dict)`` with the conditioning under the
+    keys ``crossattn`` / ``vector`` (an empty or absent ``concat`` is accepted, a non-empty one is not on the NEURONS path)."""
+
+    def __init__(self, diffusion_model: "NativeSGMUNet", compile_model: bool = False):
+        self.diffusion_model = diffusion_model
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor, c: dict, **kwargs) -> torch.Tensor:
+        cc = c.get("concat", None)
+        if cc is not None and cc.numel() > 0:
+            raise NotImplementedError("'concat' conditioning is not used by unclip6.yaml")
+        return self.diffusion_model(x, timesteps=t, context=c.get("crossattn", None), y=c.get("vector", None), **kwargs)
+
+    __call__ = forward
+
+    def to(self, device=None, dtype=None):
+        self.diffusion_model.to(device)
+        return self
+
+    def eval(self):
+        return self
+
+    def parameters(self):
+        return iter(())
+
+
+def _closure_objects(fn):
+    """Objects a python callable closes over (closure cells, bound ``self``, functools.partial arguments): used only to RECOGNISE the
+    ``denoiser`` closure utils.unclip_recon builds (utils.py:337-338) around a native engine; anything else takes the generic path."""
+    seen = []
+    for cell in getattr(fn, "__closure__", None) or ():
+        try:
+            seen.append(cell.cell_contents)
+        except ValueError:
+            pass
+    if getattr(fn, "__self__", None) is not None:
+        seen.append(fn.__self__)
+    if hasattr(fn, "func") and hasattr(fn, "args"):            # functools.partial
+        seen.extend(fn.args)
+        seen.extend((fn.keywords or {}).values())
+        seen.extend(_closure_objects(fn.func))
+    return seen
+
+
+class EulerEDMSampler:
+    """``EulerEDMSampler`` (sampling.py:216-220; ``EDMSampler.__call__`` :114-135, ``sampler_step`` :98-112 with s_churn = 0 =>
+    gamma = 0; ``prepare_sampling_loop`` :41-57) + ``VanillaCFG``.  Call it as the reference does::
+
+        samples = sampler(denoiser, x, cond=c, uc=uc)        # denoiser(x, sigma, c) -> denoised      (utils.py:337-340)
+
+    ``denoiser`` may be
+      * the closure utils.unclip_recon builds around a ``NativeDiffusionEngine`` (recognised by what it closes over), a
+        ``NativeDiffusionEngine`` / ``NativeOpenAIWrapper`` / ``NativeSGMUNet``: the FUSED path — the network evaluation with ``c_in`` folded
+        into its boundary conv, then ONE HIP kernel (nr_edm_cfg_euler_step) for c_out / c_skip, CFG combine, to_d and the Euler update;
+      * any other callable ``denoiser(x, sigma, c)``: the generic path, statement for statement the reference's loop (guider.prepare_inputs
+        -> denoiser -> guider -> to_d -> euler_step) on torch tensors.  A foreign closure that routes into a native network still runs
+        every network FLOP in HIP; only the per-step scalars differ in where they are applied."""
+
+    def __init__(self, num_steps=38, scale=5.0, discretization: Optional[LegacyDDPMDiscretization] = None, s_churn=0.0, s_tmin=0.0,
+                 s_tmax=float("inf"), s_noise=1.0, verbose=False, device="cuda"):
+        if s_churn != 0.0:
+            raise NotImplementedError("s_churn != 0 (stochastic churn) is not on the NEURONS path (unclip6.yaml sampler_config)")
+        self.num_steps = num_steps
+        self.guider = VanillaCFG(scale)
+        self.discretization = discretization or LegacyDDPMDiscretization()
+        self.denoiser = DiscreteDenoiser(discretization=self.discretization)     # host scalars of the fused path
+        self.s_churn, self.s_tmin, self.s_tmax, self.s_noise = s_churn, s_tmin, s_tmax, s_noise
+        self.verbose = verbose
+        self.device = device
+        self._engine = None          # set by NativeDiffusionEngine: lets the sampler recognise the engine's own denoiser closure
+
+    @property
+    def scale(self):
+        return self.guider.scale
+
+    @scale.setter
+    def scale(self, v):
+        self.guider.scale = v
+
+    def prepare_sampling_loop(self, x, cond, uc=None, num_steps=None):
+        sigmas = self.discretization(self.num_steps if num_steps is None else num_steps, device=x.device)
+        uc = cond if uc is None else uc
+        x = x * torch.sqrt(1.0 + sigmas[0] ** 2.0)                                                   # sampling.py:52
+        num_sigmas = len(sigmas)
+        s_in = x.new_ones([x.shape[0]])
+        return x, s_in, sigmas, num_sigmas, cond, uc
+
+    def _native_network(self, denoiser):
+        """The NativeSGMUNet behind ``denoiser`` if it is one of the recognised native forms, else None."""
+        if isinstance(denoiser, NativeSGMUNet):
+            return denoiser
+        if isinstance(denoiser, NativeOpenAIWrapper):
+            return denoiser.diffusion_model
+        if isinstance(denoiser, NativeDiffusionEngine):
+            return denoiser.model.diffusion_model
+        if callable(denoiser):
+            for obj in _closure_objects(denoiser):
+                if isinstance(obj, NativeDiffusionEngine) and (self._engine is None or obj is self._engine) and obj.is_native():
+                    return obj.model.diffusion_model
+        return None
+
+    def __call__(self, denoiser, x, cond: Dict[str, torch.Tensor], uc: Optional[Dict[str, torch.Tensor]] = None,
                  num_steps: Optional[int] = None):
+        network = self._native_network(denoiser)
+        if network is None:            # a foreign denoiser: the reference's loop around it, on whatever device its tensors live
+            return self._generic_loop(denoiser, x, cond, uc, num_steps)
         if not x.is_cuda:
             raise RuntimeError("EulerEDMSampler runs the HIP kernels: CUDA (ROCm) tensors required; there is no CPU fallback")
         uc = cond if uc is None else uc
@@ -284,16 +465,111 @@ class EulerEDMSampler:
             net = network(xin, float(idx), context=ctx, y=vec, in_scale=c_in)
             x_new = torch.empty_like(x)
             _lib.check(lib.nr_edm_cfg_euler_step(torch.cuda.current_stream().cuda_stream, net.data_ptr(), x.data_ptr(),
-                                                 x_new.data_ptr(), n, float(self.scale), sq, s, s_next))
+                                                 x_new.data_ptr(), n, float(self.guider.scale), sq, s, s_next))
             x = x_new
         return x
 
+    def _generic_loop(self, denoiser, x, cond, uc, num_steps):
+        x, s_in, sigmas, num_sigmas, cond, uc = self.prepare_sampling_loop(x.to(torch.float32), cond, uc, num_steps)
+        for i in range(num_sigmas - 1):
+            sigma, next_sigma = s_in * sigmas[i], s_in * sigmas[i + 1]                                # gamma = 0: sigma_hat = sigma
+            denoised = denoiser(*self.guider.prepare_inputs(x, sigma, cond, uc))                      # sampling.py:59-62
+            denoised = self.guider(denoised, sigma)
+            d = (x - denoised) / append_dims(sigma, x.ndim)                                           # to_d, sampling_utils.py:34-35
+            x = x + append_dims(next_sigma - sigma, x.ndim) * d                                       # euler_step, sampling.py:83-84
+        return x
 
-def unclip_sample(network: NativeSGMUNet, tokens, vector_suffix, z, noise, uc_tokens, sampler: EulerEDMSampler,
+
+class NativeDiffusionEngine:
+    """The surface of ``sgm.models.diffusion.DiffusionEngine`` that the keyframe script and ``utils.unclip_recon`` touch
+    (recon_keyframe_neurons_enhance.py:300-324,458-462; utils.py:302-350), backed by libneurons_amd.so:
+
+        .model                 NativeOpenAIWrapper(NativeSGMUNet)        model(x, t, c_dict)                        wrappers.py:23-34
+        .denoiser              DiscreteDenoiser (EpsScaling)             denoiser(model, x, sigma, c)               denoiser.py:23-75
+        .sampler               EulerEDMSampler + VanillaCFG              sampler(denoiser_fn, x, cond=, uc=); .discretization(n); .num_steps
+        .first_stage_model     NativeVAEDecoder                          decode_first_stage(z)                      diffusion.py:118-135
+        .ema_scope()           no-op context (use_ema is False in unclip6.yaml; diffusion.py:198-210)
+        .eval() / .requires_grad_() / .to(device) / .load_state_dict(ckpt["state_dict"])
+
+    ``load_state_dict`` takes the checkpoint's key names: ``model.diffusion_model.*`` -> the U-Net, ``first_stage_model.{decoder,
+    post_quant_conv}.*`` -> the decoder; ``conditioner.*`` (open_clip embedders, not called by unclip_recon), ``denoiser.sigmas`` (regenerated),
+    ``first_stage_model.{encoder,quant_conv,loss}.*`` and ``model_ema.*`` are ignored."""
+
+    def __init__(self, network_config: Optional[SGMUNetConfig] = None, first_stage_config=None, num_steps: int = 38, scale: float = 5.0,
+                 scale_factor: float = 0.18215, disable_first_stage_autocast: bool = True, use_ema: bool = False, **ignored):
+        from .vae import NativeVAEDecoder, VAEDecoderConfig
+        if use_ema:
+            raise NotImplementedError("use_ema: inference checkpoints carry the EMA weights already (unclip6.yaml has no EMA)")
+        self.model = NativeOpenAIWrapper(NativeSGMUNet(network_config or SGMUNetConfig()))
+        self.first_stage_model = NativeVAEDecoder(first_stage_config or VAEDecoderConfig())
+        disc = LegacyDDPMDiscretization()
+        self.denoiser = DiscreteDenoiser(discretization=disc)
+        self.sampler = EulerEDMSampler(num_steps=num_steps, scale=scale, discretization=disc)
+        self.sampler._engine = self
+        self.scale_factor = scale_factor
+        self.disable_first_stage_autocast = disable_first_stage_autocast
+        self.use_ema = False
+        self.conditioner = None
+        self._native_denoiser, self._native_model = self.denoiser, self.model
+
+    def is_native(self):
+        """False once a caller has swapped .denoiser / .model for foreign objects: the sampler then takes the generic path."""
+        return self.denoiser is self._native_denoiser and self.model is self._native_model
+
+    def ema_scope(self, context=None):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def eval(self):
+        return self
+
+    def requires_grad_(self, flag=False):
+        return self
+
+    def to(self, device=None, dtype=None):
+        self.model.to(device)
+        self.first_stage_model.to(device)
+        return self
+
+    @property
+    def device(self):
+        return self.model.diffusion_model.device
+
+    def load_state_dict(self, state_dict, strict=True):
+        unet_sd, vae_sd, ignored, unexpected = {}, {}, [], []
+        for k, v in state_dict.items():
+            if k.startswith("model.diffusion_model."):
+                unet_sd[k[len("model.diffusion_model."):]] = v
+            elif k.startswith("first_stage_model."):
+                kk = k[len("first_stage_model."):]
+                if kk.startswith("decoder.") or kk.startswith("post_quant_conv."):
+                    vae_sd[kk] = v
+                else:
+                    ignored.append(k)
+            elif k.startswith(("conditioner.", "denoiser.", "model_ema.", "loss_fn.")):
+                ignored.append(k)
+            else:
+                unexpected.append(k)
+        m1, u1 = self.model.diffusion_model.load_state_dict(unet_sd, strict=False)
+        m2, u2 = self.first_stage_model.load_state_dict(vae_sd, strict=False)
+        missing = ["model.diffusion_model." + k for k in m1] + ["first_stage_model." + k for k in m2]
+        unexpected += ["model.diffusion_model." + k for k in u1] + ["first_stage_model." + k for k in u2]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for NativeDiffusionEngine:\n\tMissing key(s): {missing[:8]}"
+                               f"{'...' if len(missing) > 8 else ''}\n\tUnexpected key(s): {unexpected[:8]}")
+        return missing, unexpected
+
+    @torch.no_grad()
+    def decode_first_stage(self, z):
+        return self.first_stage_model.decode_first_stage(z, scale_factor=self.scale_factor)
+
+
+def unclip_sample(network, tokens, vector_suffix, z, noise, uc_tokens, sampler: EulerEDMSampler,
                   offset_noise: Optional[torch.Tensor] = None, offset_noise_level: float = 0.04):
     """Sampling part of ``utils.unclip_recon`` (utils.py:308-340) on explicit tensors: ``tokens`` (1,256,1664) prior
     tokens x key-object mask, ``vector_suffix`` (1,1024), starting ``z`` and ``noise`` (n,4,h,w), ``uc_tokens`` the
-    random unconditional tokens (:318), ``offset_noise`` (n,) the per-sample offset draw (:328-331)."""
+    random unconditional tokens (:318), ``offset_noise`` (n,) the per-sample offset draw (:328-331).  ``network``: a NativeSGMUNet or
+    anything else ``EulerEDMSampler.__call__`` accepts as its denoiser."""
     n = z.shape[0]
     c = {"crossattn": tokens.repeat(n, 1, 1).to(z.device), "vector": vector_suffix.repeat(n, 1).to(z.device)}
     uc = {"crossattn": uc_tokens.repeat(n, 1, 1).to(z.device), "vector": vector_suffix.repeat(n, 1).to(z.device)}
