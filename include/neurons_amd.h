@@ -95,7 +95,7 @@ const char* nr_last_error(void);
  * ignored; missing keys are reported at nr_net_plan(). */
 nr_status nr_net_load_tensor(nr_net* h, const char* key, const float* host_data, const int64_t* shape, int32_t ndim);
 
-/* Fix the problem size: batch = CFG-expanded batch (2B, <= 16), frames F, latent h x w, ctx_len =
+/* Fix the problem size: batch = CFG-expanded batch (2B; <= 64: the grouped SparseCtrl schedule plans G x 2B), frames F, latent h x w, ctx_len =
  * tokens of encoder_hidden_states (77 for CLIP).  Converts/uploads
  * weights (first call), builds the launch plan and allocates the workspace arena.  May be called
  * again with another shape. */

@@ -194,7 +194,7 @@ __global__ void timestep_sincos_kernel(const float* __restrict__ t, int M, int d
   out[(size_t)m * dim + half + i] = sinf(a);
 }
 
-// y[m][n] = sum_k act(x[m][k]) * W[n][k] + b[n];  one wave per n, M <= 16, K % 8 == 0.  act: 0 none, 1 SiLU (on input)
+// y[m][n] = sum_k act(x[m][k]) * W[n][k] + b[n];  one wave per (n, 16-row slab of m), K % 8 == 0.  act: 0 none, 1 SiLU (on input)
 // out_act: 0 none, 1 SiLU (on output)
 __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ x, int M, int K,
                                                            const bf16* __restrict__ W, const float* __restrict__ b, int N,
@@ -203,6 +203,12 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
+  {   // blockIdx.y: 16-row slab of the batch
+    const int m0 = blockIdx.y * 16;
+    x += (size_t)m0 * K; y += (size_t)m0 * N;
+    if (addend) addend += (size_t)m0 * N;
+    M = M - m0 < 16 ? M - m0 : 16;
+  }
   float acc[16];
 #pragma unroll
   for (int m = 0; m < 16; ++m) acc[m] = 0.f;
@@ -437,8 +443,8 @@ extern "C" int nr_launch_timestep_sincos(const float* t, int M, int dim, float* 
 
 extern "C" int nr_launch_linear_small(const float* x, int M, int K, const bf16* W, const float* b, int N, int in_act,
                                       int out_act, float* y, const float* addend, hipStream_t stream) {
-  if (M > 16 || K % 8 != 0) return 1;
-  hipLaunchKernelGGL(linear_small_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, x, M, K, W, b, N, in_act, out_act, y,
+  if (M <= 0 || K % 8 != 0) return 1;
+  hipLaunchKernelGGL(linear_small_kernel, dim3((N + 3) / 4, (M + 15) / 16), dim3(256), 0, stream, x, M, K, W, b, N, in_act, out_act, y,
                      addend);
   return 0;
 }

@@ -194,7 +194,8 @@ __global__ void copy16_kernel(const uint4* __restrict__ a, uint4* __restrict__ b
   if (i < n16) b[i] = a[i];
 }
 
-struct TimestepVals { float v[16]; };
+constexpr int NR_MAX_BATCH = 64;   // samples per evaluation (CFG-expanded; the grouped SparseCtrl schedule runs G x 2B of them)
+struct TimestepVals { float v[NR_MAX_BATCH]; };
 __global__ void set_timesteps_kernel(float* dst, TimestepVals tv, int n) {
   if (threadIdx.x < n) dst[threadIdx.x] = tv.v[threadIdx.x];
 }
@@ -260,7 +261,7 @@ struct nr_net {
   // SparseCtrl evaluation issued ahead of time for the NEXT denoising step (nr_denoise_step_forward): its inputs do
   // not depend on the latents, only on the timestep / context / condition
   bool prefetch_valid = false;
-  float prefetch_t[16] = {0};
+  float prefetch_t[NR_MAX_BATCH] = {0};
   IO prefetch_io;
   // graph replay happens on an engine-owned non-blocking stream (capture is illegal on the legacy default
   // stream PyTorch hands over); it is fenced to the caller's stream with two events per forward
@@ -1021,7 +1022,7 @@ struct nr_net {
     }
     // ---- emb = time_embed(sinusoid(t)) + label_emb(y)  (openaimodel.py:836-841); every ResBlock then applies
     // Linear(SiLU(emb)) (emb_layers, :283-289): batched into ONE launch ----
-    t_dev = new_scratch<float>(16);
+    t_dev = new_scratch<float>(NR_MAX_BATCH);
     float* sincos = new_scratch<float>((size_t)B2 * C0);
     float* e1 = new_scratch<float>((size_t)B2 * temb_dim);
     float* et = new_scratch<float>((size_t)B2 * temb_dim);
@@ -1201,7 +1202,7 @@ struct nr_net {
     if (F != 1) throw NrError(NR_ERR_ARG, "the VAE decoder is a 2-D network: plan with frames = 1");
     ctx_persist.clear(); ops.clear(); ctx_ops.clear(); op_meta.clear(); taps.clear(); arena.reset(); parena.reset();
     temb_slots.clear(); temb_total = 0; temb_all = nullptr;
-    t_dev = new_scratch<float>(16);
+    t_dev = new_scratch<float>(NR_MAX_BATCH);
     const int Cm = cfg.block_out_channels[L - 1];
     float* zq = new_scratch<float>((size_t)nimg * zc * H * W);
     {
@@ -1258,7 +1259,7 @@ struct nr_net {
     if (F != 1) throw NrError(NR_ERR_ARG, "the VAE encoder is a 2-D network: plan with frames = 1");
     ctx_persist.clear(); ops.clear(); ctx_ops.clear(); op_meta.clear(); taps.clear(); arena.reset(); parena.reset();
     temb_slots.clear(); temb_total = 0; temb_all = nullptr;
-    t_dev = new_scratch<float>(16);
+    t_dev = new_scratch<float>(NR_MAX_BATCH);
     const int C0 = cfg.block_out_channels[0];
     Act x = new_act(nimg, H, W, C0);
     {
@@ -1322,7 +1323,7 @@ struct nr_net {
     if (L > cfg.motion_pe_max_len) throw NrError(NR_ERR_ARG, "sequence longer than max_position_embeddings");
     ctx_persist.clear(); ops.clear(); ctx_ops.clear(); op_meta.clear(); taps.clear(); arena.reset(); parena.reset();
     temb_slots.clear(); temb_total = 0; temb_all = nullptr;
-    t_dev = new_scratch<float>(16);
+    t_dev = new_scratch<float>(NR_MAX_BATCH);
     const std::string tm = "text_model.";
     Act x = new_act(B2, 1, L, C);
     {
@@ -1380,7 +1381,7 @@ struct nr_net {
 
     // ---- time embedding (unet.py:371-392): sinusoid -> Linear -> SiLU -> Linear ; then every
     // resnet's Linear(SiLU(emb)) (resnet.py:191) in ONE batched launch ----
-    t_dev = new_scratch<float>(16);
+    t_dev = new_scratch<float>(NR_MAX_BATCH);
     float* sincos = new_scratch<float>((size_t)B2 * C0);
     float* emb1 = new_scratch<float>((size_t)B2 * temb_dim);
     float* emb = new_scratch<float>((size_t)B2 * temb_dim);
@@ -1602,7 +1603,7 @@ struct nr_net {
 
   void plan(int batch, int frames, int h, int w, int ctxl) {
     const bool vae = cfg.kind == NR_KIND_VAE_DECODER || cfg.kind == NR_KIND_VAE_ENCODER || cfg.kind == NR_KIND_CLIP_TEXT;
-    if (batch <= 0 || batch > 16 || frames <= 0 || h <= 0 || w <= 0 || (ctxl <= 0 && !vae)) throw NrError(NR_ERR_ARG, "plan: bad shape");
+    if (batch <= 0 || batch > NR_MAX_BATCH || frames <= 0 || h <= 0 || w <= 0 || (ctxl <= 0 && !vae)) throw NrError(NR_ERR_ARG, "plan: bad shape");
     const int down = (cfg.kind == NR_KIND_VAE_DECODER || cfg.kind == NR_KIND_CLIP_TEXT) ? 1 : 1 << (cfg.num_levels - 1);
     if (h % down != 0 || w % down != 0)
       throw NrError(NR_ERR_ARG, "plan: latent h,w must be multiples of " + std::to_string(down));
@@ -1652,7 +1653,7 @@ struct nr_net {
   }
   void set_timesteps(hipStream_t s, const float* timesteps) {
     TimestepVals tv;
-    for (int i = 0; i < 16; ++i) tv.v[i] = i < B2 ? timesteps[i] : 0.f;
+    for (int i = 0; i < NR_MAX_BATCH; ++i) tv.v[i] = i < B2 ? timesteps[i] : 0.f;
     hipLaunchKernelGGL(set_timesteps_kernel, dim3(1), dim3(64), 0, s, t_dev, tv, B2);
   }
   // launch ops [begin, end) of segment `seg` on `s` as a (re)captured hipGraph
@@ -2117,7 +2118,7 @@ extern "C" nr_status nr_denoise_step_forward(nr_net* unet, nr_net* ctrl, nr_stre
       HIP_OK(hipEventRecord(ctrl->ev_out, ctrl->own_stream));
       ctrl->prefetch_valid = true;
       ctrl->prefetch_io = ic;
-      for (int i = 0; i < 16; ++i) ctrl->prefetch_t[i] = i < ctrl->B2 ? next_timesteps[i] : 0.f;
+      for (int i = 0; i < NR_MAX_BATCH; ++i) ctrl->prefetch_t[i] = i < ctrl->B2 ? next_timesteps[i] : 0.f;
     }
   }
   NR_CATCH
@@ -2243,7 +2244,7 @@ extern "C" nr_status nr_vae_decode(nr_net* h, nr_stream stream, const float* z_d
   std::memset(&io, 0, sizeof(io));
   io.sample = z_dev; io.out = out_dev; io.in_scale = z_scale; io.out_mul = out_mul; io.out_add = out_add; io.clamp01 = clamp01 ? 1 : 0; io.scale = 1.f; io.cond_batch = 1;
   h->io = io;
-  const float zeros[16] = {0};
+  const float zeros[NR_MAX_BATCH] = {0};
   h->run((hipStream_t)stream, zeros);
   NR_CATCH
 }
@@ -2258,7 +2259,7 @@ extern "C" nr_status nr_clip_text_forward(nr_net* h, nr_stream stream, const int
   std::memset(&io, 0, sizeof(io));
   io.ids = ids_dev; io.out = out_dev; io.in_scale = 1.f; io.out_mul = 1.f; io.scale = 1.f; io.cond_batch = 1;
   h->io = io;
-  const float zeros[16] = {0};
+  const float zeros[NR_MAX_BATCH] = {0};
   h->run((hipStream_t)stream, zeros);
   NR_CATCH
 }
@@ -2273,7 +2274,7 @@ extern "C" nr_status nr_vae_encode(nr_net* h, nr_stream stream, const float* x_d
   std::memset(&io, 0, sizeof(io));
   io.sample = x_dev; io.out = moments_dev; io.in_scale = in_mul; io.in_shift = in_add; io.out_mul = 1.f; io.scale = 1.f; io.cond_batch = 1;
   h->io = io;
-  const float zeros[16] = {0};
+  const float zeros[NR_MAX_BATCH] = {0};
   h->run((hipStream_t)stream, zeros);
   NR_CATCH
 }

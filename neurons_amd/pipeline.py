@@ -286,9 +286,14 @@ class NeuroclipsPipeline:
         n_lat = latents.numel()
         fused = use_ctrl and hasattr(self.unet, "forward_with_controlnet") and \
             getattr(self.controlnet, "set_noisy_sample_input_to_zero", False) and self.overlap_controlnet
-        # grouped schedule: G steps per SparseCtrl evaluation, at most 16 samples per evaluation (engine limit)
+        # grouped schedule: G steps per SparseCtrl evaluation; at most 64 samples per evaluation (engine limit NR_MAX_BATCH) and 2 Mi
+        # level-0 rows (the largest evaluation the full-size tests exercise: 8 clips x CFG x G = 4 at 16 f x 32 x 32, and BASELINE
+        # config 5's 4 clips x CFG x G = 2 at 32 f x 64 x 64)
         b2 = latents.shape[0] * (2 if do_classifier_free_guidance else 1)
-        G = max(1, min(self.controlnet_group, 16 // b2, len(timesteps_host))) if (fused and hasattr(self.controlnet, "forward_async")) else 1
+        rows1 = b2 * latents.shape[2] * latents.shape[3] * latents.shape[4]
+        G = max(1, min(self.controlnet_group, 64 // b2, (2 << 20) // rows1, len(timesteps_host))) \
+            if (fused and hasattr(self.controlnet, "forward_async")) else 1
+        self.last_controlnet_group = G
         pending = {}
 
         def launch_group(g):

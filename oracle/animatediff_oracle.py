@@ -112,6 +112,9 @@ def resnet_block3d(sd: SD, p: str, x, temb, groups, eps):
     return x + h
 
 
+ATTN_SCORE_BUDGET_BYTES = 4 << 30      # fp32 score matrix held at once by cross_attention (slicing over batch*heads; values unchanged)
+
+
 def _heads_to_batch(t, heads):
     """CrossAttention.reshape_heads_to_batch_dim — motion_module_new.py:181-186."""
     b, s, d = t.shape
@@ -133,10 +136,18 @@ def cross_attention(sd: SD, p: str, x, ctx, heads):
     v = F.linear(ctx, sd[f"{p}.to_v.weight"])
     d = q.shape[-1] // heads
     q, k, v = _heads_to_batch(q, heads), _heads_to_batch(k, heads), _heads_to_batch(v, heads)
-    scores = torch.baddbmm(torch.empty(q.shape[0], q.shape[1], k.shape[1], dtype=q.dtype, device=q.device), q,
-                           k.transpose(-1, -2), beta=0, alpha=d ** -0.5)
-    probs = scores.softmax(dim=-1)
-    o = _batch_to_heads(torch.bmm(probs, v), heads)
+    # The (batch*heads) problems are independent, so they may be evaluated a slice at a time without changing any value: at BASELINE
+    # config 5 (64 x 64 latent, 32 frames) the full fp32 score tensor would be 34 GB ("materialises ... scores").
+    nb = q.shape[0]
+    per = max(1, int(ATTN_SCORE_BUDGET_BYTES // max(1, q.shape[1] * k.shape[1] * q.element_size())))
+    outs = []
+    for b0 in range(0, nb, per):
+        qs, ks, vs = q[b0:b0 + per], k[b0:b0 + per], v[b0:b0 + per]
+        scores = torch.baddbmm(torch.empty(qs.shape[0], qs.shape[1], ks.shape[1], dtype=q.dtype, device=q.device), qs,
+                               ks.transpose(-1, -2), beta=0, alpha=d ** -0.5)
+        probs = scores.softmax(dim=-1)
+        outs.append(torch.bmm(probs, vs))
+    o = _batch_to_heads(outs[0] if len(outs) == 1 else torch.cat(outs), heads)
     return F.linear(o, sd[f"{p}.to_out.0.weight"], sd[f"{p}.to_out.0.bias"])
 
 

@@ -1,0 +1,125 @@
+"""GPU parity at the two BASELINE configurations that round 2 only ever ran through bench.py:
+
+  C4  one GPU's share of "8 clips per GPU, enhance mode": EIGHT clips in ONE pipeline call at full SD-1.5 width, (8,4,16,32,32) latents,
+      SparseCtrl on (grouped schedule kept at B = 8: 4 DDIM steps x 16 CFG samples = 64 samples per evaluation), CFG 8.5, 6 DDIM steps:
+      batched call vs 8 independent B = 1 calls, and clips 0 and 7 vs the fp32 oracle.
+      Reference semantics: a batch of clips == B independent B = 1 calls (sparse_controlnet.py:490-521 only broadcasts a batch-1
+      condition); scripts/neuroclips_video.py:206,238 run batch_size = 1 per rank.
+  C5  "fp8 MFMA attention + 32-frame 512x512 clips": one evaluation of both full-width networks at (2*1,4,32,64,64) with
+      temporal_position_encoding_max_len = 32 (motion_module.py:241-243 raises the reference's broadcast error beyond 24 otherwise),
+      bf16 attention and the e4m3 variant, vs the fp32 oracle (its attention evaluated a slice of batch*heads at a time).
+
+Stated tolerances: loop level PSNR >= 40 dB and rel-L2 <= 3e-2 vs the fp32 oracle (as test_fullsize_gpu.py); one evaluation
+rel-L2 <= 2.5e-2 (bf16) / <= 6e-2 (e4m3 attention operands); batched vs independent clips: PSNR >= 50 dB (same kernels, but the tile
+plan, split-K depth and the LayerNorm-fold choice depend on M, so fp32 summation order and two bf16 rounding points differ)."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+from test_engine_gpu import metrics  # noqa: E402
+
+LOOP_PSNR_DB, LOOP_REL_L2, FWD_REL_L2, FWD_REL_L2_FP8 = 40.0, 3e-2, 2.5e-2, 6e-2
+BATCH_VS_SINGLE_DB = 50.0
+
+
+@pytest.fixture(scope="module")
+def nets(cuda):
+    """ONE pair of full-width networks for the module.  The U-Net is built with temporal_position_encoding_max_len = 32 (what 32-frame
+    clips need); for the 16-frame C4 case that is the SAME network as the default 24 (the sinusoid table is a function of the position
+    only, motion_module.py:225-239, and is regenerated at load)."""
+    n = _nets(cuda, 32)
+    yield n
+    n["unet"].set_attention_fp8(False)
+    n["ctrl"].set_attention_fp8(False)
+
+
+def _nets(cuda, pe_max_len_unet):
+    from neurons_amd import _lib, NativeSparseCtrl, NativeUNet3D
+    from neurons_amd.sparsectrl import controlnet_config_from_unet
+    from neurons_amd.synth import gpu_random_state_dict
+    from neurons_amd.unet3d import UNet3DConfig, state_dict_schema
+    from oracle import animatediff_oracle as O
+    kw = {}
+    if pe_max_len_unet != 24:
+        kw["motion_module_kwargs"] = dict(UNet3DConfig().motion_module_kwargs, temporal_position_encoding_max_len=pe_max_len_unet)
+    ucfg = UNet3DConfig(**kw)
+    ccfg = controlnet_config_from_unet(ucfg, dict(
+        set_noisy_sample_input_to_zero=True, use_simplified_condition_embedding=True, conditioning_channels=4,
+        motion_module_kwargs=dict(attention_block_types=["Temporal_Self"], temporal_position_encoding_max_len=32)))
+    usd = gpu_random_state_dict(state_dict_schema(ucfg, _lib.NR_KIND_UNET3D), 1, cuda)
+    csd = gpu_random_state_dict(state_dict_schema(ccfg, _lib.NR_KIND_SPARSECTRL), 2, cuda)
+    unet, ctrl = NativeUNet3D(ucfg).to(cuda), NativeSparseCtrl(ccfg).to(cuda)
+    unet.auto_release_host_weights = False        # both handles are driven at several batch sizes here
+    ctrl.auto_release_host_weights = False
+    unet.load_state_dict({k: v.cpu() for k, v in usd.items()})
+    ctrl.load_state_dict({k: v.cpu() for k, v in csd.items()})
+    return dict(O=O, unet=unet, ctrl=ctrl, usd=usd, csd=csd, ou=O.OracleConfig.from_native(ucfg), oc=O.OracleConfig.from_native(ccfg),
+                ucfg=ucfg)
+
+
+def test_c4_eight_clips_per_call_full_width(cuda, nets):
+    from neurons_amd import DDIMScheduler, NeuroclipsPipeline
+    n = nets
+    O = n["O"]
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
+    pipe = NeuroclipsPipeline(vae=None, text_encoder=None, tokenizer=None, unet=n["unet"], scheduler=sched, controlnet=n["ctrl"]).to(cuda)
+    B, F, L, steps = 8, 16, 32, 6
+    g = torch.Generator(device=cuda).manual_seed(1000)
+    lat = torch.randn(B, 4, F, L, L, generator=g, device=cuda)
+    noise = torch.randn(B, 4, F, L, L, generator=g, device=cuda)
+    ctx_u = torch.randn(B, 77, n["ucfg"].cross_attention_dim, generator=g, device=cuda)
+    ctx_t = torch.randn(B, 77, n["ucfg"].cross_attention_dim, generator=g, device=cuda)
+    cimg = torch.randn(B, 4, 1, L, L, generator=g, device=cuda) * 0.18215
+    kw = dict(video_length=F, height=L * 8, width=L * 8, num_inference_steps=steps, guidance_scale=8.5, controlnet_image_index=[0],
+              low_strength=0.3, output_type="latent")
+    both = pipe([""] * B, latents=lat, noise=noise, text_embeddings=torch.cat([ctx_u, ctx_t]), controlnet_images=cimg, **kw).videos.clone()
+    assert pipe.last_controlnet_group == 4, "B = 8 must keep the grouped SparseCtrl schedule (64 samples per evaluation)"
+    assert torch.isfinite(both).all()
+    worst = 1e9
+    for i in range(B):
+        one = pipe("", latents=lat[i:i + 1], noise=noise[i:i + 1], text_embeddings=torch.cat([ctx_u[i:i + 1], ctx_t[i:i + 1]]),
+                   controlnet_images=cimg[i:i + 1], **kw).videos
+        rel, psnr = metrics(f"C4: clip {i} of a batch of {B} vs the same clip alone", both[i:i + 1], one)
+        worst = min(worst, psnr)
+    assert worst >= BATCH_VS_SINGLE_DB, worst
+    for i in (0, B - 1):
+        with torch.no_grad():
+            want, _ = O.neuroclips_denoise(n["usd"], n["ou"], n["csd"], n["oc"], lat[i:i + 1], noise[i:i + 1],
+                                           torch.cat([ctx_u[i:i + 1], ctx_t[i:i + 1]]), cimg[i:i + 1], (0,), steps, 8.5)
+        rel, psnr = metrics(f"C4: clip {i} of the batched call vs the fp32 oracle ({steps} DDIM steps)", both[i:i + 1], want)
+        assert psnr >= LOOP_PSNR_DB and rel <= LOOP_REL_L2, (i, psnr, rel)
+
+
+@pytest.mark.parametrize("fp8", [False, True], ids=["bf16", "e4m3"])
+def test_c5_32_frames_64x64_one_evaluation(cuda, nets, fp8):
+    n = nets
+    O, unet, ctrl = n["O"], n["unet"], n["ctrl"]
+    F, L = 32, 64
+    g = torch.Generator(device=cuda).manual_seed(5000)
+    x = torch.randn(1, 4, F, L, L, generator=g, device=cuda)
+    ctx = torch.randn(2, 77, n["ucfg"].cross_attention_dim, generator=g, device=cuda)
+    cond = torch.zeros(1, 4, F, L, L, device=cuda)
+    cond[:, :, 0] = torch.randn(1, 4, L, L, generator=g, device=cuda) * 0.18215
+    mask = torch.zeros(1, 1, F, L, L, device=cuda)
+    mask[:, :, 0] = 1
+    t = 481
+    xin = torch.cat([x] * 2)
+    unet.set_attention_fp8(fp8)
+    ctrl.set_attention_fp8(fp8)
+    down, mid = ctrl(xin, t, encoder_hidden_states=ctx, controlnet_cond=cond, conditioning_mask=mask, return_dict=False)
+    eps = unet(xin, t, encoder_hidden_states=ctx, down_block_additional_residuals=down, mid_block_additional_residual=mid).sample
+    assert torch.isfinite(eps).all()
+    with torch.no_grad():
+        rd, rm = O.sparse_controlnet_forward(n["csd"], n["oc"], xin, t, ctx, cond, mask, 1.0)
+        ref = O.unet3d_forward(n["usd"], n["ou"], xin, t, ctx, rd, rm)
+    tag = "e4m3 attention" if fp8 else "bf16"
+    relm, _ = metrics(f"C5 ({tag}): SparseCtrl mid residual, (2,4,32,64,64), full width", mid, rm)
+    rel, psnr = metrics(f"C5 ({tag}): eps of SparseCtrl + U-Net, (2,4,32,64,64), full width", eps, ref)
+    gate = FWD_REL_L2_FP8 if fp8 else FWD_REL_L2
+    assert rel <= gate and psnr >= 30.0, (rel, psnr)

@@ -145,3 +145,16 @@ def test_composite_modules_match_reference():
     sd = {f"t.{k}": v for k, v in _fill(shp, "t3d320", 54).items()}
     y = O.transformer3d(sd, "t", randn("t3d320.x", (1, 320, 2, 4, 4), 55), randn("t3d320.ctx", (1, 77, 768), 56), 8, 32)
     _close("t3d320", y, g["t3d320.y"])
+
+
+@torch.no_grad()
+def test_sliced_attention_of_the_oracle_is_value_identical(tiny, monkeypatch):
+    """The oracle evaluates softmax(q k^T) v a slice of (batch * heads) at a time when the fp32 score tensor would exceed its budget
+    (BASELINE config 5: 34 GB).  Forcing one problem per slice must reproduce the reference golden exactly as the unsliced path does."""
+    g, ucfg, _, usd, _ = tiny
+    sample, ctx = torch.from_numpy(g["sample"]), torch.from_numpy(g["ctx"])
+    a = O.unet3d_forward(usd, ucfg, sample, int(g["t"]), ctx)
+    monkeypatch.setattr(O, "ATTN_SCORE_BUDGET_BYTES", 1)
+    b = O.unet3d_forward(usd, ucfg, sample, int(g["t"]), ctx)
+    _close("eps_plain (sliced attention)", b, g["eps_plain"])
+    assert (a - b).abs().max().item() <= 1e-6 * a.abs().max().item()
