@@ -53,6 +53,14 @@ def _register_to_config(init):
         cfg = {k: v for k, v in bound.arguments.items() if k != "self"}
         object.__setattr__(self, "_internal_dict", _FrozenDict(cfg))
         init(self, *args, **kwargs)
+        # diffusers 0.11.1 ConfigMixin.register_to_config also exposes every config entry as an attribute (the reference pipeline reads
+        # ``self.unet.in_channels``, pipeline_neuroclips.py:382); attributes the module defines itself win
+        for k, v in cfg.items():
+            if not hasattr(self, k):
+                try:
+                    object.__setattr__(self, k, v)
+                except Exception:
+                    pass
     return inner
 
 
@@ -720,6 +728,154 @@ def gen_unclip(out_dir, num_steps=5, seed=123):
           "clamped frac", ((samples == 0) | (samples == 1)).double().mean().item())
 
 
+# --------------------------------------------------------------------------------------------------
+# a1 pinned by the reference's OWN NeuroclipsPipeline.__call__ (pipeline_neuroclips.py:321-501)
+# --------------------------------------------------------------------------------------------------
+class _OracleDDIM:
+    """diffusers-0.11.1 DDIMScheduler call surface (the source is not in /root/reference: parity of the scheduler arithmetic stays
+    UNPINNED) over the oracle's restatement, so that the reference's ``__call__`` can run."""
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self):
+        from oracle import animatediff_oracle as O
+        self.O = O
+        self.config = _FrozenDict(steps_offset=1, clip_sample=False)
+        self.ac = O.ddim_alphas_cumprod()
+
+    def set_timesteps(self, n, device=None):
+        self.n = n
+        self.timesteps = torch.tensor(self.O.ddim_timesteps(n), dtype=torch.long)
+
+    def scale_model_input(self, x, t):
+        return x
+
+    def add_noise(self, x, noise, timesteps):
+        assert timesteps.numel() == x.shape[0] and bool((timesteps == timesteps[0]).all())
+        return self.O.add_noise(x, noise, int(timesteps[0]), self.ac)
+
+    def step(self, eps, t, x, eta=0.0):
+        assert eta == 0.0
+        return types.SimpleNamespace(prev_sample=self.O.ddim_step(eps, int(t), x, self.ac, self.n))
+
+
+def load_reference_pipeline():
+    """Import animatediff/pipelines/pipeline_neuroclips.py from where it lies.  Extra NON-arithmetic stand-ins for what it imports from
+    diffusers: the DiffusionPipeline base (register_modules / device / progress_bar), scheduler class NAMES (type annotations only),
+    AutoencoderKL (annotation only), deprecate, is_accelerate_available."""
+    install_scaffolding()
+    tv = sys.modules.pop("torchvision", None)       # transformers probes torchvision with find_spec: the stand-in has no __spec__
+    from transformers import CLIPTextModel, CLIPTokenizer  # noqa: F401  (annotation-only imports of the reference file)
+    if tv is not None:
+        sys.modules["torchvision"] = tv
+
+    class _Bar:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def update(self, n=1):
+            pass
+
+    class DiffusionPipeline:
+        def register_modules(self, **kw):
+            for k, v in kw.items():
+                setattr(self, k, v)
+
+        @property
+        def device(self):
+            return torch.device("cpu")
+
+        def progress_bar(self, iterable=None, total=None):
+            return _Bar()
+
+        def set_progress_bar_config(self, **kw):
+            pass
+
+    u = sys.modules["diffusers.utils"]
+    u.is_accelerate_available = lambda: False
+    u.deprecate = lambda *a, **k: None
+    sys.modules["diffusers.models"].AutoencoderKL = type("AutoencoderKL", (), {})
+    _mod("diffusers.pipeline_utils", DiffusionPipeline=DiffusionPipeline)
+    names = ["DDIMScheduler", "DPMSolverMultistepScheduler", "EulerAncestralDiscreteScheduler", "EulerDiscreteScheduler",
+             "LMSDiscreteScheduler", "PNDMScheduler"]
+    _mod("diffusers.schedulers", **{n: type(n, (), {}) for n in names})
+    reference_classes()
+    from animatediff.pipelines.pipeline_neuroclips import NeuroclipsPipeline
+    return NeuroclipsPipeline
+
+
+@torch.no_grad()
+def gen_pipeline_call(out_dir, unet=None, ctrl=None):
+    """tests/golden/a1_call.npz: inputs and outputs of the reference's own ``NeuroclipsPipeline.__call__`` on the tiny networks
+    (BASELINE config 1 shapes: 8 frames, 8x8 latent, 10 DDIM steps, guidance 8.5), with the tokenizer / text encoder / VAE stand-ins of
+    tests/fake_modules.py and the oracle's DDIM restatement as ``scheduler``.  The ``noise`` the call draws inside (:418) is captured by
+    wrapping ``torch.randn_like``; the unused ``keylatents`` draw before it (:395-405) is checked by replaying the RNG.
+    Cases: (A) low_strength 0.3, one condition frame [0]; (B) low_strength 0.0, two condition frames [0, 5]; plus the facts
+    (C) low_strength 0.0 == low_strength 0.3 on case A's inputs (the F8 quirk) and (D) negative_prompt given as a str."""
+    from neurons_amd import _lib
+    from neurons_amd.synth import randn
+    from neurons_amd.unet3d import random_state_dict
+    from fake_modules import FakeTextEncoder, FakeTokenizer, FakeVAE
+    Pipe = load_reference_pipeline()
+    ucfg, ccfg = tiny_unet_config(), tiny_ctrl_config()
+    if unet is None:
+        unet = build_reference_unet(ucfg, random_state_dict(ucfg, _lib.NR_KIND_UNET3D, seed=11))
+        ctrl = build_reference_ctrl(ccfg, random_state_dict(ccfg, _lib.NR_KIND_SPARSECTRL, seed=12))
+    B, F, H, W, N, s = 1, 8, 8, 8, 10, 8.5
+    prompt = "a person walking a dog"
+    out = dict(steps=np.int64(N), guidance=np.float64(s), prompt=np.array(prompt), frames=np.int64(F))
+
+    def run(tag, seed, low_strength, index, nframes_cond, negative_prompt=None, store=True):
+        pipe = Pipe(vae=FakeVAE(), text_encoder=FakeTextEncoder(ucfg.cross_attention_dim), tokenizer=FakeTokenizer(), unet=unet,
+                    scheduler=_OracleDDIM(), controlnet=ctrl)
+        latents = randn(f"a1.{tag}.latents", (B, 4, F, H, W), 51)
+        cimg = randn(f"a1.{tag}.cimg", (B, 4, nframes_cond, H, W), 52) * 0.18215
+        drawn, traj = [], []
+        real = torch.randn_like
+
+        def spy(t, *a, **k):
+            r = real(t, *a, **k)
+            drawn.append(r.clone())
+            return r
+
+        torch.manual_seed(seed)
+        torch.randn_like = spy
+        try:
+            res = pipe(prompt, video_length=F, height=H * 8, width=W * 8, num_inference_steps=N, guidance_scale=s,
+                       negative_prompt=negative_prompt, latents=latents.clone(), controlnet_images=cimg.clone(),
+                       controlnet_image_index=list(index), low_strength=low_strength,
+                       callback=lambda i, t, lat: traj.append((i, int(t), lat.clone())), callback_steps=1)
+        finally:
+            torch.randn_like = real
+        assert len(drawn) == 1 and len(traj) == N
+        noise = drawn[0]
+        # RNG order (:395-405 then :418): one unused randn of the latent shape, then the noise
+        torch.manual_seed(seed)
+        _keylatents = torch.randn(B, 4, F, H, W)
+        assert torch.equal(torch.randn(B, 4, F, H, W), noise), "noise is the SECOND draw of the latent shape"
+        videos = res.videos
+        assert tuple(videos.shape) == (B, 3, F, H * 8, W * 8) and videos.dtype == torch.float32
+        if store:
+            out.update({f"{tag}.latents": latents.numpy(), f"{tag}.cimg": cimg.numpy(), f"{tag}.noise": noise.numpy(),
+                        f"{tag}.index": np.array(index), f"{tag}.low_strength": np.float64(low_strength), f"{tag}.seed": np.int64(seed),
+                        f"{tag}.final_latents": traj[-1][2].numpy(), f"{tag}.latents_after_step0": traj[0][2].numpy(),
+                        f"{tag}.timesteps": np.array([t for _, t, _ in traj]),
+                        f"{tag}.videos_sub": videos[:, :, :, ::8, ::8].numpy()})       # the fake VAE is 8x nearest: every 8th pixel is everything
+        return traj[-1][2], videos
+
+    fa, _ = run("A", 1234, 0.3, (0,), 1)
+    run("B", 4321, 0.0, (0, 5), 2)
+    fc, _ = run("A", 1234, 0.0, (0,), 1, store=False)
+    out["quirk_low_strength_0_equals_0p3"] = np.array(bool(torch.equal(fa, fc)))
+    fd, _ = run("A", 1234, 0.3, (0,), 1, negative_prompt="", store=False)
+    out["negative_prompt_empty_str_equals_none"] = np.array(bool(torch.equal(fa, fd)))
+    np.savez_compressed(os.path.join(out_dir, "a1_call.npz"), **out)
+    print("a1_call:", {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -733,5 +889,6 @@ if __name__ == "__main__":
     gen_clip(out_dir)
     gen_weights(out_dir)
     gen_unclip(out_dir)
+    gen_pipeline_call(out_dir, unet, ctrl)
     for f in sorted(os.listdir(out_dir)):
         print(f, os.path.getsize(os.path.join(out_dir, f)) // 1024, "KiB")
