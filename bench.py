@@ -18,7 +18,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
   cpu_baseline the oracle (fp32 torch restatement of the reference graph, eager, math attention) timed on the host
                cores for a bounded sample and scaled to the clip.  The same oracle leg also CHECKS the clip just timed
                (config.psnr_c2_vs_fp32_oracle_db: final latents vs the oracle run in fp32 on the GPU, outside the timed region);
-               --no-cpu-baseline skips the whole leg.  SparseCtrl is evaluated 4 DDIM steps at a time (pipeline.controlnet_group):
+               --no-cpu-baseline skips the whole leg.  SparseCtrl is evaluated several (50 steps: 5) DDIM steps at a time (pipeline.controlnet_group_size):
                all 50 evaluations per clip are computed inside the timed region.
 """
 import argparse
@@ -249,7 +249,9 @@ def main():
             host_sd[kind] = sd
             if world > 1:
                 # converts the weights for the shape every rank will run: SparseCtrl is evaluated `grp` DDIM steps at a time (pipeline.py)
-                grp0 = max(1, min(int(os.environ.get("NR_CTRL_GROUP", "4")), 16 // (2 * args.batch), args.ddim_steps))
+                from neurons_amd.pipeline import controlnet_group_size
+                grp0 = controlnet_group_size(args.ddim_steps, 2 * args.batch, F, L, L,
+                                             int(os.environ["NR_CTRL_GROUP"]) if os.environ.get("NR_CTRL_GROUP") else "auto")
                 net._ensure_plan(2 * args.batch * (grp0 if kind == _lib.NR_KIND_SPARSECTRL else 1), F, L, L, 77)
         if world > 1:
             broadcast_native_weights(net, src=0)
@@ -298,7 +300,7 @@ def main():
         value = total_frames / elapsed
         # ---- roofline of the dominant kernel class (MFMA implicit GEMM), HIP events per launch ----
         # SparseCtrl is evaluated `grp` DDIM steps at a time (pipeline.controlnet_group): its per-launch profile covers grp steps
-        grp = max(1, min(pipe.controlnet_group, 16 // (2 * Bc), args.ddim_steps))
+        grp = getattr(pipe, "last_controlnet_group", 1)
         if args.no_op_profile:
             print(json.dumps({"metric": "denoising frames/sec, 16f x 256^2 clip, 50 DDIM steps", "value": round(value, 4), "unit": "frames/s",
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),

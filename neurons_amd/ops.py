@@ -189,3 +189,24 @@ def cfg_ddim_step(eps, x, guidance_scale, alpha_prod_t, alpha_prod_t_prev, do_cf
     _lib.check(lib.nr_cfg_ddim_step(_stream(), _ptr(eps), _ptr(x), _ptr(out), x.numel(), float(guidance_scale),
                                     1 if do_cfg else 0, float(alpha_prod_t), float(alpha_prod_t_prev)))
     return out
+
+
+def ff_fused(t, x, gamma, beta, w1, b1, w2, b2, wpo, bpo, eps=1e-5):
+    """out = x + proj_out(t + FF(t)),  FF(t) = net.2(GEGLU(net.0(LayerNorm(t))))  — the tail of a (temporal) transformer at C = 320 in ONE
+    launch (ffpanel.hip).  The weight folding is done here on the host exactly as engine.hip does it: LayerNorm into net.0
+    (w_ln_linear, value/gate interleave), net.2 + proj_out into Wc = [Wpo | Wpo Wff2], bc = bpo + Wpo bff2 (w_fold_ff_proj).
+    t, x: [M, C] bf16; w1 [8C, C], b1 [8C], w2 [C, 4C], b2 [C], wpo [C, C], bpo [C] fp32."""
+    _chk_bf16(t, x)
+    M, C = t.shape
+    wf = w1.float()
+    ws = (wf * gamma.float()[None]).to(torch.bfloat16)
+    c = ws.float().sum(dim=1)
+    b = (wf.double() @ beta.double()).float() + b1.float()
+    wsp, _ = geglu_permute(ws, None)
+    cp, bp = geglu_permute(c[:, None], b)
+    wc = torch.cat([wpo.float(), wpo.float() @ w2.float()], dim=1).to(torch.bfloat16).contiguous()
+    bc = (bpo.float() + wpo.float() @ b2.float()).contiguous()
+    out = torch.empty(M, C, dtype=torch.bfloat16, device=t.device)
+    _lib.check(_lib.load().nr_op_ff_fused(_stream(), _ptr(t), _ptr(x), _ptr(out), M, C, _ptr(wsp.contiguous()), _ptr(cp.reshape(-1).contiguous()),
+                                          _ptr(bp.contiguous()), _ptr(wc), _ptr(bc), float(eps)))
+    return out

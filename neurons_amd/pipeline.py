@@ -61,6 +61,26 @@ def controlnet_group_plan(timesteps, group):
     return groups, steps
 
 
+def controlnet_group_size(num_steps, batch2, frames, lat_h, lat_w, preferred="auto"):
+    """DDIM steps per SparseCtrl evaluation under the grouped schedule (host logic, unit-tested on CPU).
+    Bounds: at most 64 samples per evaluation (engine limit NR_MAX_BATCH) and 2 Mi level-0 rows (the largest evaluation the full-size tests
+    exercise: 8 clips x CFG x 4 steps at 16 f x 32 x 32, BASELINE config 5's 4 clips x CFG x 2 steps at 32 f x 64 x 64).
+    An integer ``preferred`` is taken as is (capped).  ``"auto"``: the size in 1..5 with the least total cost
+    ``c(G) * ceil(N / G) * G`` -- the tail of the last group is evaluated and never consumed (50 steps at G = 4: 2 of 52 evaluations), and
+    c(G) is the measured per-step cost of one evaluation at group size G relative to G >= 4 (5.64 / 4.68 / 4.15 ms at G = 1 / 2 / 4 on
+    MI355X, G = 8 no better: tools/ctrl_batch.py); 50, 25 and 10 steps give G = 5 (no tail)."""
+    cap = max(1, min(64 // max(1, batch2), (2 << 20) // max(1, batch2 * frames * lat_h * lat_w), num_steps))
+    if preferred != "auto":
+        return max(1, min(int(preferred), cap))
+    rel = {1: 1.36, 2: 1.13, 3: 1.06}
+    best, best_cost = 1, None
+    for g in range(1, min(cap, 5) + 1):
+        cost = rel.get(g, 1.0) * (-(-num_steps // g)) * g
+        if best_cost is None or cost < best_cost - 1e-9 or (abs(cost - best_cost) <= 1e-9 and abs(g - 4) < abs(best - 4)):
+            best, best_cost = g, cost
+    return best
+
+
 class NeuroclipsPipeline:
     _optional_components = []
 
@@ -87,7 +107,8 @@ class NeuroclipsPipeline:
         # SparseCtrl evaluations of `controlnet_group` consecutive DDIM steps run as ONE forward on a `group` x larger batch, one group
         # ahead of the U-Net steps that consume them (the network sees timestep, context and condition only, not the latents:
         # set_noisy_sample_input_to_zero).  Same 50 evaluations, better GEMM shapes; 1 = one evaluation per step (nr_denoise_step_forward)
-        self.controlnet_group = int(os.environ.get("NR_CTRL_GROUP", "4"))
+        # "auto" (default): controlnet_group_size picks the size with no wasted tail (5 for 50 / 25 / 10 steps); an integer forces it
+        self.controlnet_group = int(os.environ["NR_CTRL_GROUP"]) if os.environ.get("NR_CTRL_GROUP") else "auto"
 
     # ---- DiffusionPipeline surface used by the scripts (SURVEY §8c "Python harness rows") ----
     def register_modules(self, **kwargs):
@@ -286,12 +307,9 @@ class NeuroclipsPipeline:
         n_lat = latents.numel()
         fused = use_ctrl and hasattr(self.unet, "forward_with_controlnet") and \
             getattr(self.controlnet, "set_noisy_sample_input_to_zero", False) and self.overlap_controlnet
-        # grouped schedule: G steps per SparseCtrl evaluation; at most 64 samples per evaluation (engine limit NR_MAX_BATCH) and 2 Mi
-        # level-0 rows (the largest evaluation the full-size tests exercise: 8 clips x CFG x G = 4 at 16 f x 32 x 32, and BASELINE
-        # config 5's 4 clips x CFG x G = 2 at 32 f x 64 x 64)
+        # grouped schedule: G steps per SparseCtrl evaluation (controlnet_group_size)
         b2 = latents.shape[0] * (2 if do_classifier_free_guidance else 1)
-        rows1 = b2 * latents.shape[2] * latents.shape[3] * latents.shape[4]
-        G = max(1, min(self.controlnet_group, 64 // b2, (2 << 20) // rows1, len(timesteps_host))) \
+        G = controlnet_group_size(len(timesteps_host), b2, latents.shape[2], latents.shape[3], latents.shape[4], self.controlnet_group) \
             if (fused and hasattr(self.controlnet, "forward_async")) else 1
         self.last_controlnet_group = G
         pending = {}

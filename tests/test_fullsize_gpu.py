@@ -109,7 +109,7 @@ def test_c2_25_step_loop_vs_oracle(c2):
 
 def test_c2_multi_gpu_startup_flow_on_one_gpu(c2, cuda):
     """SURVEY 8e as bench.py runs it with N > 1, replayed in one process at full size: "rank 0" loads the state dicts and only PLANS
-    (U-Net for the CFG batch, SparseCtrl for the grouped batch of 4 steps), exports manifest + packed arena; a "rank 1" pair of FRESH
+    (U-Net for the CFG batch, SparseCtrl for the grouped batch the pipeline will use), exports manifest + packed arena; a "rank 1" pair of FRESH
     networks imports them (never sees a state dict, cannot convert anything) and must run the grouped pipeline to the same latents
     bit for bit.  Catches any weight conversion the pipeline needs that planning alone did not make."""
     from neurons_amd import DDIMScheduler, NativeSparseCtrl, NativeUNet3D, NeuroclipsPipeline
@@ -117,8 +117,10 @@ def test_c2_multi_gpu_startup_flow_on_one_gpu(c2, cuda):
     a_unet, a_ctrl = NativeUNet3D(c2["unet"].config).to(cuda), NativeSparseCtrl(c2["ctrl"].config).to(cuda)
     a_unet.load_state_dict({k: v.cpu() for k, v in c2["usd"].items()})
     a_ctrl.load_state_dict({k: v.cpu() for k, v in c2["csd"].items()})
+    from neurons_amd.pipeline import controlnet_group_size
+    G = controlnet_group_size(6, 2, F, L, L)          # what the pipeline will choose for the 6-step call below
     a_unet._ensure_plan(2, F, L, L, 77)
-    a_ctrl._ensure_plan(8, F, L, L, 77)
+    a_ctrl._ensure_plan(2 * G, F, L, L, 77)
     b_unet, b_ctrl = NativeUNet3D(c2["unet"].config).to(cuda), NativeSparseCtrl(c2["ctrl"].config).to(cuda)
     for src, dst in ((a_unet, b_unet), (a_ctrl, b_ctrl)):
         manifest, arena = src.export_weights()
@@ -128,7 +130,7 @@ def test_c2_multi_gpu_startup_flow_on_one_gpu(c2, cuda):
     for unet, ctrl in ((a_unet, a_ctrl), (b_unet, b_ctrl)):
         sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
         pipe = NeuroclipsPipeline(vae=None, text_encoder=None, tokenizer=None, unet=unet, scheduler=sched, controlnet=ctrl).to(cuda)
-        assert pipe.controlnet_group == 4
+        assert pipe.controlnet_group == "auto"
         outs.append(pipe("", video_length=F, height=L * 8, width=L * 8, num_inference_steps=6, guidance_scale=8.5, latents=inp["lat"],
                          noise=inp["noise"], text_embeddings=inp["ctx"], controlnet_images=inp["cimg"], controlnet_image_index=[0],
                          low_strength=0.3, output_type="latent").videos.clone())

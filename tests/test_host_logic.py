@@ -222,3 +222,20 @@ def test_controlnet_group_plan_invariants():
             for g, grp in enumerate(groups):
                 assert len(grp["timesteps"]) == g_eff and grp["slot"] == g % 2
                 assert grp["timesteps"] == [ts[min(g * g_eff + p, n - 1)] for p in range(g_eff)]
+
+
+def test_controlnet_group_size_rule():
+    """pipeline.controlnet_group_size: "auto" avoids the wasted tail (50 / 25 / 10 steps -> 5), respects the 64-sample and 2 Mi-row caps,
+    never exceeds the step count; an integer is taken as is (capped)."""
+    from neurons_amd.pipeline import controlnet_group_size as gs
+    assert gs(50, 2, 16, 32, 32) == 5 and gs(25, 2, 16, 32, 32) == 5 and gs(10, 2, 8, 8, 8) == 5
+    assert gs(6, 2, 16, 32, 32) == 3 and gs(6, 16, 16, 32, 32) == 3          # B = 1 and B = 8 (C4): two full groups of 3
+    assert gs(50, 16, 16, 32, 32) == 4                                       # 64 // 16: the sample cap
+    assert gs(50, 8, 32, 64, 64) == 2                                        # BASELINE config 5: the 2 Mi-row cap
+    assert gs(1, 2, 16, 32, 32) == 1 and gs(3, 2, 16, 32, 32) == 3
+    for forced in (1, 2, 3, 4, 8):
+        assert gs(50, 2, 16, 32, 32, forced) == forced
+    assert gs(50, 16, 16, 32, 32, 8) == 4 and gs(2, 2, 16, 32, 32, 4) == 2
+    for n in range(1, 60):
+        g = gs(n, 2, 16, 32, 32)
+        assert 1 <= g <= min(5, n)

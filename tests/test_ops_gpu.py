@@ -347,3 +347,30 @@ def test_gemm_ex_temporal_pe_rowvec_scale_act(cuda, M, N, K):
     out2 = ops.gemm_ex(a, w, bias, res=res, act=1, out_scale=0.5)
     h = (a.float() @ w.to(torch.bfloat16).float().t() + bias) * 0.5
     _cmp(f"scale+quick_gelu+res gemm {M}x{N}x{K}", out2, h * torch.sigmoid(1.702 * h) + res.float())
+
+
+@pytest.mark.parametrize("M", [32768, 4096 + 80, 128])
+def test_fused_feedforward_proj_out_matches_torch(cuda, M):
+    """ffpanel.hip: LayerNorm -> net.0 (GEGLU) -> net.2 (+t) -> proj_out (+x) at C = 320 in one launch, the 4C-wide hidden activation
+    kept in registers, against the fp32 torch composition of the reference modules (motion_module_new.py:441-518 FeedForward / GEGLU;
+    attention.py:129-140,297-299 residual adds and proj_out).  Ragged M exercises the clamped panel rows and the predicated stores."""
+    from neurons_amd import ops
+    C = 320
+    g = torch.Generator(device="cuda").manual_seed(M)
+    t = (torch.randn(M, C, generator=g, device="cuda") * 1.2 + 0.2).to(torch.bfloat16)
+    x = torch.randn(M, C, generator=g, device="cuda").to(torch.bfloat16)
+    gamma = 1.0 + 0.2 * torch.randn(C, generator=g, device="cuda")
+    beta = 0.1 * torch.randn(C, generator=g, device="cuda")
+    w1 = torch.randn(8 * C, C, generator=g, device="cuda") * C ** -0.5
+    b1 = 0.1 * torch.randn(8 * C, generator=g, device="cuda")
+    w2 = torch.randn(C, 4 * C, generator=g, device="cuda") * (4 * C) ** -0.5
+    b2 = 0.1 * torch.randn(C, generator=g, device="cuda")
+    wpo = torch.randn(C, C, generator=g, device="cuda") * C ** -0.5
+    bpo = 0.1 * torch.randn(C, generator=g, device="cuda")
+    out = ops.ff_fused(t, x, gamma, beta, w1, b1, w2, b2, wpo, bpo)
+    tf = t.float()
+    h = torch.nn.functional.linear(torch.nn.functional.layer_norm(tf, (C,), gamma, beta, 1e-5), w1, b1)
+    ff = torch.nn.functional.linear(h[:, :4 * C] * torch.nn.functional.gelu(h[:, 4 * C:]), w2, b2)
+    ref = x.float() + torch.nn.functional.linear(tf + ff, wpo, bpo)
+    _cmp(f"fused FF + proj_out M={M}", out, ref)
+    assert torch.equal(out, ops.ff_fused(t, x, gamma, beta, w1, b1, w2, b2, wpo, bpo))
