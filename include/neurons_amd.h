@@ -320,6 +320,15 @@ nr_status nr_op_ff_fused(nr_stream stream, const void* t_dev, const void* x_dev,
                          const void* w1_ln_geglu_dev, const float* c1_dev, const float* b1_dev, const void* wc_dev, const float* bc_dev,
                          float ln_eps);
 
+/* One temporal-attention block of the C = 320 level in one launch (tattn.hip; engine: temporal_module):
+ *   t <- t + to_out(softmax(q k^T / sqrt(d)) v),  [q | k | v] = (LayerNorm(t) + pe[frame]) [Wq | Wk | Wv]^T,  sequence = the 16 frames of a pixel
+ * (motion_module.py:210-218,270-329; motion_module_new.py:201-287).  t: bf16 [nbatch * 16 * hw][320] ("(b f) (h w) c"), updated in place;
+ * w*: bf16 [320][320] (nn.Linear weights); gamma fp32 [320]; gb fp32 [16][320] = LayerNorm bias + positional encoding of the frame;
+ * bo fp32 [320] (to_out[0].bias).  wq == NULL re-uses the weight stream packed by the previous call. */
+nr_status nr_op_tattn_fused(nr_stream stream, void* t_dev, int32_t nbatch, int32_t hw, const void* wq_dev, const void* wk_dev,
+                            const void* wv_dev, const void* wo_dev, const float* gamma_dev, const float* gb_dev, const float* bo_dev,
+                            float ln_eps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,12 @@ int nr_launch_add_bf16_multi(const NrAddMulti* p, hipStream_t stream);
 int nr_groupnorm_launches(const NrGnParams* p);
 int nr_launch_fold_linear_pair(const float* w2, const float* w1, const float* b2, const float* b1, int C, int J, bf16* wc, float* bc,
                                hipStream_t stream);
+// tattn.hip: one kernel per temporal-attention block of the C = 320 level
+size_t nr_tattn_stream_bytes(void);
+int nr_tattn_fused_eligible(int C, int heads, int frames, int hw, long long rows);
+int nr_launch_tattn_stream_pack(const bf16* wq, const bf16* wk, const bf16* wv, const bf16* wo, bf16* stream, hipStream_t s);
+int nr_launch_tattn_fused(bf16* t, int nbatch, int hw, const bf16* stream, const float* gamma, const float* gb, const float* bo, float ln_eps,
+                          hipStream_t s);
 // ffpanel.hip: fused FeedForward(GEGLU) + proj_out of the C = 320 level
 size_t nr_ff_stream_bytes(int C);
 int nr_ff_fused_eligible(int C, long long M);
@@ -977,6 +983,50 @@ struct nr_net {
     const std::string b = pre + ".transformer_blocks.0";
     for (int k = 0; k < cfg.motion_num_attention_blocks; ++k) {
       const std::string ab = b + ".attention_blocks." + std::to_string(k);
+      if (nr_tattn_fused_eligible(C, heads, F, x.H * x.W, t.rows()) && t.ld == C) {
+        // C = 320, F = 16: the whole block (LayerNorm + PE, q|k|v, 16 x 16 attention per pixel and head, to_out + residual) in ONE launch
+        // that updates t in place (tattn.hip); q|k|v and the attention output never reach HBM
+        const std::string nrm = b + ".norms." + std::to_string(k);
+        const bf16* wq = w_linear(ab + ".to_q.weight", C, C);
+        const bf16* wk = w_linear(ab + ".to_k.weight", C, C);
+        const bf16* wv = w_linear(ab + ".to_v.weight", C, C);
+        const bf16* wo = w_linear(ab + ".to_out.0.weight", C, C);
+        const std::string sname = "tas:" + ab + ".to_q.weight|" + ab + ".to_k.weight|" + ab + ".to_v.weight|" + ab + ".to_out.0.weight";
+        const bf16* stream = (const bf16*)cached(sname, [&]() {
+          void* d = nullptr;
+          const size_t nb = nr_tattn_stream_bytes();
+          HIP_OK(hipMalloc(&d, nb));
+          LAUNCH_OK(nr_launch_tattn_stream_pack(wq, wk, wv, wo, (bf16*)d, nullptr));
+          HIP_OK(hipDeviceSynchronize());
+          dev[sname] = d; dev_bytes[sname] = nb; weight_bytes += nb;
+          return d;
+        });
+        // gb[f][c] = LayerNorm bias + sinusoidal positional encoding of frame f (motion_module.py:225-243)
+        check_shape(nrm + ".bias", need(nrm + ".bias"), {C});
+        const std::string gname = "tagb:" + std::to_string(F) + ":" + nrm;
+        const float* gb = (const float*)cached(gname, [&]() {
+          const HostTensor& be = data_of(nrm + ".bias");
+          std::vector<float> h((size_t)F * C);
+          const float kk = (float)(-std::log(10000.0) / (double)C);
+          for (int pos = 0; pos < F; ++pos)
+            for (int i = 0; i < C; i += 2) {
+              const float a = (float)pos * std::exp((float)i * kk);
+              h[(size_t)pos * C + i] = be.data[i] + std::sin(a);
+              if (i + 1 < C) h[(size_t)pos * C + i + 1] = be.data[i + 1] + std::cos(a);
+            }
+          return upload(gname, h.data(), h.size() * 4);
+        });
+        const float* gamma = w_f32(nrm + ".weight", C);
+        const float* bo = w_f32(ab + ".to_out.0.bias", C);
+        bf16* tp = t.ptr; const int nb2 = t.nimg / F, hw = x.H * x.W;
+        const double M = (double)t.rows();
+        char d[160];
+        snprintf(d, sizeof(d), "tattn_fused M=%d C=%d F=%d (LN+PE, q|k|v, attention, to_out + residual)", (int)t.rows(), C, F);
+        emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_tattn_fused(tp, nb2, hw, stream, gamma, gb, bo, 1e-5f, s)); }, NR_PROF_IGEMM,
+             2.0 * M * C * 4.0 * C + 4.0 * (M / F) * heads * (double)F * F * (C / heads), 2.0 * (2.0 * M * C + 4.0 * C * (double)C), d);
+        op_tap("tattn_fused", t);
+        continue;
+      }
       // LayerNorm, then + pe[frame] (motion_module.py:212,277): both folded into the q|k|v GEMM
       Act qkv = ln_linear(t, b + ".norms." + std::to_string(k), {ab + ".to_q.weight", ab + ".to_k.weight", ab + ".to_v.weight"}, {}, C,
                           false, 0, true);
@@ -2526,5 +2576,21 @@ extern "C" nr_status nr_op_ff_fused(nr_stream stream, const void* t_dev, const v
   if (w1_ln_geglu_dev) LAUNCH_OK(nr_launch_ff_stream_pack((const bf16*)w1_ln_geglu_dev, (const bf16*)wc_dev, (bf16*)ws, (hipStream_t)stream));
   LAUNCH_OK(nr_launch_ff_fused((const bf16*)t_dev, C, (const bf16*)x_dev, C, (bf16*)out_dev, C, M, (const bf16*)ws, c1_dev, b1_dev, bc_dev,
                                ln_eps, (hipStream_t)stream));
+  NR_CATCH
+}
+
+// ---- fused temporal-attention block (tattn.hip), op-level entry for tests.  t: bf16 [nbatch * 16 * hw][320], updated in place;
+// wq / wk / wv / wo: bf16 [320][320]; gamma fp32 [320]; gb fp32 [16][320] = LayerNorm bias + positional encoding; bo fp32 [320] ----
+extern "C" nr_status nr_op_tattn_fused(nr_stream stream, void* t_dev, int32_t nbatch, int32_t hw, const void* wq_dev, const void* wk_dev,
+                                       const void* wv_dev, const void* wo_dev, const float* gamma_dev, const float* gb_dev, const float* bo_dev,
+                                       float ln_eps) {
+  NR_TRY
+  if (!nr_tattn_fused_eligible(320, 8, 16, hw, 1 << 30)) throw NrError(NR_ERR_UNSUPPORTED, "fused temporal attention: C = 320, 8 heads, 16 frames, hw % 8 == 0");
+  static void* ws = nullptr;
+  if (!ws) HIP_OK(hipMalloc(&ws, nr_tattn_stream_bytes()));
+  // wq == NULL: reuse the stream packed by the previous call (timing loops)
+  if (wq_dev) LAUNCH_OK(nr_launch_tattn_stream_pack((const bf16*)wq_dev, (const bf16*)wk_dev, (const bf16*)wv_dev, (const bf16*)wo_dev, (bf16*)ws,
+                                                    (hipStream_t)stream));
+  LAUNCH_OK(nr_launch_tattn_fused((bf16*)t_dev, nbatch, hw, (const bf16*)ws, gamma_dev, gb_dev, bo_dev, ln_eps, (hipStream_t)stream));
   NR_CATCH
 }

@@ -1,0 +1,374 @@
+// One kernel per temporal-attention block of the 32x32 level (C = 320, 8 heads of d = 40, F = 16 frames):
+//
+//     t  <-  t + to_out( softmax( q k^T / sqrt(d) ) v ) ,   [q | k | v] = ( LayerNorm(t) + pe[frame] ) . [Wq | Wk | Wv]^T
+//
+// i.e. TemporalTransformerBlock's `norm -> VersatileAttention -> + hidden_states` (animatediff/models/motion_module.py:210-218) with
+// VersatileAttention.forward (:270-329: regroup "(b f) d c -> (b d) f c", PositionalEncoding :241-243, CrossAttention arithmetic
+// motion_module_new.py:201-287, to_out[0] with bias).  Until round 3 this was three launches -- LayerNorm-folded q|k|v projection
+// (43 us at M = 32768), the strided 16 x 16 attention core (25 us, HBM-bound on the 63 MB q|k|v tensor) and the to_out GEMM + residual
+// (23 us) -- with q|k|v and the attention output round-tripping through HBM.  Here a workgroup owns 8 pixels x all 16 frames (128 rows
+// of the "(b f) (h w) c" activation, gathered with stride h*w*C) and nothing but t leaves the chip.
+//
+// Structure (256-thread workgroup = 4 waves, one per SIMD; wave w owns 2 pixels = 2 MFMA row tiles of 16 frames):
+//   * prologue: the wave's 32 x 320 panel of t -> registers, LayerNorm statistics, then xn = (x - mean) rstd gamma + (beta + pe[frame])
+//     rounded to bf16 IN the registers (the rounding point of the un-fused LayerNorm kernel), kept as MFMA fragments (80 VGPRs).
+//   * per head h, four weight stages streamed through a ring of three LDS slots by linear LDS-DMA copies (the stream is stored in
+//     HBM as the LDS image, XOR-swizzled [rows][64] sub-tiles as in gemm.hip / ffpanel.hip):
+//        q_h, k_h  [48 n][320 k] (40 rows + 8 zero rows):  acc = W . xn^T  ("transposed" issue: lane holds 4 channels of its frame)
+//        v_h       same shape, operands SWAPPED:           acc = xn . W^T  (lane holds 4 frames of its channel = V^T as A operand)
+//        o_h       [320 n][64 k-slots]: Wo[:, 40 h .. 40 h + 39] in the k order in which the attention output sits in registers
+//   * attention of (pixel, head) entirely in registers with v_mfma_f32_16x16x16_bf16 (k = 16 = one accumulator tile):
+//        S^T = K Q^T (3 MFMAs: 48 padded channels), softmax over the 16 keys = 4 registers x 4 lane groups (two xor-shuffles),
+//        O^T = V^T P^T (3 MFMAs); every accumulator -> operand hand-over is lane-local (cdna_hip_programming.md 3, "An accumulator
+//        tile as the next MFMA's operand"): no LDS round trip.
+//   * out += Wo_h . O_h^T accumulates over the heads in 160 VGPRs; epilogue t + bo + acc, written in place (rows are private).
+// Algorithmic work per launch at M = 32768: 26.8 GFLOP GEMM + 0.17 GFLOP attention; HBM: t in + t out = 42 MB (+ 1.1 MB of weights,
+// L2-resident per XCD).
+#include "common.h"
+#include <cstdlib>
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ void glds16(const void* src, unsigned lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_wave_base) : "memory", "m0");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+constexpr int TA_C = 320, TA_HEADS = 8, TA_D = 40, TA_F = 16;
+constexpr int TA_ROWS = 128;                    // rows per workgroup = 8 pixels x 16 frames
+constexpr int TA_QSUB = 48 * 64;                // elements of one [48][64] sub-tile of a q / k / v stage
+constexpr int TA_QKV_BYTES = 32 * 1024;         // stage stride of a q / k / v stage (30 KiB image + 2 KiB pad: 8 DMA per wave)
+constexpr int TA_OSUB = 64 * 64;
+constexpr int TA_O_BYTES = 40 * 1024;           // o stage: five [64][64] sub-tiles (10 DMA per wave)
+constexpr int TA_HEAD_BYTES = 3 * TA_QKV_BYTES + TA_O_BYTES;
+constexpr int TA_SLOT = TA_O_BYTES;             // ring slot
+constexpr int TA_NS = 3;
+
+struct NrTAttnParams {
+  bf16* t;                 // [B2 * F * hw][C], updated in place
+  int hw, nbatch;          // pixels per frame-image, CFG batch
+  const bf16* stream;      // 8 heads x (q | k | v | o) stages (tattn_stream_pack_kernel)
+  const float* gamma;      // [C] LayerNorm weight
+  const float* gb;         // [F][C] LayerNorm bias + positional encoding of the frame
+  const float* bo;         // [C] to_out bias
+  float ln_eps;
+  float scale_log2e;       // d^-0.5 * log2(e)
+};
+
+__device__ __forceinline__ s16x4 pack4(const f32x4& v) {
+  bf16x4 b;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) b[e] = (bf16)v[e];
+  return __builtin_bit_cast(s16x4, b);
+}
+
+__global__ __launch_bounds__(256) void tattn_fused_kernel(NrTAttnParams p) {
+  constexpr int C = TA_C, KS = C / 32, NT2 = C / 16;
+  extern __shared__ __attribute__((aligned(16))) bf16 smem[];   // TA_NS slots of 40 KiB
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+
+  // ---- weight stream ----
+  const char* wsrc = reinterpret_cast<const char*>(p.stream) + (size_t)lane * 16;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lptr_t)smem);
+  // stage index s = 4 head + part (0 q, 1 k, 2 v, 3 o); ring slot s % 3
+  auto issue = [&](int head, int part, int slot) {
+    const char* src = wsrc + (size_t)head * TA_HEAD_BYTES + (size_t)part * TA_QKV_BYTES;
+    const unsigned dst = lds0 + (unsigned)(slot * TA_SLOT);
+    if (part < 3) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) glds16(src + (wave * 8 + i) * 1024, dst + (unsigned)((wave * 8 + i) * 1024));
+    } else {
+#pragma unroll
+      for (int i = 0; i < 10; ++i) glds16(src + (wave * 10 + i) * 1024, dst + (unsigned)((wave * 10 + i) * 1024));
+    }
+  };
+  issue(0, 0, 0);
+  issue(0, 1, 1);
+
+  // ---- the row panel: tile mt = pixel, lane row fr = frame; row index in t = (b F + frame) hw + pixel ----
+  const int groups_per_img = p.hw >> 3;
+  const int b = blockIdx.x / groups_per_img;
+  const int pix0 = (blockIdx.x - b * groups_per_img) * 8 + wave * 2;
+  const size_t row_stride = (size_t)p.hw * C;                       // between frames
+  bf16* trow[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) trow[mt] = p.t + ((size_t)(b * TA_F + fr) * p.hw + pix0 + mt) * C;
+  bf16x8 xb[2][KS];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xb[mt][ks] = *(const bf16x8*)(trow[mt] + 32 * ks + 8 * fg);
+  // LayerNorm (two-pass in registers: mean, then centred second moment) + positional encoding, rounded to bf16 in place
+  {
+    float mu[2], rstd[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      float s = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)xb[mt][ks][e];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      mu[mt] = s * (1.0f / C);
+      float q = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = (float)xb[mt][ks][e] - mu[mt]; q += d * d; }
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      rstd[mt] = rsqrtf(q * (1.0f / C) + p.ln_eps);
+    }
+    const float* gbr = p.gb + (size_t)fr * C + 8 * fg;
+    const float* gar = p.gamma + 8 * fg;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const f32x4 g0 = *(const f32x4*)(gar + 32 * ks), g1 = *(const f32x4*)(gar + 32 * ks + 4);
+      const f32x4 b0 = *(const f32x4*)(gbr + 32 * ks), b1 = *(const f32x4*)(gbr + 32 * ks + 4);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        bf16x8 v = xb[mt][ks];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = (bf16)(((float)v[e] - mu[mt]) * rstd[mt] * g0[e] + b0[e]);
+          v[4 + e] = (bf16)(((float)v[4 + e] - mu[mt]) * rstd[mt] * g1[e] + b1[e]);
+        }
+        xb[mt][ks] = v;
+      }
+    }
+  }
+
+  f32x4 oacc[NT2][2];
+#pragma unroll
+  for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) oacc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int slot = 0;
+  // NEXT: LDS-DMA instructions this wave issued for the FOLLOWING stage (they may stay in flight); 0 on the very last stage
+  auto stage_wait = [&](int next_dma) {
+    if (next_dma == 10) wait_vmcnt<10>(); else if (next_dma == 8) wait_vmcnt<8>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+  };
+  auto next_slot = [&]() { slot = slot + 1 == TA_NS ? 0 : slot + 1; };
+
+  // fragment of a q / k / v stage: 16 weight rows nt (0..2), k-step ks
+  auto frag_qkv = [&](const bf16* sW, int nt, int ks) {
+    const int row = nt * 16 + fr;
+    return *(const bf16x8*)(sW + (ks >> 1) * TA_QSUB + row * 64 + ((((ks & 1) * 4 + fg) ^ (row & 7)) << 3));
+  };
+  // acc[nt][mt] over K = 320; SWAP: activations as the A operand (result transposed: lane = channel, registers = frames)
+  auto gemm_qkv = [&](const bf16* sW, f32x4 (&acc)[3][2], bool swap) {
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 w0[3], w1[3], w2[3];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) { w0[nt] = frag_qkv(sW, nt, 0); w1[nt] = frag_qkv(sW, nt, 1); }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 (&wc)[3] = (ks % 3 == 0) ? w0 : (ks % 3 == 1 ? w1 : w2);
+      bf16x8 (&wn)[3] = (ks % 3 == 0) ? w2 : (ks % 3 == 1 ? w0 : w1);
+      if (ks + 2 < KS) {
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) wn[nt] = frag_qkv(sW, nt, ks + 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          acc[nt][mt] = swap ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb[mt][ks], wc[nt], acc[nt][mt], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[nt], xb[mt][ks], acc[nt][mt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto frag_o = [&](const bf16* sW, int nt, int ks2) {
+    const int row = (nt & 3) * 16 + fr;
+    return *(const bf16x8*)(sW + (nt >> 2) * TA_OSUB + row * 64 + (((ks2 * 4 + fg) ^ (row & 7)) << 3));
+  };
+
+  for (int head = 0; head < TA_HEADS; ++head) {
+    const bool last = head + 1 == TA_HEADS;
+    f32x4 qa[3][2], ka[3][2], va[3][2];
+    // ---- q stage (s = 4 head): in flight behind it: k (8) ----
+    stage_wait(8);
+    issue(head, 2, (slot + 2) % TA_NS);
+    gemm_qkv(smem + slot * (TA_SLOT / 2), qa, false);
+    next_slot();
+    // ---- k stage: in flight behind it: v (8) ----
+    stage_wait(8);
+    issue(head, 3, (slot + 2) % TA_NS);
+    gemm_qkv(smem + slot * (TA_SLOT / 2), ka, false);
+    next_slot();
+    // ---- v stage: in flight behind it: o (10) ----
+    stage_wait(10);
+    if (!last) issue(head + 1, 0, (slot + 2) % TA_NS);
+    gemm_qkv(smem + slot * (TA_SLOT / 2), va, true);
+    next_slot();
+
+    // ---- attention of this head for the wave's two pixels, in registers ----
+    bf16x8 ob0[2], ob1[2];          // B fragments of the two k-steps of the o stage
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt)      // S^T[key 4 fg + r][query fr] += K[key][c] Q[query][c] over the 16 channels of tile nt
+        s = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pack4(ka[nt][mt]), pack4(qa[nt][mt]), s, 0, 0, 0);
+      float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      f32x4 e;
+      float l = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f((s[r] - mx) * p.scale_log2e); l += e[r]; }
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+      const float inv = __builtin_amdgcn_rcpf(l);
+      const s16x4 pb = pack4(e);          // P^T[key 4 fg + r][query fr]: the B operand of O^T = V^T P^T as it stands
+      f32x4 o[3];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {       // O^T[channel 16 g + 4 fg + r][query fr]
+        o[g] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pack4(va[g][mt]), pb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        o[g] *= inv;
+      }
+      bf16x8 b0, b1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        b0[r] = (bf16)o[0][r]; b0[4 + r] = (bf16)o[1][r];         // k-slots 8 fg + j: channels {4 fg + j} and {16 + 4 fg + j}
+        b1[r] = (bf16)o[2][r]; b1[4 + r] = (bf16)0.0f;           // k-slots 32 + 8 fg + j: channels {32 + 4 fg + j} (fg < 2), rest zero
+      }
+      ob0[mt] = b0; ob1[mt] = b1;
+    }
+
+    // ---- o stage: out += Wo[:, head] . O^T ; in flight behind it: next head's q (8) ----
+    stage_wait(last ? 0 : 8);
+    if (!last) issue(head + 1, 1, (slot + 2) % TA_NS);
+    {
+      const bf16* sW = smem + slot * (TA_SLOT / 2);
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = frag_o(sW, i, 0);
+#pragma unroll
+      for (int grp = 0; grp < 10; ++grp) {
+        const int ks2 = grp / 5, q = grp - 5 * ks2;
+        bf16x8 (&cur)[4] = (grp & 1) ? fb : fa;
+        bf16x8 (&nxt)[4] = (grp & 1) ? fa : fb;
+        if (grp + 1 < 10) {
+          const int g2 = grp + 1, k2 = g2 / 5, q2 = g2 - 5 * k2;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) nxt[i] = frag_o(sW, 4 * q2 + i, k2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int nt = 4 * q + i;
+          oacc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[i], ks2 ? ob1[0] : ob0[0], oacc[nt][0], 0, 0, 0);
+          oacc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[i], ks2 ? ob1[1] : ob0[1], oacc[nt][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    next_slot();
+  }
+
+  // ---- epilogue: t <- t + bo + acc (lane: frame fr of pixel mt, channels 16 nt + 4 fg .. +3), in place ----
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    bf16* tr = trow[mt] + 4 * fg;
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) {
+      const bf16x4 xv = *(const bf16x4*)(tr + 16 * nt);
+      const f32x4 bb = *(const f32x4*)(p.bo + 16 * nt + 4 * fg);
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16)(oacc[nt][mt][e] + bb[e] + (float)xv[e]);
+      *(bf16x4*)(tr + 16 * nt) = o;
+    }
+  }
+}
+
+// Builds the weight stream from the four bf16 [C][C] matrices (rows = output features).  One thread per 16-byte chunk.
+__global__ __launch_bounds__(256) void tattn_stream_pack_kernel(const bf16* __restrict__ wq, const bf16* __restrict__ wk, const bf16* __restrict__ wv,
+                                                                const bf16* __restrict__ wo, bf16* __restrict__ stream) {
+  constexpr int C = TA_C;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  constexpr int CH_HEAD = TA_HEAD_BYTES / 16;
+  if (idx >= TA_HEADS * CH_HEAD) return;
+  const int head = idx / CH_HEAD;
+  int c = idx - head * CH_HEAD;
+  bf16x8 v = bf16x8_zero();
+  if (c < 3 * (TA_QKV_BYTES / 16)) {
+    const int part = c / (TA_QKV_BYTES / 16);
+    c -= part * (TA_QKV_BYTES / 16);
+    if (c < 5 * 48 * 8) {                                      // [5 sub-tiles][48 rows][8 chunks]; the tail of the stage is padding
+      const int sub = c / (48 * 8), row = (c / 8) % 48, phys = c & 7;
+      const int lchunk = phys ^ (row & 7);
+      if (row < TA_D) {
+        const bf16* w = part == 0 ? wq : (part == 1 ? wk : wv);
+        v = *(const bf16x8*)(w + (size_t)(head * TA_D + row) * C + 64 * sub + 8 * lchunk);
+      }
+    }
+  } else {
+    c -= 3 * (TA_QKV_BYTES / 16);
+    const int sub = c >> 9, row = (c >> 3) & 63, phys = c & 7;   // [5][64 n rows][8 chunks of 8 k-slots]
+    const int lchunk = phys ^ (row & 7);
+    const int n = 64 * sub + row;
+    const int ks2 = lchunk >> 2, fgq = lchunk & 3;
+    const bf16* src = wo + (size_t)n * C + head * TA_D;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int ch = -1;
+      if (ks2 == 0) ch = j < 4 ? 4 * fgq + j : 16 + 4 * fgq + (j - 4);
+      else if (j < 4 && fgq < 2) ch = 32 + 4 * fgq + j;
+      v[j] = ch >= 0 ? src[ch] : (bf16)0.0f;
+    }
+  }
+  *(bf16x8*)(stream + (size_t)idx * 8) = v;
+}
+
+unsigned long long g_ta_attr = 0;
+
+}  // namespace
+
+extern "C" size_t nr_tattn_stream_bytes(void) { return (size_t)TA_HEADS * TA_HEAD_BYTES; }
+
+extern "C" int nr_tattn_fused_eligible(int C, int heads, int frames, int hw, long long rows) {
+  static const bool off = getenv("NR_TATTN_FUSED") && getenv("NR_TATTN_FUSED")[0] == '0';   // A/B switch
+  return !off && C == TA_C && heads == TA_HEADS && frames == TA_F && hw % 8 == 0 && rows >= 4096;
+}
+
+extern "C" int nr_launch_tattn_stream_pack(const bf16* wq, const bf16* wk, const bf16* wv, const bf16* wo, bf16* stream, hipStream_t s) {
+  const int total = TA_HEADS * (TA_HEAD_BYTES / 16);
+  hipLaunchKernelGGL(tattn_stream_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, wq, wk, wv, wo, stream);
+  return 0;
+}
+
+extern "C" int nr_launch_tattn_fused(bf16* t, int nbatch, int hw, const bf16* stream, const float* gamma, const float* gb, const float* bo,
+                                     float ln_eps, hipStream_t s) {
+  if (nbatch <= 0 || hw <= 0 || hw % 8 != 0) return 1;
+  NrTAttnParams p;
+  p.t = t; p.hw = hw; p.nbatch = nbatch; p.stream = stream; p.gamma = gamma; p.gb = gb; p.bo = bo; p.ln_eps = ln_eps;
+  p.scale_log2e = 1.4426950408889634f / sqrtf((float)TA_D);
+  constexpr size_t shm = (size_t)TA_NS * TA_SLOT;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!(g_ta_attr >> (dev & 63) & 1ull)) {
+    if (hipFuncSetAttribute((const void*)tattn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return 2;
+    g_ta_attr |= 1ull << (dev & 63);
+  }
+  hipLaunchKernelGGL(tattn_fused_kernel, dim3((unsigned)(nbatch * (hw / 8))), dim3(256), shm, s, p);
+  return 0;
+}

@@ -210,3 +210,27 @@ def ff_fused(t, x, gamma, beta, w1, b1, w2, b2, wpo, bpo, eps=1e-5):
     _lib.check(_lib.load().nr_op_ff_fused(_stream(), _ptr(t), _ptr(x), _ptr(out), M, C, _ptr(wsp.contiguous()), _ptr(cp.reshape(-1).contiguous()),
                                           _ptr(bp.contiguous()), _ptr(wc), _ptr(bc), float(eps)))
     return out
+
+
+def temporal_pe_table(frames, C, device):
+    """PositionalEncoding table (motion_module.py:225-239): pe[pos, 0::2] = sin(pos * div), pe[pos, 1::2] = cos(pos * div)."""
+    import math
+    position = torch.arange(frames, device=device, dtype=torch.float32).unsqueeze(1)
+    div = torch.exp(torch.arange(0, C, 2, device=device, dtype=torch.float32) * (-math.log(10000.0) / C))
+    pe = torch.zeros(frames, C, device=device)
+    pe[:, 0::2] = torch.sin(position * div)
+    pe[:, 1::2] = torch.cos(position * div)
+    return pe
+
+
+def tattn_fused(t, nbatch, hw, gamma, beta, wq, wk, wv, wo, bo, eps=1e-5, reuse_stream=False):
+    """t <- t + to_out(temporal self-attention(LayerNorm(t) + pe)) over the 16 frames of every pixel, C = 320, 8 heads, ONE launch (tattn.hip).
+    t: [nbatch * 16 * hw, 320] bf16 in "(b f) (h w) c" row order, updated IN PLACE and returned; w*: [320, 320] fp32 or bf16."""
+    _chk_bf16(t)
+    C, F = 320, 16
+    assert t.shape == (nbatch * F * hw, C)
+    gb = (beta.float()[None] + temporal_pe_table(F, C, t.device)).contiguous()
+    ws = [w.to(torch.bfloat16).contiguous() for w in (wq, wk, wv, wo)]
+    _lib.check(_lib.load().nr_op_tattn_fused(_stream(), _ptr(t), nbatch, hw, None if reuse_stream else _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]),
+                                             _ptr(ws[3]), _ptr(gamma.float().contiguous()), _ptr(gb), _ptr(bo.float().contiguous()), float(eps)))
+    return t

@@ -58,6 +58,8 @@ class FakeVAE:
     def decode(self, z):
         assert z.shape[0] == 1 and z.shape[1] == 4, "the reference decodes frame by frame"
         self.calls += 1
-        img = torch.tanh(z[:, :3] * 0.7 + 0.1 * z[:, 3:4])
+        # gentle on purpose: the pipeline hands over latents / 0.18215 (values of order 100 with random-init networks); a steep map would turn
+        # the loop's bf16-level latent differences into sign flips of saturated pixels and measure nothing
+        img = torch.tanh(z[:, :3] * 0.006 + 0.002 * z[:, 3:4])
         img = img.repeat_interleave(8, dim=-1).repeat_interleave(8, dim=-2)
         return types.SimpleNamespace(sample=img)

@@ -374,3 +374,33 @@ def test_fused_feedforward_proj_out_matches_torch(cuda, M):
     ref = x.float() + torch.nn.functional.linear(tf + ff, wpo, bpo)
     _cmp(f"fused FF + proj_out M={M}", out, ref)
     assert torch.equal(out, ops.ff_fused(t, x, gamma, beta, w1, b1, w2, b2, wpo, bpo))
+
+
+@pytest.mark.parametrize("nbatch,hw", [(2, 1024), (1, 264), (3, 8)])
+def test_fused_temporal_attention_block_matches_torch(cuda, nbatch, hw):
+    """tattn.hip: norm -> (+ positional encoding) -> to_q|k|v -> softmax(q k^T / sqrt(40)) v over the 16 frames of each pixel -> to_out (+bias)
+    -> + residual, C = 320, 8 heads, one launch, in place; against the fp32 torch composition of the reference
+    (motion_module.py:210-218 block, :270-329 VersatileAttention incl. the "(b f) d c -> (b d) f c" regroup, :225-243 PositionalEncoding;
+    motion_module_new.py:201-287 attention arithmetic).  Tolerance as the other MFMA ops (bf16 operands, fp32 accumulation)."""
+    from neurons_amd import ops
+    C, F, H = 320, 16, 8
+    g = torch.Generator(device="cuda").manual_seed(nbatch * 1000 + hw)
+    t = (torch.randn(nbatch * F * hw, C, generator=g, device="cuda") * 1.1 + 0.1).to(torch.bfloat16)
+    gamma = 1.0 + 0.2 * torch.randn(C, generator=g, device="cuda")
+    beta = 0.1 * torch.randn(C, generator=g, device="cuda")
+    wq, wk, wv, wo = (torch.randn(C, C, generator=g, device="cuda") * C ** -0.5 for _ in range(4))
+    wq = wq * 2.0                                  # sharper softmax: exercises the max subtraction
+    bo = 0.1 * torch.randn(C, generator=g, device="cuda")
+    x = t.float().view(nbatch, F, hw, C)
+    n = torch.nn.functional.layer_norm(x, (C,), gamma, beta, 1e-5) + ops.temporal_pe_table(F, C, t.device)[None, :, None, :]
+    seq = n.permute(0, 2, 1, 3).reshape(nbatch * hw, F, C)                     # (b d) f c
+    bw = lambda w: w.to(torch.bfloat16).float()
+    q, k, v = (torch.nn.functional.linear(seq, bw(w)).view(-1, F, H, C // H).transpose(1, 2) for w in (wq, wk, wv))
+    a = torch.softmax(q @ k.transpose(-1, -2) * (C // H) ** -0.5, dim=-1) @ v
+    o = torch.nn.functional.linear(a.transpose(1, 2).reshape(nbatch * hw, F, C), bw(wo), bo)
+    ref = x + o.view(nbatch, hw, F, C).permute(0, 2, 1, 3)
+    t1 = t.clone()
+    out = ops.tattn_fused(t1, nbatch, hw, gamma, beta, wq, wk, wv, wo, bo)
+    _cmp(f"fused temporal attention block nbatch={nbatch} hw={hw}", out.view(nbatch, F, hw, C), ref)
+    t2 = t.clone()
+    assert torch.equal(out, ops.tattn_fused(t2, nbatch, hw, gamma, beta, wq, wk, wv, wo, bo))
