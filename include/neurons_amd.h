@@ -314,11 +314,12 @@ nr_status nr_op_attention(nr_stream stream, int32_t mode, const void* q_dev, con
 
 /* Fused FeedForward(GEGLU) + proj_out of the C = 320 level (ffpanel.hip; engine: feed_forward_proj_out):
  *   out = x + bc + [t | GEGLU(LayerNorm(t) W1^T + b1)] . Wc^T        (attention.py:129-140,297-299; motion_module.py:150-158,219-221)
- * with the inputs in the engine's converted formats: w1 = gamma-scaled, value/gate-interleaved rows [8C][C] bf16, c1[n] = sum_k w1[n][k],
- * b1 = bias + beta . W1 (interleaved), wc = [Wpo | Wpo Wff2] [C][5C] bf16, bc = bpo + Wpo bff2.  t, x, out: bf16 [M][C]. */
+ * with the weights in the engine's converted formats: w1 = value/gate-interleaved rows [8C][C] bf16 and b1 its bias in the same order,
+ * gamma / beta the LayerNorm parameters, wc = [Wpo | Wpo Wff2] [C][5C] bf16, bc = bpo + Wpo bff2.  t, x, out: bf16 [M][C].
+ * w1 == NULL re-uses the weight stream packed by the previous call. */
 nr_status nr_op_ff_fused(nr_stream stream, const void* t_dev, const void* x_dev, void* out_dev, int32_t M, int32_t C,
-                         const void* w1_ln_geglu_dev, const float* c1_dev, const float* b1_dev, const void* wc_dev, const float* bc_dev,
-                         float ln_eps);
+                         const void* w1_geglu_dev, const float* gamma_dev, const float* beta_dev, const float* b1_geglu_dev,
+                         const void* wc_dev, const float* bc_dev, float ln_eps);
 
 /* One temporal-attention block of the C = 320 level in one launch (tattn.hip; engine: temporal_module):
  *   t <- t + to_out(softmax(q k^T / sqrt(d)) v),  [q | k | v] = (LayerNorm(t) + pe[frame]) [Wq | Wk | Wv]^T,  sequence = the 16 frames of a pixel

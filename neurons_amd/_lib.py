@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libneurons_amd.so")
+# NR_LIB_VARIANT=pk loads libneurons_amd_pk.so: the SAME sources built WITH packed fp32 VALU ops (make -C neurons_amd/csrc pk), the
+# other arm of the two-stream determinism A/B (tools/race_gn.py, profiles/r03_race_*); never the product library
+LIB_PATH = os.path.join(_HERE, "libneurons_amd" + ("_" + os.environ["NR_LIB_VARIANT"] if os.environ.get("NR_LIB_VARIANT") else "") + ".so")
 
 NR_KIND_UNET3D = 0
 NR_KIND_SPARSECTRL = 1
@@ -103,7 +105,7 @@ SYMBOLS = {
     "nr_op_groupnorm": (_I32, [_VP, _VP, _I32, _VP, _I32, _I32, _I32, _I32, _VP, _VP, C.c_float, _I32, _VP, _VP]),
     "nr_op_layernorm": (_I32, [_VP, _VP, _VP, _I32, _I32, _VP, _VP, C.c_float, _VP, _I32, _I32]),
     "nr_op_attention": (_I32, [_VP, _I32, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32]),
-    "nr_op_ff_fused": (_I32, [_VP, _VP, _VP, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, C.c_float]),
+    "nr_op_ff_fused": (_I32, [_VP, _VP, _VP, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, C.c_float]),
     "nr_op_tattn_fused": (_I32, [_VP, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_float]),
 }
 

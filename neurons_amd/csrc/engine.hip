@@ -71,8 +71,8 @@ int nr_launch_tattn_fused(bf16* t, int nbatch, int hw, const bf16* stream, const
 size_t nr_ff_stream_bytes(int C);
 int nr_ff_fused_eligible(int C, long long M);
 int nr_launch_ff_stream_pack(const bf16* w1, const bf16* wc, bf16* stream, hipStream_t s);
-int nr_launch_ff_fused(const bf16* t, int ldt, const bf16* x, int ldx, bf16* out, int ldo, int M, const bf16* stream, const float* c1,
-                       const float* b1, const float* bc, float ln_eps, hipStream_t s);
+int nr_launch_ff_fused(const bf16* t, int ldt, const bf16* x, int ldx, bf16* out, int ldo, int M, const bf16* stream, const float* gamma,
+                       const float* beta, const float* b1, const float* bc, float ln_eps, hipStream_t s);
 }
 
 namespace {
@@ -897,16 +897,19 @@ struct nr_net {
     }
     if (nr_ff_fused_eligible(C, t.rows()) && t.ld == C && x.ld == C) {
       // C = 320, >= 4096 rows: LayerNorm + GEGLU projection + the folded GEMM in ONE launch (ffpanel.hip); the 4C-wide hidden activation
-      // stays in registers.  The weights travel as one pre-arranged stage stream built from the same converted pieces.
-      const LnW lw = w_ln_linear({ff + ".net.0.proj.weight"}, {ff + ".net.0.proj.bias"}, ln, inner, C, true);
+      // stays in registers; LayerNorm is applied to the register panel.  The weights travel as one pre-arranged stage stream.
+      const bf16* w1 = w_geglu(ff + ".net.0.proj.weight", inner, C);
+      const float* b1 = b_geglu(ff + ".net.0.proj.bias", inner);
+      const float* gamma = w_f32(ln + ".weight", C);
+      const float* beta = w_f32(ln + ".bias", C);
       const FoldW fw = w_fold_ff_proj(ff + ".net.2", pre + ".proj_out", C);
-      const std::string sname = "ffs:" + ln + "|" + ff + ".net.0.proj.weight|" + ff + ".net.0.proj.bias|" + ff + ".net.2.weight|" + ff +
-                                ".net.2.bias|" + pre + ".proj_out.weight|" + pre + ".proj_out.bias";
+      const std::string sname = "ffs:" + ff + ".net.0.proj.weight|" + ff + ".net.2.weight|" + ff + ".net.2.bias|" + pre + ".proj_out.weight|" + pre +
+                                ".proj_out.bias";
       const bf16* stream = (const bf16*)cached(sname, [&]() {
         void* d = nullptr;
         const size_t nb = nr_ff_stream_bytes(C);
         HIP_OK(hipMalloc(&d, nb));
-        LAUNCH_OK(nr_launch_ff_stream_pack(lw.w, fw.w, (bf16*)d, nullptr));
+        LAUNCH_OK(nr_launch_ff_stream_pack(w1, fw.w, (bf16*)d, nullptr));
         HIP_OK(hipDeviceSynchronize());
         dev[sname] = d; dev_bytes[sname] = nb; weight_bytes += nb;
         return d;
@@ -914,10 +917,10 @@ struct nr_net {
       Act out = new_act(x.nimg, x.H, x.W, C);
       const bf16* tp = t.ptr; const bf16* xp = x.ptr; bf16* op = out.ptr;
       const int M = (int)t.rows();
-      const float* c1 = lw.c; const float* b1 = lw.b; const float* bc = fw.b;
+      const float* bc = fw.b;
       char d[160];
       snprintf(d, sizeof(d), "ff_fused M=%d C=%d (LN + GEGLU 8C + folded net.2|proj_out 5C)", M, C);
-      emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_ff_fused(tp, C, xp, C, op, C, M, stream, c1, b1, bc, 1e-5f, s)); }, NR_PROF_IGEMM,
+      emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_ff_fused(tp, C, xp, C, op, C, M, stream, gamma, beta, b1, bc, 1e-5f, s)); }, NR_PROF_IGEMM,
            2.0 * M * (double)C * (8.0 * C + 5.0 * C), 2.0 * (3.0 * M * (double)C + 13.0 * C * (double)C), d);
       op_tap("ff_fused", out);
       return out;
@@ -2565,17 +2568,17 @@ extern "C" nr_status nr_op_attention(nr_stream stream, int32_t mode, const void*
 
 // ---- fused FeedForward + proj_out (ffpanel.hip), op-level entry for tests: inputs in the engine's converted formats ----
 extern "C" nr_status nr_op_ff_fused(nr_stream stream, const void* t_dev, const void* x_dev, void* out_dev, int32_t M, int32_t C,
-                                    const void* w1_ln_geglu_dev, const float* c1_dev, const float* b1_dev, const void* wc_dev,
-                                    const float* bc_dev, float ln_eps) {
+                                    const void* w1_geglu_dev, const float* gamma_dev, const float* beta_dev, const float* b1_geglu_dev,
+                                    const void* wc_dev, const float* bc_dev, float ln_eps) {
   NR_TRY
   if (!nr_ff_fused_eligible(C, 1 << 30)) throw NrError(NR_ERR_UNSUPPORTED, "the fused FeedForward kernel is built for C = 320");
   static void* ws = nullptr;
   const size_t nb = nr_ff_stream_bytes(C);
   if (!ws) HIP_OK(hipMalloc(&ws, nb));
   // w1 == NULL: reuse the stage stream packed by the previous call (timing loops)
-  if (w1_ln_geglu_dev) LAUNCH_OK(nr_launch_ff_stream_pack((const bf16*)w1_ln_geglu_dev, (const bf16*)wc_dev, (bf16*)ws, (hipStream_t)stream));
-  LAUNCH_OK(nr_launch_ff_fused((const bf16*)t_dev, C, (const bf16*)x_dev, C, (bf16*)out_dev, C, M, (const bf16*)ws, c1_dev, b1_dev, bc_dev,
-                               ln_eps, (hipStream_t)stream));
+  if (w1_geglu_dev) LAUNCH_OK(nr_launch_ff_stream_pack((const bf16*)w1_geglu_dev, (const bf16*)wc_dev, (bf16*)ws, (hipStream_t)stream));
+  LAUNCH_OK(nr_launch_ff_fused((const bf16*)t_dev, C, (const bf16*)x_dev, C, (bf16*)out_dev, C, M, (const bf16*)ws, gamma_dev, beta_dev,
+                               b1_geglu_dev, bc_dev, ln_eps, (hipStream_t)stream));
   NR_CATCH
 }
 

@@ -54,41 +54,53 @@ struct NrFFParams {
   bf16* out; int ldo;            // [M][C]
   int M;
   const bf16* stream;            // 65 stages x 40 KiB (ff_stream_pack_kernel)
-  const float* c1;               // [8C] sum_k W1'[n][k]     (LayerNorm fold, value/gate-interleaved row order)
-  const float* b1;               // [8C] b1 + beta . W1
+  const float* gamma;            // [C] LayerNorm weight
+  const float* beta;             // [C] LayerNorm bias
+  const float* b1;               // [8C] net.0 bias in the value/gate-interleaved row order of the weight
   const float* bc;               // [C]  bpo + Wpo bff2
   float ln_eps;
+  int dbg;               // timing experiments only (NR_FUSED_DBG): 1 no DMA waits, 2 no stage barriers, 4 no DMA issue (results are wrong)
 };
+
+// exact-erf GELU gate times the value, two outputs at a time (Abramowitz-Stegun 7.1.25 as gelu_erf_fast of common.h)
+__device__ __forceinline__ float geglu1(float v, float g) { return v * gelu_erf_fast(g); }
 
 __global__ __launch_bounds__(256) void ff_fused_kernel(NrFFParams p) {
   constexpr int C = FF_C, KS = C / 32, NT2 = C / 16;       // 10 k-steps of the panel, 20 16-column groups of the output
-  extern __shared__ __attribute__((aligned(16))) bf16 smem[];   // FF_NS stages, then c1 | b1 (2 x 8C floats)
+  extern __shared__ __attribute__((aligned(16))) bf16 smem[];   // FF_NS stages, then b1 (8C floats)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
 
-  // ---- weight stream: every workgroup walks the same 65 stages; wave w copies bytes [10 w KiB, 10 (w+1) KiB) of each ----
+  // ---- weight stream.  The 20 (W1, W1, g-piece) triples are independent up to the order of the fp32 accumulation, so every workgroup
+  // walks them from its own starting triple: the 32 workgroups of an XCD then read 20 different regions of the stream instead of all
+  // hammering the same 40 KiB (the same few L2 channels) in lockstep.  blockIdx % 8 labels the XCD (speed only; results depend on blockIdx
+  // alone, so they are reproducible run to run). ----
+  const int pair0 = (int)((blockIdx.x >> 3) % FF_PAIRS);
   const char* wsrc = reinterpret_cast<const char*>(p.stream) + (size_t)wave * (FF_DMA * 1024) + (size_t)lane * 16;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lptr_t)smem) + (unsigned)wave * (FF_DMA * 1024);
-  auto issue = [&](int stage) {
-    const unsigned dst = lds0 + (unsigned)((stage % FF_NS) * FF_STAGE * 2);
-    const char* src = wsrc + (size_t)stage * (FF_STAGE * 2);
-#pragma unroll
-    for (int i = 0; i < FF_DMA; ++i) glds16(src + i * 1024, dst + (unsigned)(i * 1024));
+  // logical stage s (order of execution) -> stage of the stream
+  auto phys_stage = [&](int s) {
+    if (s < FF_TSTAGES) return s;
+    const int q = (s - FF_TSTAGES) / 3, r = (s - FF_TSTAGES) - 3 * q;
+    int pr = pair0 + q;
+    pr = pr >= FF_PAIRS ? pr - FF_PAIRS : pr;
+    return FF_TSTAGES + 3 * pr + r;
   };
-  issue(0);
-  issue(1);
-  // the GEGLU epilogue constants (LayerNorm-fold column sums and folded bias, 2 x 8C floats) live in LDS behind the ring: a global load
-  // inside the stage loop would make hipcc wait for it with a vmcnt that also drains the LDS-DMA issued before it
-  float* sC1 = reinterpret_cast<float*>(smem + FF_NS * FF_STAGE);
-  float* sB1 = sC1 + 8 * C;
-  for (int i = tid * 4; i < 8 * C; i += 256 * 4) {
-    *(f32x4*)(sC1 + i) = *(const f32x4*)(p.c1 + i);
-    *(f32x4*)(sB1 + i) = *(const f32x4*)(p.b1 + i);
-  }
-  __syncthreads();      // the constants are visible to every wave before the first epilogue (the stage barriers are raw s_barrier)
+  auto issue_piece = [&](int s, int slot, int i) {      // one of the 10 LDS-DMA instructions of logical stage s
+    const char* src = wsrc + (size_t)phys_stage(s) * (FF_STAGE * 2);
+    glds16(src + i * 1024, lds0 + (unsigned)(slot * FF_STAGE * 2) + (unsigned)(i * 1024));
+  };
+#pragma unroll
+  for (int i = 0; i < FF_DMA; ++i) issue_piece(0, 0, i);
+#pragma unroll
+  for (int i = 0; i < FF_DMA; ++i) issue_piece(1, 1, i);
+  // the net.0 bias (8C floats) lives in LDS behind the ring: a global load inside the stage loop would make hipcc wait for it with a
+  // vmcnt that also drains the LDS-DMA issued before it
+  float* sB1 = reinterpret_cast<float*>(smem + FF_NS * FF_STAGE);
+  for (int i = tid * 4; i < 8 * C; i += 256 * 4) *(f32x4*)(sB1 + i) = *(const f32x4*)(p.b1 + i);
 
   // ---- the row panel: lane holds row (16 mt + fr) of its wave's 32 rows, k = 32 ks + 8 fg .. +7 ----
   const int mrow0 = blockIdx.x * FF_ROWS + wave * 32;
@@ -101,43 +113,45 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(NrFFParams p) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) xb[mt][ks] = *(const bf16x8*)(ap + 32 * ks);
   }
-  // LayerNorm statistics from the panel (fp32 sums of the raw bf16 pairs; var = E[x^2] - mean^2 as in gemm.hip LNF / rowpanel.hip)
-  float rs[2], mr[2];      // rstd_m and mean_m * rstd_m
-  {
-    const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      float s = 0.f, q = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const bf16x2 pr = {xb[mt][ks][2 * e], xb[mt][ks][2 * e + 1]};
-          s = __builtin_amdgcn_fdot2_f32_bf16(pr, one2, s, false);
-          q = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, q, false);
-        }
-      s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
-      s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
-      const float mu = s * (1.0f / C);
-      rs[mt] = rsqrtf(fmaxf(q * (1.0f / C) - mu * mu, 0.f) + p.ln_eps);
-      mr[mt] = mu * rs[mt];
-    }
-  }
+  __syncthreads();      // b1 is visible to every wave before the first chunk (the stage barriers are raw s_barrier)
 
   f32x4 oacc[NT2][2];
 #pragma unroll
   for (int nt = 0; nt < NT2; ++nt)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) oacc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8 gB[2][2];            // [k-step of the g-piece = W1 chunk parity][mt]
 
-  // A fragment of a [320 n][64 k] stage (t-part / g-piece): 16 n rows nt, k-step ks2 (32 deep)
+  // ---- stage sequencing: ring slot and waits are runtime values, everything that indexes registers is unrolled ----
+  int s = 0, ring = 0;
+  const char* pf_src = wsrc;
+  unsigned pf_dst = lds0;
+  auto stage_begin = [&]() -> const bf16* {
+    // stage s must have landed: this wave's 10 DMA pieces of stage s + 1 (issued during stage s - 1) may stay outstanding.  No other
+    // vector-memory operation is issued inside the loop, so the count is exact.
+    if (!(p.dbg & 1)) { if (s + 1 < FF_NSTAGES) wait_vmcnt<FF_DMA>(); else wait_vmcnt<0>(); }
+    if (!(p.dbg & 2)) __builtin_amdgcn_s_barrier();            // everyone's pieces of stage s landed; everyone is done reading stage s - 1
+    // where the pieces of stage s + 2 come from / go to (the slot stage s - 1 occupied).  The last two stages re-fetch the final stage into
+    // that free slot, so the piece issue stays unconditional (a branch per piece would cut the MFMA groups into separate scheduling regions)
+    const int s2 = s + 2 < FF_NSTAGES ? s + 2 : FF_NSTAGES - 1;
+    int sl = ring + 2;
+    sl = sl >= FF_NS ? sl - FF_NS : sl;
+    pf_src = wsrc + (size_t)phys_stage(s2) * (FF_STAGE * 2);
+    pf_dst = lds0 + (unsigned)(sl * FF_STAGE * 2);
+    return smem + ring * FF_STAGE;
+  };
+  // piece i of stage s + 2 goes out behind MFMA group i of stage s: spreads the ~100-cycle issue cost of an LDS-DMA piece over the stage
+  // instead of stalling its head
+  auto prefetch_piece = [&](int i) { if (!(p.dbg & 4)) glds16(pf_src + i * 1024, pf_dst + (unsigned)(i * 1024)); };
+  auto stage_end = [&]() { ++s; ring = ring + 1 == FF_NS ? 0 : ring + 1; };
+
   auto frag_n320 = [&](const bf16* sW, int nt, int ks2) {
     const int row = (nt & 3) * 16 + fr;
     return *(const bf16x8*)(sW + (nt >> 2) * FF_SUB + row * 64 + (((ks2 * 4 + fg) ^ (row & 7)) << 3));
   };
-  // out += A(stage [320 n][64 k]) x B(b0 | b1 per mt): 40 fragment reads, 80 MFMAs; reads run one 4-group ahead of the MFMAs
-  auto gemm_n320 = [&](const bf16* sW, const bf16x8 (&b0)[2], const bf16x8 (&b1)[2]) {
+  // one 4-nt group of a [320 n][64 k] stage: 4 fragment reads (issued one group ahead by the caller) -> 8 MFMAs
+  // out += A(stage [320 n][64 k]) x B(b0 | b1 per mt): 10 groups of (4 reads, 8 MFMAs); EPI(grp) is VALU work the caller wants
+  // interleaved with group grp's MFMAs (the previous chunk's GEGLU epilogue)
+  auto gemm_n320 = [&](const bf16* sW, const bf16x8 (&b0)[2], const bf16x8 (&b1)[2], auto&& epi) {
     bf16x8 fa[4], fb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) fa[i] = frag_n320(sW, i, 0);
@@ -151,99 +165,188 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(NrFFParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) nxt[i] = frag_n320(sW, 4 * q2 + i, k2);
       }
+      prefetch_piece(grp);
       __builtin_amdgcn_sched_barrier(0);
+      epi(grp);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int nt = 4 * q + i;
         oacc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[i], ks2 ? b1[0] : b0[0], oacc[nt][0], 0, 0, 0);
         oacc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[i], ks2 ? b1[1] : b0[1], oacc[nt][1], 0, 0, 0);
       }
+      // one MFMA, then the VALU / transcendental instructions that fit under it, eight times
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x402, 4, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  auto no_epi = [](int) {};
 
-  // ---- stage sequencing: ring index and waits are runtime values, everything that indexes registers is unrolled ----
-  int s = 0, ring = 0;
-  auto stage_begin = [&]() -> const bf16* {
-    // stage s must have landed: this wave's DMA of stage s + 1 (issued one stage ago) may stay outstanding.  No other vector-memory
-    // operation is issued inside the loop (the GEGLU constants sit in LDS), so the count is exact.
-    if (s + 1 < FF_NSTAGES) wait_vmcnt<FF_DMA>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();            // everyone's pieces of stage s landed; everyone is done reading stage s - 1
-    if (s + 2 < FF_NSTAGES) issue(s + 2);    // into the buffer stage s - 1 occupied
-    const bf16* sW = smem + ring * FF_STAGE;
-    ++s;
-    ring = ring + 1 == FF_NS ? 0 : ring + 1;
-    return sW;
-  };
-
-  // ---- t-part: out += t[:, 64 ts .. 64 ts + 63] . Wpo[:, same]^T ----
+  // ---- t-part: out += t[:, 64 ts .. 64 ts + 63] . Wpo[:, same]^T  (raw t) ----
 #pragma unroll
   for (int ts = 0; ts < FF_TSTAGES; ++ts) {
     const bf16* sW = stage_begin();
     const bf16x8 b0[2] = {xb[0][2 * ts], xb[1][2 * ts]};
     const bf16x8 b1[2] = {xb[0][2 * ts + 1], xb[1][2 * ts + 1]};
-    gemm_n320(sW, b0, b1);
+    gemm_n320(sW, b0, b1, no_epi);
+    stage_end();
   }
 
-  for (int pair = 0; pair < FF_PAIRS; ++pair) {
+  // ---- LayerNorm of the panel in registers (two-pass: mean, centred second moment), rounded to bf16 exactly where the un-fused LayerNorm
+  // kernel rounds; gamma / beta come from global memory once (the two stages in flight are simply waited for here) ----
+  {
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      // ---- W1 chunk: 64 interleaved rows = 32 hidden units (16 value | 16 gate | 16 value | 16 gate) ----
-      const bf16* sW = stage_begin();
-      const int nw0 = (2 * pair + r) * 64;
-      f32x4 acc[4][2];
+    for (int mt = 0; mt < 2; ++mt) {
+      float sm = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sm += (float)xb[mt][ks][e];
+      sm += __shfl_xor(sm, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      const float mu = sm * (1.0f / C);
+      float q = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = (float)xb[mt][ks][e] - mu; q += d * d; }
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      const float rstd = rsqrtf(q * (1.0f / C) + p.ln_eps);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const f32x4 g0 = *(const f32x4*)(p.gamma + 32 * ks + 8 * fg), g1 = *(const f32x4*)(p.gamma + 32 * ks + 8 * fg + 4);
+        const f32x4 e0 = *(const f32x4*)(p.beta + 32 * ks + 8 * fg), e1 = *(const f32x4*)(p.beta + 32 * ks + 8 * fg + 4);
+        bf16x8 v = xb[mt][ks];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = (bf16)(((float)v[e] - mu) * rstd * g0[e] + e0[e]);
+          v[4 + e] = (bf16)(((float)v[4 + e] - mu) * rstd * g1[e] + e1[e]);
+        }
+        xb[mt][ks] = v;
+      }
+    }
+  }
+
+  // W1 chunk: acc = b1 + xn . W1[chunk]^T.  EPI(ks) = VALU work interleaved with k-step ks (the previous chunk's GEGLU epilogue)
+  auto gemm_w1 = [&](const bf16* sW, int chunk, f32x4 (&acc)[4][2], auto&& epi) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const f32x4 bv = *(const f32x4*)(sB1 + chunk * 64 + 16 * nt + 4 * fg);      // lane's 4 columns of tile nt: the bias is the C operand
+      acc[nt][0] = bv; acc[nt][1] = bv;
+    }
+    auto read_w = [&](bf16x8 (&wf)[4], int ks) {
+      const int t = ks >> 1, k2 = ks & 1;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int row = nt * 16 + fr;
+        wf[nt] = *(const bf16x8*)(sW + t * FF_SUB + row * 64 + (((k2 * 4 + fg) ^ (row & 7)) << 3));
+      }
+    };
+    bf16x8 wf0[4], wf1[4], wf2[4];
+    read_w(wf0, 0);
+    read_w(wf1, 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 (&wc)[4] = (ks % 3 == 0) ? wf0 : (ks % 3 == 1 ? wf1 : wf2);
+      bf16x8 (&wn)[4] = (ks % 3 == 0) ? wf2 : (ks % 3 == 1 ? wf0 : wf1);
+      if (ks + 2 < KS) read_w(wn, ks + 2);
+      prefetch_piece(ks);
+      __builtin_amdgcn_sched_barrier(0);
+      epi(ks);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      auto read_w = [&](bf16x8 (&wf)[4], int ks) {
-        const int t = ks >> 1, k2 = ks & 1;
+        for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[nt], xb[mt][ks], acc[nt][mt], 0, 0, 0);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const int row = nt * 16 + fr;
-          wf[nt] = *(const bf16x8*)(sW + t * FF_SUB + row * 64 + (((k2 * 4 + fg) ^ (row & 7)) << 3));
-        }
-      };
-      bf16x8 wf0[4], wf1[4], wf2[4];
-      read_w(wf0, 0);
-      read_w(wf1, 1);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        bf16x8 (&wc)[4] = (ks % 3 == 0) ? wf0 : (ks % 3 == 1 ? wf1 : wf2);
-        bf16x8 (&wn)[4] = (ks % 3 == 0) ? wf2 : (ks % 3 == 1 ? wf0 : wf1);
-        if (ks + 2 < KS) read_w(wn, ks + 2);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[nt], xb[mt][ks], acc[nt][mt], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x402, 4, 0);
       }
-      // GEGLU epilogue in fragment layout: lane holds rows (16 mt + fr), interleaved columns 16 nt + 4 fg + e
-      f32x4 bv[4], cv[4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        bv[nt] = *(const f32x4*)(sB1 + nw0 + 16 * nt + 4 * fg);
-        cv[nt] = *(const f32x4*)(sC1 + nw0 + 16 * nt + 4 * fg);
-      }
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        bf16x8 gb;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {              // value tile 2 h, gate tile 2 h + 1
-          const f32x4 v = acc[2 * h][mt] * rs[mt] + (bv[2 * h] - cv[2 * h] * mr[mt]);
-          const f32x4 g = acc[2 * h + 1][mt] * rs[mt] + (bv[2 * h + 1] - cv[2 * h + 1] * mr[mt]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) gb[4 * h + e] = (bf16)(v[e] * gelu_erf_fast(g[e]));
-        }
-        gB[r][mt] = gb;
-      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- g-piece: out += g[:, 64 pair .. +63] . (Wpo Wff2)[:, same]^T ----
-    const bf16* sW = stage_begin();
-    gemm_n320(sW, gB[0], gB[1]);
+  };
+  // GEGLU epilogue of one chunk, cut into 8 slices of 2 outputs: slice i -> (mt = i >> 2, h = (i >> 1) & 1, e0 = 2 (i & 1)).
+  // Lane holds rows (16 mt + fr); value tile 2 h, gate tile 2 h + 1, columns 4 fg + e.
+  float gt[2][8];
+  auto epi_slice = [&](const f32x4 (&acc)[4][2], int i) {
+    const int mt = i >> 2, h = (i >> 1) & 1, e0 = 2 * (i & 1);
+    float r0 = geglu1(acc[2 * h][mt][e0], acc[2 * h + 1][mt][e0]);
+    float r1 = geglu1(acc[2 * h][mt][e0 + 1], acc[2 * h + 1][mt][e0 + 1]);
+    // pin the slice where it is written: without the opaque statement LLVM sinks the whole epilogue (pure arithmetic) down to its first
+    // use, the operand packing in front of the g-piece, where no MFMA is left to hide it
+    asm volatile("" : "+v"(r0), "+v"(r1));
+    gt[mt][4 * h + e0] = r0;
+    gt[mt][4 * h + e0 + 1] = r1;
+  };
+  auto pack_g = [&](bf16x8& dst, int mt) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[e] = (bf16)gt[mt][e];
+  };
+
+  bf16x8 gB[2][2];            // [k-step of the g-piece = W1 chunk parity][mt]
+  f32x4 accA[4][2], accB[4][2];
+  for (int q = 0; q < FF_PAIRS; ++q) {
+    int pair = pair0 + q;
+    pair = pair >= FF_PAIRS ? pair - FF_PAIRS : pair;
+    // ---- chunk A: MFMAs only ----
+    {
+      const bf16* sW = stage_begin();
+      gemm_w1(sW, 2 * pair, accA, no_epi);
+      stage_end();
+    }
+    // ---- chunk B: MFMAs with chunk A's GEGLU epilogue interleaved (slices 0..7 behind k-steps 0..7) ----
+    {
+      const bf16* sW = stage_begin();
+      gemm_w1(sW, 2 * pair + 1, accB, [&](int ks) { if (ks < 8) epi_slice(accA, ks); });
+      pack_g(gB[0][0], 0);
+      pack_g(gB[0][1], 1);
+      stage_end();
+    }
+    // ---- g-piece: out += g[:, 64 pair .. +63] . (Wpo Wff2)[:, same]^T.  k-step 0 (groups 0..4) needs chunk A only: chunk B's epilogue
+    // rides on those groups (two slices each on groups 0..3) ----
+    {
+      const bf16* sW = stage_begin();
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = frag_n320(sW, i, 0);
+#pragma unroll
+      for (int grp = 0; grp < 10; ++grp) {
+        const int ks2 = grp / 5, qq = grp - 5 * ks2;
+        bf16x8 (&cur)[4] = (grp & 1) ? fb : fa;
+        bf16x8 (&nxt)[4] = (grp & 1) ? fa : fb;
+        if (grp + 1 < 10) {
+          const int g2 = grp + 1, k2 = g2 / 5, q2 = g2 - 5 * k2;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) nxt[i] = frag_n320(sW, 4 * q2 + i, k2);
+        }
+        prefetch_piece(grp);
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp < 4) { epi_slice(accB, 2 * grp); epi_slice(accB, 2 * grp + 1); }
+        if (grp == 4) { pack_g(gB[1][0], 0); pack_g(gB[1][1], 1); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int nt = 4 * qq + i;
+          oacc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[i], gB[ks2][0], oacc[nt][0], 0, 0, 0);
+          oacc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[i], gB[ks2][1], oacc[nt][1], 0, 0, 0);
+        }
+        if (grp < 4) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x402, 8, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      stage_end();
+    }
   }
 
+  wait_vmcnt<0>();      // the tail's dummy pieces
   // ---- epilogue: out = x + bc + acc, lane holds rows (16 mt + fr), columns 16 nt + 4 fg .. +3 ----
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
@@ -263,7 +366,7 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(NrFFParams p) {
   }
 }
 
-// Builds the 65-stage weight stream from W1' ([8C][C] bf16: LayerNorm-folded, value/gate-interleaved rows, engine w_ln_linear) and
+// Builds the 65-stage weight stream from W1 ([8C][C] bf16, value/gate-interleaved rows: engine w_geglu) and
 // Wc ([C][5C] bf16 = [Wpo | Wpo Wff2], engine w_fold_ff_proj).  One thread per 16-byte chunk of the stream.
 __global__ __launch_bounds__(256) void ff_stream_pack_kernel(const bf16* __restrict__ w1, const bf16* __restrict__ wc, bf16* __restrict__ stream) {
   constexpr int C = FF_C;
@@ -309,12 +412,14 @@ extern "C" int nr_launch_ff_stream_pack(const bf16* w1, const bf16* wc, bf16* st
 }
 
 extern "C" int nr_launch_ff_fused(const bf16* t, int ldt, const bf16* x, int ldx, bf16* out, int ldo, int M, const bf16* stream,
-                                  const float* c1, const float* b1, const float* bc, float ln_eps, hipStream_t s) {
+                                  const float* gamma, const float* beta, const float* b1, const float* bc, float ln_eps, hipStream_t s) {
   if (M <= 0 || ldt % 8 != 0 || ldx % 4 != 0 || ldo % 4 != 0) return 1;
   NrFFParams p;
-  p.t = t; p.ldt = ldt; p.x = x; p.ldx = ldx; p.out = out; p.ldo = ldo; p.M = M; p.stream = stream; p.c1 = c1; p.b1 = b1; p.bc = bc;
+  p.t = t; p.ldt = ldt; p.x = x; p.ldx = ldx; p.out = out; p.ldo = ldo; p.M = M; p.stream = stream; p.gamma = gamma; p.beta = beta; p.b1 = b1; p.bc = bc;
   p.ln_eps = ln_eps;
-  constexpr size_t shm = (size_t)FF_NS * FF_STAGE * sizeof(bf16) + (size_t)2 * 8 * FF_C * sizeof(float);
+  static const int dbg = getenv("NR_FUSED_DBG") ? atoi(getenv("NR_FUSED_DBG")) : 0;
+  p.dbg = dbg;
+  constexpr size_t shm = (size_t)FF_NS * FF_STAGE * sizeof(bf16) + (size_t)8 * FF_C * sizeof(float);
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!(g_ff_attr >> (dev & 63) & 1ull)) {

@@ -59,6 +59,7 @@ struct NrTAttnParams {
   const float* bo;         // [C] to_out bias
   float ln_eps;
   float scale_log2e;       // d^-0.5 * log2(e)
+  int dbg;                 // timing experiments only (NR_FUSED_DBG): 1 no DMA waits, 2 no stage barriers, 4 no DMA issue (results are wrong)
 };
 
 __device__ __forceinline__ s16x4 pack4(const f32x4& v) {
@@ -77,23 +78,31 @@ __global__ __launch_bounds__(256) void tattn_fused_kernel(NrTAttnParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
 
-  // ---- weight stream ----
+  // ---- weight stream.  The heads are independent up to the order of the fp32 accumulation of the out tile, so every workgroup walks them
+  // from its own starting head: the 32 workgroups of an XCD then read 8 different regions of the stream instead of all hammering the same
+  // 32 KiB (the same few L2 channels) in lockstep.  blockIdx % 8 labels the XCD (speed only; results depend on blockIdx alone). ----
+  const int head0 = (int)((blockIdx.x >> 3) & (TA_HEADS - 1));
   const char* wsrc = reinterpret_cast<const char*>(p.stream) + (size_t)lane * 16;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lptr_t)smem);
-  // stage index s = 4 head + part (0 q, 1 k, 2 v, 3 o); ring slot s % 3
-  auto issue = [&](int head, int part, int slot) {
-    const char* src = wsrc + (size_t)head * TA_HEAD_BYTES + (size_t)part * TA_QKV_BYTES;
-    const unsigned dst = lds0 + (unsigned)(slot * TA_SLOT);
-    if (part < 3) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) glds16(src + (wave * 8 + i) * 1024, dst + (unsigned)((wave * 8 + i) * 1024));
-    } else {
-#pragma unroll
-      for (int i = 0; i < 10; ++i) glds16(src + (wave * 10 + i) * 1024, dst + (unsigned)((wave * 10 + i) * 1024));
-    }
+  // Stage order: q k v o per head.  (Running the o stage one head late, so that its 80 MFMAs cover the shuffle / exp latency chain of the next
+  // head's attention, was built and spilled 129 VGPRs: the panel, the packed q|k|v tiles and the attention state do not fit 256 VGPRs.)
+  // piece i of a stage: q / k / v stages have 32 pieces of 1 KiB (8 per wave), o stages 40 (10 per wave)
+  const char* pf_src = wsrc;
+  unsigned pf_dst = lds0;
+  int pf_n = 0;                     // pieces per wave of the stage being prefetched: 8 or 10
+  auto set_prefetch = [&](int hidx, int part, int slot) {      // hidx: position in this workgroup's head order
+    const int head = (head0 + hidx) & (TA_HEADS - 1);
+    pf_n = part < 3 ? 8 : 10;
+    pf_src = wsrc + (size_t)head * TA_HEAD_BYTES + (size_t)part * TA_QKV_BYTES + (size_t)(wave * pf_n) * 1024;
+    pf_dst = lds0 + (unsigned)(slot * TA_SLOT) + (unsigned)(wave * pf_n * 1024);
   };
-  issue(0, 0, 0);
-  issue(0, 1, 1);
+  auto prefetch_piece = [&](int i) { if (!(p.dbg & 4)) glds16(pf_src + i * 1024, pf_dst + (unsigned)(i * 1024)); };
+  set_prefetch(0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) prefetch_piece(i);
+  set_prefetch(0, 1, 1);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) prefetch_piece(i);
 
   // ---- the row panel: tile mt = pixel, lane row fr = frame; row index in t = (b F + frame) hw + pixel ----
   const int groups_per_img = p.hw >> 3;
@@ -156,20 +165,23 @@ __global__ __launch_bounds__(256) void tattn_fused_kernel(NrTAttnParams p) {
     for (int mt = 0; mt < 2; ++mt) oacc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   int slot = 0;
-  // NEXT: LDS-DMA instructions this wave issued for the FOLLOWING stage (they may stay in flight); 0 on the very last stage
+  // stage start: this wave's pieces of the stage (landed) vs the FOLLOWING stage's pieces (next_dma of them may stay in flight)
   auto stage_wait = [&](int next_dma) {
-    if (next_dma == 10) wait_vmcnt<10>(); else if (next_dma == 8) wait_vmcnt<8>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
+    if (!(p.dbg & 1)) { if (next_dma == 10) wait_vmcnt<10>(); else wait_vmcnt<8>(); }
+    if (!(p.dbg & 2)) __builtin_amdgcn_s_barrier();
   };
   auto next_slot = [&]() { slot = slot + 1 == TA_NS ? 0 : slot + 1; };
+  auto slot_plus2 = [&]() { int x = slot + 2; return x >= TA_NS ? x - TA_NS : x; };
 
   // fragment of a q / k / v stage: 16 weight rows nt (0..2), k-step ks
   auto frag_qkv = [&](const bf16* sW, int nt, int ks) {
     const int row = nt * 16 + fr;
     return *(const bf16x8*)(sW + (ks >> 1) * TA_QSUB + row * 64 + ((((ks & 1) * 4 + fg) ^ (row & 7)) << 3));
   };
-  // acc[nt][mt] over K = 320; SWAP: activations as the A operand (result transposed: lane = channel, registers = frames)
-  auto gemm_qkv = [&](const bf16* sW, f32x4 (&acc)[3][2], bool swap) {
+  // acc[nt][mt] over K = 320; SWAP: activations as the A operand (result transposed: lane = channel, registers = frames).
+  // One LDS-DMA piece of the stage two ahead goes out behind each of the first pf_n k-steps.
+  auto gemm_qkv = [&](const bf16* sW, s16x4 (&outp)[3][2], bool swap) {
+    f32x4 acc[3][2];
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt)
 #pragma unroll
@@ -185,6 +197,8 @@ __global__ __launch_bounds__(256) void tattn_fused_kernel(NrTAttnParams p) {
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt) wn[nt] = frag_qkv(sW, nt, ks + 2);
       }
+      if (ks < 8) prefetch_piece(ks);
+      else if (pf_n == 10) prefetch_piece(ks);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int nt = 0; nt < 3; ++nt)
@@ -194,95 +208,126 @@ __global__ __launch_bounds__(256) void tattn_fused_kernel(NrTAttnParams p) {
                              : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[nt], xb[mt][ks], acc[nt][mt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    // the attention consumes these tiles as bf16 MFMA operands: keep them packed (12 VGPRs per tensor instead of 24)
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) outp[nt][mt] = pack4(acc[nt][mt]);
   };
   auto frag_o = [&](const bf16* sW, int nt, int ks2) {
     const int row = (nt & 3) * 16 + fr;
     return *(const bf16x8*)(sW + (nt >> 2) * TA_OSUB + row * 64 + (((ks2 * 4 + fg) ^ (row & 7)) << 3));
   };
 
-  for (int head = 0; head < TA_HEADS; ++head) {
-    const bool last = head + 1 == TA_HEADS;
-    f32x4 qa[3][2], ka[3][2], va[3][2];
-    // ---- q stage (s = 4 head): in flight behind it: k (8) ----
-    stage_wait(8);
-    issue(head, 2, (slot + 2) % TA_NS);
-    gemm_qkv(smem + slot * (TA_SLOT / 2), qa, false);
-    next_slot();
-    // ---- k stage: in flight behind it: v (8) ----
-    stage_wait(8);
-    issue(head, 3, (slot + 2) % TA_NS);
-    gemm_qkv(smem + slot * (TA_SLOT / 2), ka, false);
-    next_slot();
-    // ---- v stage: in flight behind it: o (10) ----
-    stage_wait(10);
-    if (!last) issue(head + 1, 0, (slot + 2) % TA_NS);
-    gemm_qkv(smem + slot * (TA_SLOT / 2), va, true);
-    next_slot();
-
-    // ---- attention of this head for the wave's two pixels, in registers ----
-    bf16x8 ob0[2], ob1[2];          // B fragments of the two k-steps of the o stage
+  // ---- attention of one head for the wave's two pixels, cut into 7 phases at its latency points (MFMA result -> cross-lane shuffle ->
+  // exp -> shuffle -> rcp -> MFMA); each phase is pinned (opaque asm) so that the o stage of the previous head can put one group of 8
+  // MFMAs between consecutive phases ----
+  s16x4 qa[3][2], ka[3][2], va[3][2];
+  f32x4 at_s[2], at_o[3][2];          // at_s: scores, then their exponentials
+  float at_m[2], at_l[2];
+  bf16x8 ob_prev0[2], ob_prev1[2];   // O^T of the head whose o stage runs next, as the two B fragments of that stage
+  auto attn_phase = [&](int ph) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ph == 0) {               // S^T[key 4 fg + r][query fr] += K[key][c] Q[query][c] over the 16 channels of tile nt
+        f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int nt = 0; nt < 3; ++nt)      // S^T[key 4 fg + r][query fr] += K[key][c] Q[query][c] over the 16 channels of tile nt
-        s = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pack4(ka[nt][mt]), pack4(qa[nt][mt]), s, 0, 0, 0);
-      float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      f32x4 e;
-      float l = 0.f;
+        for (int nt = 0; nt < 3; ++nt) s4 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ka[nt][mt], qa[nt][mt], s4, 0, 0, 0);
+        at_s[mt] = s4;
+      } else if (ph == 1) {
+        float mx = fmaxf(fmaxf(at_s[mt][0], at_s[mt][1]), fmaxf(at_s[mt][2], at_s[mt][3]));
+        at_m[mt] = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      } else if (ph == 2) {
+        at_m[mt] = fmaxf(at_m[mt], __shfl_xor(at_m[mt], 32, 64));
+      } else if (ph == 3) {
+        float l = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f((s[r] - mx) * p.scale_log2e); l += e[r]; }
-      l += __shfl_xor(l, 16, 64);
-      l += __shfl_xor(l, 32, 64);
-      const float inv = __builtin_amdgcn_rcpf(l);
-      const s16x4 pb = pack4(e);          // P^T[key 4 fg + r][query fr]: the B operand of O^T = V^T P^T as it stands
-      f32x4 o[3];
+        for (int r = 0; r < 4; ++r) { at_s[mt][r] = __builtin_amdgcn_exp2f((at_s[mt][r] - at_m[mt]) * p.scale_log2e); l += at_s[mt][r]; }
+        at_l[mt] = l + __shfl_xor(l, 16, 64);
+      } else if (ph == 4) {
+        at_l[mt] = at_l[mt] + __shfl_xor(at_l[mt], 32, 64);
+      } else if (ph == 5) {        // O^T[channel 16 g + 4 fg + r][query fr] = V^T P^T
+        const s16x4 pb = pack4(at_s[mt]);
 #pragma unroll
-      for (int g = 0; g < 3; ++g) {       // O^T[channel 16 g + 4 fg + r][query fr]
-        o[g] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pack4(va[g][mt]), pb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        o[g] *= inv;
+        for (int g = 0; g < 3; ++g)
+          at_o[g][mt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va[g][mt], pb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      } else {
+        const float inv = __builtin_amdgcn_rcpf(at_l[mt]);
+        bf16x8 b0, b1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          b0[r] = (bf16)(at_o[0][mt][r] * inv); b0[4 + r] = (bf16)(at_o[1][mt][r] * inv);   // k-slots 8 fg + j: channels {4 fg + j}, {16 + 4 fg + j}
+          b1[r] = (bf16)(at_o[2][mt][r] * inv); b1[4 + r] = (bf16)0.0f;                    // k-slots 32 + 8 fg + j: channels {32 + 4 fg + j} (fg < 2)
+        }
+        ob_prev0[mt] = b0; ob_prev1[mt] = b1;
       }
-      bf16x8 b0, b1;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        b0[r] = (bf16)o[0][r]; b0[4 + r] = (bf16)o[1][r];         // k-slots 8 fg + j: channels {4 fg + j} and {16 + 4 fg + j}
-        b1[r] = (bf16)o[2][r]; b1[4 + r] = (bf16)0.0f;           // k-slots 32 + 8 fg + j: channels {32 + 4 fg + j} (fg < 2), rest zero
-      }
-      ob0[mt] = b0; ob1[mt] = b1;
     }
+    // pin the phase
+    if (ph == 0) asm volatile("" : "+v"(at_s[0]), "+v"(at_s[1]));
+    else if (ph == 1 || ph == 2) asm volatile("" : "+v"(at_m[0]), "+v"(at_m[1]));
+    else if (ph == 3) asm volatile("" : "+v"(at_l[0]), "+v"(at_l[1]), "+v"(at_s[0]), "+v"(at_s[1]));
+    else if (ph == 4) asm volatile("" : "+v"(at_l[0]), "+v"(at_l[1]));
+    else if (ph == 5) asm volatile("" : "+v"(at_o[0][0]), "+v"(at_o[1][0]), "+v"(at_o[2][0]), "+v"(at_o[0][1]), "+v"(at_o[1][1]), "+v"(at_o[2][1]));
+    else asm volatile("" : "+v"(ob_prev0[0]), "+v"(ob_prev0[1]), "+v"(ob_prev1[0]), "+v"(ob_prev1[1]));
+  };
+  // o stage: out += Wo[:, head] . O^T (ob_prev*), 10 groups of 8 MFMAs; WITH_ATTN: attention phases 0..5 of the current head in front of groups 0..5, phase 6 behind the last
+  auto gemm_o = [&](const bf16* sW, bool with_attn) {
+    bf16x8 fa[4], fb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = frag_o(sW, i, 0);
+#pragma unroll
+    for (int grp = 0; grp < 10; ++grp) {
+      const int ks2 = grp / 5, q = grp - 5 * ks2;
+      bf16x8 (&cur)[4] = (grp & 1) ? fb : fa;
+      bf16x8 (&nxt)[4] = (grp & 1) ? fa : fb;
+      if (grp + 1 < 10) {
+        const int g2 = grp + 1, k2 = g2 / 5, q2 = g2 - 5 * k2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) nxt[i] = frag_o(sW, 4 * q2 + i, k2);
+      }
+      if (grp < 8) prefetch_piece(grp);
+      __builtin_amdgcn_sched_barrier(0);
+      if (with_attn && grp < 6) attn_phase(grp);      // phase 6 overwrites the B fragments this stage reads: after the last group
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int nt = 4 * q + i;
+        oacc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[i], ks2 ? ob_prev1[0] : ob_prev0[0], oacc[nt][0], 0, 0, 0);
+        oacc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[i], ks2 ? ob_prev1[1] : ob_prev0[1], oacc[nt][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (with_attn) attn_phase(6);
+  };
 
-    // ---- o stage: out += Wo[:, head] . O^T ; in flight behind it: next head's q (8) ----
-    stage_wait(last ? 0 : 8);
-    if (!last) issue(head + 1, 1, (slot + 2) % TA_NS);
-    {
-      const bf16* sW = smem + slot * (TA_SLOT / 2);
-      bf16x8 fa[4], fb[4];
+  for (int it = 0; it < TA_HEADS; ++it) {
+    const bool last = it + 1 == TA_HEADS;
+    // ---- q stage; in flight behind it: k (8).  Prefetch: v of this head (8) ----
+    stage_wait(8);
+    set_prefetch(it, 2, slot_plus2());
+    gemm_qkv(smem + slot * (TA_SLOT / 2), qa, false);
+    next_slot();
+    // ---- k stage; behind it: v (8).  Prefetch: o of this head (10) ----
+    stage_wait(8);
+    set_prefetch(it, 3, slot_plus2());
+    gemm_qkv(smem + slot * (TA_SLOT / 2), ka, false);
+    next_slot();
+    // ---- v stage; behind it: o (10).  Prefetch: q of the next head (last head: a harmless re-fetch of the first head's q keeps the piece
+    // issue unconditional) ----
+    stage_wait(10);
+    set_prefetch(last ? 0 : it + 1, 0, slot_plus2());
+    gemm_qkv(smem + slot * (TA_SLOT / 2), va, true);
+    next_slot();
+    // ---- attention of this head (both pixels of the wave), in registers ----
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = frag_o(sW, i, 0);
-#pragma unroll
-      for (int grp = 0; grp < 10; ++grp) {
-        const int ks2 = grp / 5, q = grp - 5 * ks2;
-        bf16x8 (&cur)[4] = (grp & 1) ? fb : fa;
-        bf16x8 (&nxt)[4] = (grp & 1) ? fa : fb;
-        if (grp + 1 < 10) {
-          const int g2 = grp + 1, k2 = g2 / 5, q2 = g2 - 5 * k2;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) nxt[i] = frag_o(sW, 4 * q2 + i, k2);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int nt = 4 * q + i;
-          oacc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[i], ks2 ? ob1[0] : ob0[0], oacc[nt][0], 0, 0, 0);
-          oacc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[i], ks2 ? ob1[1] : ob0[1], oacc[nt][1], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
+    for (int ph = 0; ph < 7; ++ph) attn_phase(ph);
+    // ---- o stage; behind it: q of the next head (8) or the dummy.  Prefetch: k of the next head ----
+    stage_wait(8);
+    set_prefetch(last ? 0 : it + 1, 1, slot_plus2());
+    gemm_o(smem + slot * (TA_SLOT / 2), false);
     next_slot();
   }
+  wait_vmcnt<0>();      // the tail's dummy pieces
 
   // ---- epilogue: t <- t + bo + acc (lane: frame fr of pixel mt, channels 16 nt + 4 fg .. +3), in place ----
 #pragma unroll
@@ -362,6 +407,8 @@ extern "C" int nr_launch_tattn_fused(bf16* t, int nbatch, int hw, const bf16* st
   NrTAttnParams p;
   p.t = t; p.hw = hw; p.nbatch = nbatch; p.stream = stream; p.gamma = gamma; p.gb = gb; p.bo = bo; p.ln_eps = ln_eps;
   p.scale_log2e = 1.4426950408889634f / sqrtf((float)TA_D);
+  static const int dbg = getenv("NR_FUSED_DBG") ? atoi(getenv("NR_FUSED_DBG")) : 0;
+  p.dbg = dbg;
   constexpr size_t shm = (size_t)TA_NS * TA_SLOT;
   int dev = 0;
   (void)hipGetDevice(&dev);

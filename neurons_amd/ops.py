@@ -191,24 +191,19 @@ def cfg_ddim_step(eps, x, guidance_scale, alpha_prod_t, alpha_prod_t_prev, do_cf
     return out
 
 
-def ff_fused(t, x, gamma, beta, w1, b1, w2, b2, wpo, bpo, eps=1e-5):
+def ff_fused(t, x, gamma, beta, w1, b1, w2, b2, wpo, bpo, eps=1e-5, reuse_stream=False):
     """out = x + proj_out(t + FF(t)),  FF(t) = net.2(GEGLU(net.0(LayerNorm(t))))  — the tail of a (temporal) transformer at C = 320 in ONE
-    launch (ffpanel.hip).  The weight folding is done here on the host exactly as engine.hip does it: LayerNorm into net.0
-    (w_ln_linear, value/gate interleave), net.2 + proj_out into Wc = [Wpo | Wpo Wff2], bc = bpo + Wpo bff2 (w_fold_ff_proj).
+    launch (ffpanel.hip).  The weight conversion is done here on the host exactly as engine.hip does it: value/gate interleave of net.0
+    (w_geglu / b_geglu), net.2 + proj_out folded into Wc = [Wpo | Wpo Wff2], bc = bpo + Wpo bff2 (w_fold_ff_proj).
     t, x: [M, C] bf16; w1 [8C, C], b1 [8C], w2 [C, 4C], b2 [C], wpo [C, C], bpo [C] fp32."""
     _chk_bf16(t, x)
     M, C = t.shape
-    wf = w1.float()
-    ws = (wf * gamma.float()[None]).to(torch.bfloat16)
-    c = ws.float().sum(dim=1)
-    b = (wf.double() @ beta.double()).float() + b1.float()
-    wsp, _ = geglu_permute(ws, None)
-    cp, bp = geglu_permute(c[:, None], b)
+    w1p, b1p = geglu_permute(w1.to(torch.bfloat16), b1.float())
     wc = torch.cat([wpo.float(), wpo.float() @ w2.float()], dim=1).to(torch.bfloat16).contiguous()
     bc = (bpo.float() + wpo.float() @ b2.float()).contiguous()
     out = torch.empty(M, C, dtype=torch.bfloat16, device=t.device)
-    _lib.check(_lib.load().nr_op_ff_fused(_stream(), _ptr(t), _ptr(x), _ptr(out), M, C, _ptr(wsp.contiguous()), _ptr(cp.reshape(-1).contiguous()),
-                                          _ptr(bp.contiguous()), _ptr(wc), _ptr(bc), float(eps)))
+    _lib.check(_lib.load().nr_op_ff_fused(_stream(), _ptr(t), _ptr(x), _ptr(out), M, C, None if reuse_stream else _ptr(w1p), _ptr(gamma.float().contiguous()),
+                                          _ptr(beta.float().contiguous()), _ptr(b1p), _ptr(wc), _ptr(bc), float(eps)))
     return out
 
 

@@ -286,3 +286,29 @@ def test_export_import_weights_gives_bit_identical_forward(cuda):
     assert unet2.weight_bytes() == unet.weight_bytes()
     with pytest.raises(RuntimeError, match="fresh network"):
         unet2.import_weights(*unet.export_weights())
+
+
+def test_two_stream_schedules_are_bit_reproducible_50x(cuda):
+    """the overlapped step (SparseCtrl beside the U-Net encoder on two streams, nr_denoise_step_forward) and the grouped
+    pipeline schedule (nr_sparsectrl_forward_async one group ahead of nr_unet3d_forward_after) repeated 50 times each on the tiny
+    fixture must give bit-identical results every time.  (Round 2's two-stream flake showed up within a handful of repetitions in the
+    build WITH packed fp32 VALU ops: tools/race_gn.py, profiles/r03_race_*.)"""
+    from neurons_amd import DDIMScheduler, NeuroclipsPipeline
+    g = np.load(os.path.join(GOLD, "tiny_networks.npz"))
+    unet, ctrl = _tiny()
+    sample, ctx = torch.from_numpy(g["sample"]).cuda(), torch.from_numpy(g["ctx"]).cuda()
+    cond, mask = torch.from_numpy(g["cond"]).cuda(), torch.from_numpy(g["mask"]).cuda()
+    first = unet.forward_with_controlnet(ctrl, sample, int(g["t"]), ctx, cond, mask, 1.0).sample.clone()
+    for rep in range(50):
+        again = unet.forward_with_controlnet(ctrl, sample, int(g["t"]), ctx, cond, mask, 1.0).sample
+        assert torch.equal(first, again), f"overlapped step differs at repetition {rep}"
+    c1 = np.load(os.path.join(GOLD, "c1_loop.npz"))
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
+    pipe = NeuroclipsPipeline(vae=None, text_encoder=None, tokenizer=None, unet=unet, scheduler=sched, controlnet=ctrl).to("cuda")
+    kw = dict(video_length=8, height=64, width=64, num_inference_steps=int(c1["steps"]), guidance_scale=float(c1["guidance"]),
+              latents=torch.from_numpy(c1["latents"]).cuda(), noise=torch.from_numpy(c1["noise"]), text_embeddings=torch.from_numpy(c1["ctx"]).cuda(),
+              controlnet_images=torch.from_numpy(c1["cimg"]).cuda(), controlnet_image_index=[0], low_strength=0.3, output_type="latent")
+    ref = pipe("", **kw).videos.clone()
+    assert pipe.last_controlnet_group > 1
+    for rep in range(50):
+        assert torch.equal(ref, pipe("", **kw).videos), f"grouped schedule differs at repetition {rep}"

@@ -139,6 +139,17 @@ def test_c2_multi_gpu_startup_flow_on_one_gpu(c2, cuda):
     torch.cuda.empty_cache()
 
 
+def test_c2_grouped_schedule_is_bit_reproducible_at_full_size(c2):
+    """three repetitions of the grouped two-stream schedule at full size (5 DDIM steps each), bit-equal every time."""
+    pipe, inp, F, L = c2["pipe"], c2["inp"], c2["F"], c2["L"]
+    kw = dict(video_length=F, height=L * 8, width=L * 8, num_inference_steps=5, guidance_scale=8.5, latents=inp["lat"], noise=inp["noise"],
+              text_embeddings=inp["ctx"], controlnet_images=inp["cimg"], controlnet_image_index=[0], low_strength=0.3, output_type="latent")
+    ref = pipe("", **kw).videos.clone()
+    assert pipe.last_controlnet_group == 5
+    for rep in range(3):
+        assert torch.equal(ref, pipe("", **kw).videos), f"full-size grouped schedule differs at repetition {rep}"
+
+
 @pytest.fixture(scope="module")
 def c3(cuda):
     from neurons_amd.sgm import NativeSGMUNet, SGMUNetConfig, sgm_state_dict_schema

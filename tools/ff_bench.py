@@ -40,14 +40,18 @@ lib = _lib.load()
 st = torch.cuda.current_stream().cuda_stream
 
 
+w1p, b1p = ops.geglu_permute(w1.to(torch.bfloat16), b1.float())
+gam, bet = gamma.contiguous(), beta.contiguous()
+
+
 def fused_pack():
-    _lib.check(lib.nr_op_ff_fused(st, t.data_ptr(), x.data_ptr(), out.data_ptr(), M, C, wsp.data_ptr(), cp.data_ptr(), bp.data_ptr(), wc.data_ptr(),
-                                  bc.data_ptr(), 1e-5))
+    _lib.check(lib.nr_op_ff_fused(st, t.data_ptr(), x.data_ptr(), out.data_ptr(), M, C, w1p.data_ptr(), gam.data_ptr(), bet.data_ptr(), b1p.data_ptr(),
+                                  wc.data_ptr(), bc.data_ptr(), 1e-5))
 
 
 def fused():      # stage stream already packed by fused_pack()
-    _lib.check(lib.nr_op_ff_fused(st, t.data_ptr(), x.data_ptr(), out.data_ptr(), M, C, None, cp.data_ptr(), bp.data_ptr(), wc.data_ptr(),
-                                  bc.data_ptr(), 1e-5))
+    _lib.check(lib.nr_op_ff_fused(st, t.data_ptr(), x.data_ptr(), out.data_ptr(), M, C, None, gam.data_ptr(), bet.data_ptr(), b1p.data_ptr(),
+                                  wc.data_ptr(), bc.data_ptr(), 1e-5))
 
 
 def two_launch():
