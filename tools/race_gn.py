@@ -32,7 +32,10 @@ print("variant:", os.environ.get("NR_LIB_VARIANT", "product (no packed fp32)"), 
       (ref.float() - tref).abs().max().item(), flush=True)
 s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
 ITERS = int(os.environ.get("RACE_ITERS", "300"))
-for other in ("none", "gn", "gemm", "conv", "attn"):
+# "big_*": the other stream's kernel fills the whole chip (65 536 workgroups), so the GroupNorm's waves SHARE their SIMDs with it
+xbig = torch.randn(2048, 8, 8, C, device=dev).to(torch.bfloat16)
+abig = torch.randn(1 << 18, 64, device=dev).to(torch.bfloat16)
+for other in ("none", "gn", "gemm", "conv", "attn", "big_gn_silu", "big_gn_nosilu", "big_gemm"):
     bad = 0
     lanes, halves, examples = collections.Counter(), collections.Counter(), []
     for it in range(ITERS):
@@ -46,6 +49,12 @@ for other in ("none", "gn", "gemm", "conv", "attn"):
                     ops.conv3x3(xc, wc)
                 elif other == "attn":
                     ops.attention_self(qkv, 8)
+            if other == "big_gn_silu":
+                ops.groupnorm(xbig, g, b, groups=32, eps=1e-5, silu=True)
+            elif other == "big_gn_nosilu":
+                ops.groupnorm(xbig, g, b, groups=32, eps=1e-5, silu=False)
+            elif other == "big_gemm":
+                ops.gemm(abig, w)
         with torch.cuda.stream(s1):
             outs = [ops.groupnorm(x, g, b, groups=32, eps=1e-5, silu=True) for _ in range(4)]
         torch.cuda.synchronize()
