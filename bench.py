@@ -36,7 +36,7 @@ PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
 
-CURRENT_ROUND = "r02"      # a committed traffic file of an earlier round is reported as historical
+CURRENT_ROUND = "r03"      # a committed traffic file of an earlier round is reported as historical
 
 
 def parse():
@@ -434,7 +434,8 @@ def pmc_traffic():
     name = os.path.basename(files[-1])
     return {"igemm_hbm_gbytes_per_ddim_step": round(d["igemm_hbm_bytes_per_ddim_step"] / 1e9, 2),
             "whole_step_hbm_gbytes": round(d["whole_step_hbm_bytes"] / 1e9, 2), "source": name,
-            "traffic_source_round": name.split("_")[0], "historical": name.split("_")[0] != CURRENT_ROUND}
+            "traffic_source_round": name.split("_")[0], "historical": name.split("_")[0] != CURRENT_ROUND,
+            "measured_in_this_run": False}      # a committed profiler measurement of the same command, not a live counter read
 
 
 def cpu_baseline(host_sd, ucfg, ccfg, args):

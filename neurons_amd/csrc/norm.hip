@@ -521,7 +521,8 @@ static int gn_launch_impl(NrGnParams* pp, hipStream_t stream, bool count_only, i
     // small images: single fused launch (needs an even channels-per-group and an even split point of the concat)
     const int cg = C / p.groups;
     const long long pairs = (long long)p.hw * (cg / 2);
-    if (p.hw <= 64 && cg % 2 == 0 && p.c0 % 2 == 0 && pairs <= 256LL * 48) {
+    static const bool small_on = !(getenv("NR_GN_SMALL") && getenv("NR_GN_SMALL")[0] == '0');   // bisect switch (profiles/r03_race_*)
+    if (small_on && p.hw <= 64 && cg % 2 == 0 && p.c0 % 2 == 0 && pairs <= 256LL * 48) {
       dim3 grid(p.groups, p.nimg);
       if (pairs <= 256LL * 8) GNL((gn_fused_small_kernel<8>), grid, dim3(256), 0, stream, p);
       else if (pairs <= 256LL * 16) GNL((gn_fused_small_kernel<16>), grid, dim3(256), 0, stream, p);
