@@ -1748,13 +1748,22 @@ struct nr_net {
     const size_t end = seg == 0 ? split_op : (seg == 1 ? split_op2 : ops.size());
     if (begin >= end) return;
     auto& cache = gcache[seg];
+    // key = the IO fields this segment's kernels read: only segment 1 (the ControlNet-residual adds) sees the residual pointers, so the
+    // encoder / decoder graphs of the U-Net are shared by every (slot, phase) of the grouped SparseCtrl schedule instead of being
+    // captured once per residual-buffer set
+    IO key = io;
+    if (seg != 1 && cfg.kind == NR_KIND_UNET3D) {
+      std::memset((void*)key.down_res, 0, sizeof(key.down_res));
+      key.mid_res = nullptr;
+      key.has_res = 0;
+    }
     GraphSlot* hit = nullptr;
-    for (auto& g : cache) if (g.exec && g.io == io) { hit = &g; break; }
+    for (auto& g : cache) if (g.exec && g.io == key) { hit = &g; break; }
     if (!hit) {
       if ((int)cache.size() >= NR_GRAPH_SLOTS) {              // evict the least recently used graph
         size_t lru = 0;
         for (size_t i = 1; i < cache.size(); ++i) if (cache[i].used < cache[lru].used) lru = i;
-        HIP_OK(hipStreamSynchronize(s));                       // it may still be executing
+        HIP_OK(hipDeviceSynchronize());                        // it may still be executing, on this or on another stream
         (void)hipGraphExecDestroy(cache[lru].exec);
         cache.erase(cache.begin() + lru);
       }
@@ -1772,7 +1781,7 @@ struct nr_net {
       hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
       (void)hipGraphDestroy(g);
       if (e != hipSuccess) throw NrError(NR_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-      GraphSlot gs; gs.io = io; gs.exec = ex;
+      GraphSlot gs; gs.io = key; gs.exec = ex;
       cache.push_back(gs);
       hit = &cache.back();
     }
@@ -2002,28 +2011,45 @@ extern "C" nr_status nr_net_import_weights(nr_net* h, nr_stream stream, const ch
   std::string line;
   if (!next_line(line) || line.rfind("NRW1 ", 0) != 0) throw NrError(NR_ERR_ARG, "bad manifest header");
   if (std::atoi(line.c_str() + 5) != h->cfg.kind) throw NrError(NR_ERR_ARG, "manifest is for a different network kind");
-  HIP_OK(hipMalloc((void**)&h->import_base, (size_t)arena_bytes));
-  h->import_bytes = (size_t)arena_bytes;
-  HIP_OK(hipMemcpyAsync(h->import_base, src_dev, (size_t)arena_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (arena_bytes <= 0) throw NrError(NR_ERR_ARG, "empty arena");
+  // parse and validate the WHOLE manifest into temporaries first: a bad line must leave the handle fresh (importable again)
+  std::map<std::string, HostTensor> new_host;
+  struct DevRec { std::string name; size_t off, bytes; };
+  std::vector<DevRec> new_dev;
   while (next_line(line)) {
     if (line.size() < 3) continue;
     std::vector<std::string> tok;
     size_t a = 0;
-    while (a < line.size()) { size_t b = line.find(' ', a); if (b == std::string::npos) b = line.size(); tok.push_back(line.substr(a, b - a)); a = b + 1; }
+    while (a < line.size()) { size_t b = line.find(' ', a); if (b == std::string::npos) b = line.size(); if (b > a) tok.push_back(line.substr(a, b - a)); a = b + 1; }
+    if (tok.empty()) continue;
     if (tok[0] == "H" && tok.size() >= 3) {
       HostTensor t;                                   // shape only: the data never exists on this rank
       const int nd = std::atoi(tok[2].c_str());
-      for (int i = 0; i < nd && 3 + i < (int)tok.size(); ++i) t.shape.push_back(std::atoll(tok[3 + i].c_str()));
-      h->host[tok[1]] = std::move(t);
+      if (nd < 0 || nd > 8 || 3 + nd != (int)tok.size()) throw NrError(NR_ERR_ARG, "bad manifest line: " + line);
+      for (int i = 0; i < nd; ++i) {
+        const long long d = std::atoll(tok[3 + i].c_str());
+        if (d < 0) throw NrError(NR_ERR_ARG, "bad manifest line: " + line);
+        t.shape.push_back(d);
+      }
+      new_host[tok[1]] = std::move(t);
     } else if (tok[0] == "D" && tok.size() == 4) {
-      const size_t off = (size_t)std::atoll(tok[2].c_str()), b = (size_t)std::atoll(tok[3].c_str());
-      if (off + b > (size_t)arena_bytes) throw NrError(NR_ERR_ARG, "manifest entry beyond the arena: " + tok[1]);
-      h->dev[tok[1]] = h->import_base + off;
-      h->dev_bytes[tok[1]] = b;
-      h->weight_bytes += b;
+      const long long off = std::atoll(tok[2].c_str()), b = std::atoll(tok[3].c_str());
+      if (off < 0 || b <= 0 || off > arena_bytes || b > arena_bytes - off) throw NrError(NR_ERR_ARG, "manifest entry beyond the arena: " + tok[1]);
+      new_dev.push_back(DevRec{tok[1], (size_t)off, (size_t)b});
     } else throw NrError(NR_ERR_ARG, "bad manifest line: " + line);
   }
-  HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+  char* base = nullptr;
+  HIP_OK(hipMalloc((void**)&base, (size_t)arena_bytes));
+  if (hipMemcpyAsync(base, src_dev, (size_t)arena_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess ||
+      hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+    (void)hipFree(base);
+    throw NrError(NR_ERR_HIP, "copying the weight arena failed");
+  }
+  // commit
+  h->import_base = base;
+  h->import_bytes = (size_t)arena_bytes;
+  h->host = std::move(new_host);
+  for (auto& r : new_dev) { h->dev[r.name] = base + r.off; h->dev_bytes[r.name] = r.bytes; h->weight_bytes += r.bytes; }
   NR_CATCH
 }
 

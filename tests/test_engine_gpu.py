@@ -286,6 +286,18 @@ def test_export_import_weights_gives_bit_identical_forward(cuda):
     assert unet2.weight_bytes() == unet.weight_bytes()
     with pytest.raises(RuntimeError, match="fresh network"):
         unet2.import_weights(*unet.export_weights())
+    # a manifest with a bad record must leave the handle FRESH: the corrected manifest imports afterwards
+    manifest, arena = unet.export_weights()
+    unet3 = NativeUNet3D(unet.config).to("cuda")
+    lines = manifest.split(b"\n")
+    bad_off = b"\n".join(lines[:-3] + [b"D bogus:entry 999999999999 64"] + lines[-3:])
+    bad_syntax = b"\n".join(lines[:5] + [b"X what is this"] + lines[5:])
+    for bad in (bad_off, bad_syntax):
+        with pytest.raises(RuntimeError, match="manifest"):
+            unet3.import_weights(bad, arena)
+    unet3.import_weights(manifest, arena)
+    got3 = unet3.forward_with_controlnet(ctrl2, sample, int(g["t"]), ctx, cond, mask, 1.0).sample
+    assert torch.equal(want, got3)
 
 
 def test_two_stream_schedules_are_bit_reproducible_50x(cuda):
