@@ -63,6 +63,16 @@ __device__ __forceinline__ size_t rowvec_row(const NrGemmParams& p, int m) {
 // ADMA: LDS-DMA issued from inline asm (tiles really stay in flight across the barrier; pays for long K) instead of the builtin
 // (the compiler then drains the DMA in front of the next fragment read: DMA and MFMA of a k-tile do not overlap, but its M0
 // handling is cheaper: measured faster for the short-K Linears of this workload).
+#ifdef NR_STAMP
+// Diagnostic build only (make stamp -> libneurons_amd_stamp.so, tools/igemm_timeline.py): shader-clock stamps of wave 0 of the first
+// 512 workgroups.  The stamps go to a buffer of their own; no output value depends on them.
+#define NR_STAMP_SLOTS 48
+__device__ unsigned long long nr_stamp_buf[512][NR_STAMP_SLOTS];
+#define NR_STAMP_AT(slot) do { if (threadIdx.x == 0 && blockIdx.x < 512 && (slot) < NR_STAMP_SLOTS) nr_stamp_buf[blockIdx.x][(slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NR_STAMP_AT(slot) do { } while (0)
+#endif
+
 template <int BM, int BN, int NS, int WGM, int WGN, bool LNF = false, bool ADMA = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams p, int splitk, float* partial, int m_fast) {
   constexpr int BK = 64;
@@ -77,6 +87,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  NR_STAMP_AT(0);
   const int wm = wave / WGN, wn = wave % WGN;
   const int ntn = (p.N + BN - 1) / BN;
   const int ntm = (p.M + BM - 1) / BM;
@@ -272,10 +283,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
   for (int s0 = 0; s0 < NS - 1; ++s0)
     if (kt_begin + s0 < kt_end) stage(s0);
   int cur = 0;
+  NR_STAMP_AT(1);
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     // tile kt must have landed; the younger (NS-2) tiles may stay outstanding (vmcnt counts in issue order)
     if (kt + (NS - 2) < kt_end) wait_vmcnt<(NS - 2) * G>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();            // everyone's pieces of tile kt landed; everyone left tile kt-1
+    NR_STAMP_AT(4 + (kt - kt_begin));
     const bf16* sA = smem + cur * TILE;
     const bf16* sB = sA + BM * BK;
     // fragment reads of k-step 0 go out FIRST, so their LDS latency is covered by the staging code below
@@ -332,6 +345,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
     }
     cur = cur + 1 == NS ? 0 : cur + 1;
   }
+  NR_STAMP_AT(2);
   // per-row mean / rstd of this wave's MT row tiles (lane: row fr of each tile)
   float ln_mu[MT], ln_rs[MT];
   if constexpr (LNF) {
@@ -453,6 +467,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
       for (int e = 0; e < 4; ++e) { o[e] = (bf16)va[e]; o[4 + e] = (bf16)vb[e]; }
       *(bf16x8*)(p.out + (size_t)m * p.ldo + n) = o;
     }
+#ifdef NR_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    NR_STAMP_AT(3);
     return;
   }
 #pragma unroll
@@ -687,11 +705,16 @@ void apply_override(const NrGemmParams& p, Plan& pl, int& m_fast) {
 
 extern "C" int nr_rowpanel_eligible(const NrGemmParams* pp);
 extern "C" int nr_launch_rowpanel(const NrGemmParams* pp, hipStream_t stream);
+// gemm256.hip: 256-row tiles with role-alternating wave groups for the long-K convs / Linears
+extern "C" int nr_igemm256_plan(const NrGemmParams* pp, int* bn_out, int* splitk_out);
+extern "C" size_t nr_igemm256_workspace_bytes(const NrGemmParams* pp);
+extern "C" int nr_launch_igemm256(const NrGemmParams* pp, float* workspace, int m_fast, int* splitk_used, hipStream_t stream);
 
 // fp32 scratch (bytes) a launch of this shape needs for split-K slabs (0 if none)
 extern "C" size_t nr_igemm_workspace_bytes(const NrGemmParams* pp) {
   if (pp->out_f32 || pp->ln_c) return 0;
   if (nr_rowpanel_eligible(pp)) return 0;
+  if (nr_igemm256_plan(pp, nullptr, nullptr)) return nr_igemm256_workspace_bytes(pp);
   Plan pl = choose_plan(*pp);
   int mf = 0;
   apply_override(*pp, pl, mf);
@@ -705,6 +728,24 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
   const int Cin = p.c0 + p.c1;
   // K = 320 Linears on >= 4096 rows: the register-resident row-panel kernel (rowpanel.hip)
   if (p.K == p.ksize * p.ksize * Cin && nr_rowpanel_eligible(pp)) return nr_launch_rowpanel(pp, stream);
+  {
+    int bn256 = 0, sk256 = 1;
+    if (nr_igemm256_plan(pp, &bn256, &sk256)) {
+      const double w_e = (double)p.N * p.K;
+      const double a_e = (double)p.M * Cin * (p.ksize == 3 ? (p.stride == 2 ? 4.0 : (p.ups ? 0.25 : 1.0)) : 1.0);
+      int mf = w_e > a_e ? 1 : 0;
+      const int ntm_ = (p.M + 255) / 256, ntn_ = (p.N + bn256 - 1) / bn256;
+      if (ntm_ >= 8 && ntn_ >= 4 && w_e >= 3.0e6) mf = 8;
+      int used = 1;
+      const int rc = nr_launch_igemm256(pp, workspace, mf, &used, stream);
+      if (rc) return rc;
+      if (used > 1) {
+        const long long total = (long long)p.M * (p.N / 4);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p, used, (const float*)workspace);
+      }
+      return 0;
+    }
+  }
   if (p.K % 64 != 0 || Cin % 64 != 0 || p.N % 32 != 0) return 1;
   if (p.a1 && (p.c0 % 64 != 0)) return 2;
   if (p.K != p.ksize * p.ksize * Cin) return 3;
@@ -757,3 +798,10 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
   }
   return 0;
 }
+
+#ifdef NR_STAMP
+extern "C" int nr_stamp_read(void* dst, size_t bytes) {
+  const size_t n = bytes < sizeof(nr_stamp_buf) ? bytes : sizeof(nr_stamp_buf);
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(nr_stamp_buf), n, 0, hipMemcpyDeviceToHost);
+}
+#endif
