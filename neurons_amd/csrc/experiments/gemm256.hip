@@ -18,8 +18,9 @@
 //   issued in phase 2t by every wave (group 0 between its MFMAs, group 1 behind its fragment reads) and must have landed by the barrier
 //   in front of phase 2t + 3 (group 0's fragment read): every wave waits for ITS pieces at the end of phase 2t + 2
 //   (vmcnt(pieces issued in that phase)); the slot it overwrites held tile t - 1, last read in phase 2t - 2.
-// STATUS (round 3, profiles/r03_gemm256_ab.txt, r03_gemm256_ablation.txt): bit-compatible with gemm.hip (same sums up to split-K order) but
-// SLOWER, so it is OFF by default (NR_IGEMM256=2 routes every eligible launch here for the A/B).  On the long-K 3x3 convs the 128-row
+// STATUS (round 3, profiles/r03_gemm256_ab.txt, r03_gemm256_ablation.txt): REJECTED, not part of the product library (built only by
+// `make -C neurons_amd/csrc experiments`; NR_IGEMM256=2 routes every eligible launch here for the A/B).  Bit-compatible with gemm.hip
+// (same sums up to split-K order) but SLOWER.  On the long-K 3x3 convs the 128-row
 // kernel runs 950-1,050 TFLOP/s; this one 600-770 (per occupied CU about equal, 1.0-1.17 PFLOP/s-equivalent; with 128-wide tiles the
 // U-Net's grids are 80-384 tiles = 0.6-0.75 of the CUs, and the 160-wide instantiation that would make them 64-256 spills 18-58
 // VGPRs).  The ablation build said why the per-CU rate does not beat two co-resident 128-wide workgroups: with no DMA and no fragment

@@ -63,6 +63,16 @@ __device__ __forceinline__ size_t rowvec_row(const NrGemmParams& p, int m) {
 // ADMA: LDS-DMA issued from inline asm (tiles really stay in flight across the barrier; pays for long K) instead of the builtin
 // (the compiler then drains the DMA in front of the next fragment read: DMA and MFMA of a k-tile do not overlap, but its M0
 // handling is cheaper: measured faster for the short-K Linears of this workload).
+// a / d for 0 <= a < 2^22, d > 0 through the float reciprocal with one correction step (exact in that range).  The tile-index and
+// im2col-row arithmetic of the prologue used ~10 integer (two of them 64-bit) divisions = 2,300-3,100 of the 4,400-4,900 cycles between
+// kernel entry and the first LDS-DMA (in-kernel stamps, profiles/r03_igemm_timeline_smallm.txt): per WORKGROUP, i.e. once per tile.
+__device__ __forceinline__ int fdiv_small(int a, int d) {
+  int q = (int)((float)a * __builtin_amdgcn_rcpf((float)d));
+  const int r = a - q * d;
+  q += (r >= d ? 1 : 0) - (r < 0 ? 1 : 0);
+  return q;
+}
+
 #ifdef NR_STAMP
 // Diagnostic build only (make stamp -> libneurons_amd_stamp.so, tools/igemm_timeline.py): shader-clock stamps of wave 0 of the first
 // 512 workgroups.  The stamps go to a buffer of their own; no output value depends on them.
@@ -74,7 +84,7 @@ __device__ unsigned long long nr_stamp_buf[512][NR_STAMP_SLOTS];
 #endif
 
 template <int BM, int BN, int NS, int WGM, int WGN, bool LNF = false, bool ADMA = false>
-__global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams p, int splitk, float* partial, int m_fast) {
+__global__ __launch_bounds__(64 * WGM * WGN, (LNF && WGM * WGN == 8) ? 4 : 1) void igemm_bf16_kernel(NrGemmParams p, int splitk, float* partial, int m_fast) {
   constexpr int BK = 64;
   constexpr int NW = WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -100,7 +110,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7, local = orig >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
   }
-  const int slice = bid / (ntn * ntm);
+  const int slice = splitk > 1 ? fdiv_small(bid, ntn * ntm) : 0;
   bid -= slice * ntn * ntm;
   // tile order inside an XCD's range: the operand that is re-used by neighbouring tiles should be the BIG
   // one.  m_fast: neighbours share a weight panel (weight-heavy 4x4 / 8x8 levels); else an activation panel.
@@ -110,14 +120,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
     // flight together on an XCD (2 per CU) then form a G x (64 / G) block: both operand panels of the block fit its 4 MiB L2, where
     // a plain n-fastest walk streams the whole weight matrix past the L2 once per m-tile row (W > L2: GEGLU / q|k|v at 16x16, 8x8)
     const int G = m_fast;
-    const int band = bid / (G * ntn);
+    const int band = fdiv_small(bid, G * ntn);
     const int first = band * G;
     const int gsz = min(G, ntm - first);
     const int r = bid - band * G * ntn;
-    bm = first + r % gsz;
-    bn = r / gsz;
-  } else if (m_fast) { bn = bid / ntm; bm = bid - bn * ntm; } else { bm = bid / ntn; bn = bid - bm * ntn; }
+    bn = fdiv_small(r, gsz);
+    bm = first + r - bn * gsz;
+  } else if (m_fast) { bn = fdiv_small(bid, ntm); bm = bid - bn * ntm; } else { bm = fdiv_small(bid, ntn); bn = bid - bm * ntn; }
   const int m0 = bm * BM, n0 = bn * BN;
+  NR_STAMP_AT(40);
   const int lr = lane >> 3;                 // row within the 8-row group
   const int lp = lane & 7;                  // physical 16-B chunk
   const int lchunk = (lp ^ lr) << 3;        // logical chunk (elements) this lane must fetch
@@ -136,9 +147,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
       a_pix[j] = mm; a_oy[j] = 0; a_ox[j] = 0;
     } else {
       const int ohw = p.OH * p.OW;
-      const int n = mm / ohw;
+      const int n = fdiv_small(mm, ohw);
       const int r = mm - n * ohw;
-      a_pix[j] = n; a_oy[j] = r / p.OW; a_ox[j] = r - a_oy[j] * p.OW;
+      a_pix[j] = n; a_oy[j] = fdiv_small(r, p.OW); a_ox[j] = r - a_oy[j] * p.OW;
     }
   }
   const bf16* zsrc = (const bf16*)nr_zero16;
@@ -162,9 +173,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
     }
   }
 
+  NR_STAMP_AT(41);
   const int nk_total = p.K / BK;
-  const int kt_begin = (int)(((long long)nk_total * slice) / splitk);
-  const int kt_end = (int)(((long long)nk_total * (slice + 1)) / splitk);
+  int kt_begin = 0, kt_end = nk_total;
+  if (splitk > 1) { kt_begin = fdiv_small(nk_total * slice, splitk); kt_end = fdiv_small(nk_total * (slice + 1), splitk); }
 
   // ---- running source pointers of the NEXT k-tile to stage.  The k index walks (tap, channel) with the
   // channel fastest, so between two k-tiles every pointer simply advances by 64 elements; the im2col
@@ -178,8 +190,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
   int st_tap, st_c;
   {
     const int kbase = kt_begin * BK;
-    if (tap_inner) { st_tap = kt_begin % 9; st_c = (kt_begin / 9) * BK; }
-    else { st_tap = p.ksize == 3 ? kbase / Cin : 0; st_c = kbase - st_tap * Cin; }
+    if (tap_inner) { const int q9 = fdiv_small(kt_begin, 9); st_tap = kt_begin - 9 * q9; st_c = q9 * BK; }
+    else { st_tap = p.ksize == 3 ? fdiv_small(kbase, Cin) : 0; st_c = kbase - st_tap * Cin; }
 #pragma unroll
     for (int j = 0; j < GB; ++j) {
       const int n = n0 + 8 * (wave * GB + j) + lr;
@@ -225,7 +237,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_bf16_kernel(NrGemmParams
       }
     }
   };
+  NR_STAMP_AT(42);
   setup_rows();
+  NR_STAMP_AT(43);
 
   auto stage = [&](int buf) {
     bf16* sA = smem + buf * TILE;
@@ -705,16 +719,26 @@ void apply_override(const NrGemmParams& p, Plan& pl, int& m_fast) {
 
 extern "C" int nr_rowpanel_eligible(const NrGemmParams* pp);
 extern "C" int nr_launch_rowpanel(const NrGemmParams* pp, hipStream_t stream);
-// gemm256.hip: 256-row tiles with role-alternating wave groups for the long-K convs / Linears
+#ifdef NR_EXPERIMENTS
+// Rejected experiments (csrc/experiments/, built only by `make experiments` into libneurons_amd_exp.so for the A/B tools; never the product):
+// gemm256.hip: 256-row tiles with role-alternating wave groups for the long-K convs / Linears (NR_IGEMM256=2)
 extern "C" int nr_igemm256_plan(const NrGemmParams* pp, int* bn_out, int* splitk_out);
 extern "C" size_t nr_igemm256_workspace_bytes(const NrGemmParams* pp);
 extern "C" int nr_launch_igemm256(const NrGemmParams* pp, float* workspace, int m_fast, int* splitk_used, hipStream_t stream);
+
+// smallm.hip: panel-resident kernel for the small-M Linears (weights straight into registers, no staged k-loop) (NR_SMALLM=1|2)
+extern "C" int nr_smallm_plan(const NrGemmParams* pp, int* ks_out, int* npass_out);
+extern "C" int nr_launch_smallm(const NrGemmParams* pp, hipStream_t stream);
+#endif
 
 // fp32 scratch (bytes) a launch of this shape needs for split-K slabs (0 if none)
 extern "C" size_t nr_igemm_workspace_bytes(const NrGemmParams* pp) {
   if (pp->out_f32 || pp->ln_c) return 0;
   if (nr_rowpanel_eligible(pp)) return 0;
+#ifdef NR_EXPERIMENTS
+  if (pp->K == pp->ksize * pp->ksize * (pp->c0 + pp->c1) && nr_smallm_plan(pp, nullptr, nullptr)) return 0;
   if (nr_igemm256_plan(pp, nullptr, nullptr)) return nr_igemm256_workspace_bytes(pp);
+#endif
   Plan pl = choose_plan(*pp);
   int mf = 0;
   apply_override(*pp, pl, mf);
@@ -728,6 +752,9 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
   const int Cin = p.c0 + p.c1;
   // K = 320 Linears on >= 4096 rows: the register-resident row-panel kernel (rowpanel.hip)
   if (p.K == p.ksize * p.ksize * Cin && nr_rowpanel_eligible(pp)) return nr_launch_rowpanel(pp, stream);
+#ifdef NR_EXPERIMENTS
+  // M <= 512 Linears with K a multiple of 640: the panel-resident kernel (smallm.hip)
+  if (p.K == p.ksize * p.ksize * Cin && !getenv("NR_IGEMM_FORCE") && nr_smallm_plan(pp, nullptr, nullptr)) return nr_launch_smallm(pp, stream);
   {
     int bn256 = 0, sk256 = 1;
     if (nr_igemm256_plan(pp, &bn256, &sk256)) {
@@ -746,6 +773,7 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
       return 0;
     }
   }
+#endif
   if (p.K % 64 != 0 || Cin % 64 != 0 || p.N % 32 != 0) return 1;
   if (p.a1 && (p.c0 % 64 != 0)) return 2;
   if (p.K != p.ksize * p.ksize * Cin) return 3;
@@ -800,8 +828,11 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
 }
 
 #ifdef NR_STAMP
-extern "C" int nr_stamp_read(void* dst, size_t bytes) {
+extern "C" int nr_stamp_read(void* dst, size_t bytes, int clear) {
   const size_t n = bytes < sizeof(nr_stamp_buf) ? bytes : sizeof(nr_stamp_buf);
-  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(nr_stamp_buf), n, 0, hipMemcpyDeviceToHost);
+  int rc = 0;
+  if (dst) rc = (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(nr_stamp_buf), n, 0, hipMemcpyDeviceToHost);
+  if (clear) { void* d = nullptr; (void)hipGetSymbolAddress(&d, HIP_SYMBOL(nr_stamp_buf)); (void)hipMemset(d, 0, sizeof(nr_stamp_buf)); }
+  return rc;
 }
 #endif

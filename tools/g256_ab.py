@@ -6,6 +6,7 @@ import sys
 
 import torch
 
+os.environ.setdefault("NR_LIB_VARIANT", "exp")      # make -C neurons_amd/csrc experiments
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neurons_amd import ops  # noqa: E402
 
