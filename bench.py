@@ -212,7 +212,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # NR_DIST_FORCE=1 under torchrun with ONE rank: the same NCCL (= RCCL) init / broadcast / all-reduce / barrier calls as N > 1
+    # (tests/test_dist_gpu.py runs this on the single-GPU box)
+    use_dist = world > 1 or (os.environ.get("NR_DIST_FORCE") == "1" and "RANK" in os.environ)
+    if use_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
         dist.init_process_group("nccl", device_id=dev)
@@ -247,13 +250,13 @@ def main():
             sd = {k: v.cpu() for k, v in gpu_random_state_dict(state_dict_schema(cfg, kind), seed, dev).items()}
             net.load_state_dict(sd)
             host_sd[kind] = sd
-            if world > 1:
+            if use_dist:
                 # converts the weights for the shape every rank will run: SparseCtrl is evaluated `grp` DDIM steps at a time (pipeline.py)
                 from neurons_amd.pipeline import controlnet_group_size
                 grp0 = controlnet_group_size(args.ddim_steps, 2 * args.batch, F, L, L,
                                              int(os.environ["NR_CTRL_GROUP"]) if os.environ.get("NR_CTRL_GROUP") else "auto")
                 net._ensure_plan(2 * args.batch * (grp0 if kind == _lib.NR_KIND_SPARSECTRL else 1), F, L, L, 77)
-        if world > 1:
+        if use_dist:
             broadcast_native_weights(net, src=0)
     torch.cuda.empty_cache()
 

@@ -308,8 +308,11 @@ struct nr_net {
   const HostTensor& data_of(const std::string& key) const {
     const HostTensor& t = need(key);
     if ((int64_t)t.data.size() != t.numel())
-      throw NrError(NR_ERR_STATE, "host copy of " + key + " was released after the first plan and this shape needs a conversion that plan did not make; "
-                                  "load the state dict again (or keep the host copies: auto_release_host_weights = False)");
+      throw NrError(NR_ERR_STATE, import_base
+                                      ? "this handle was filled by nr_net_import_weights (no fp32 host weights) and the requested shape needs a converted "
+                                        "weight the exporting plan did not make (" + key + "): export from a handle planned for THIS shape, or load a state dict"
+                                      : "host copy of " + key + " was released (nr_net_release_host_weights) and this shape needs a conversion the earlier "
+                                        "plans did not make; load the state dict again, or do not release the host copies");
     return t;
   }
 

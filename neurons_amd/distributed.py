@@ -51,13 +51,24 @@ def broadcast_state_dict(schema: Dict[str, tuple], state_dict, src: int = 0, dev
     return out
 
 
+def _collectives_active() -> bool:
+    """True when the collectives below should run: an initialised process group of more than one rank, or of ONE rank when
+    NR_DIST_FORCE=1 (tests/test_dist_gpu.py: the RCCL code path of a single-GPU box: init, object broadcast, 2.5 GB device
+    broadcast, MAX all-reduce, barrier)."""
+    import os
+    import torch.distributed as dist
+    return dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("NR_DIST_FORCE") == "1")
+
+
 def broadcast_native_weights(net, src: int = 0):
     """rank ``src`` has loaded + planned ``net`` (its converted bf16 weights exist on its GPU); every other rank holds a
     FRESH network of the same config.  The manifest (a few hundred KB of text) goes through ``broadcast_object_list``, the packed
     arena (2.55 GB U-Net / 0.99 GB SparseCtrl) through ONE device-to-device broadcast (RCCL over xGMI); receivers import it without
-    ever holding fp32 host weights or re-running the conversion."""
+    ever holding fp32 host weights or re-running the conversion.  Shape constraint: the arena holds exactly the converted weights of the
+    plan(s) rank ``src`` made before exporting, so ``src`` must have planned the shape every rank will run (bench.py does); a receiver
+    asked for another shape raises NR_ERR_STATE naming the missing conversion (it has no host weights to convert from)."""
     import torch.distributed as dist
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not _collectives_active():
         return net
     rank = dist.get_rank()
     if rank == src:
@@ -78,7 +89,7 @@ def broadcast_native_weights(net, src: int = 0):
 def max_over_ranks(value: float, device=None) -> float:
     """MAX all-reduce of a timing scalar (bench.py's elapsed time)."""
     import torch.distributed as dist
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not _collectives_active():
         return float(value)
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

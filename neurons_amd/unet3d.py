@@ -6,6 +6,7 @@ Same constructor keywords that matter (unet.py:42-90), same ``forward`` signatur
 libneurons_amd.so (C ABI ``nr_unet3d_forward``); there is no torch fallback.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from types import SimpleNamespace
 from typing import Optional, Sequence, Tuple
@@ -401,10 +402,11 @@ class _NativeNet:
         key = (batch, frames, h, w, ctx_len)
         if key != self._plan_key:
             _lib.check(_lib.load().nr_net_plan(self._handle(), batch, frames, h, w, ctx_len))
-            # the fp32 host copies (5 GB for the U-Net) are dropped once converted.  A later plan for a DIFFERENT shape may need
-            # conversions this one did not make (the LayerNorm folding is chosen per GEMM shape): set auto_release_host_weights = False
-            # on a handle that will be driven at several batch sizes, or load the state dict again
-            if getattr(self, "auto_release_host_weights", True):
+            # The fp32 host copies (5 GB for the U-Net) are KEPT by default: which converted weights a plan builds depends on its GEMM
+            # shapes (LayerNorm folding, row-panel / fused-kernel weight streams are chosen per M), so a later plan at another batch
+            # (CFG off, another clip count, the synchronous controlnet(...) call next to the grouped schedule) may need one more.
+            # A caller that drives ONE shape can drop them: auto_release_host_weights = True (or NR_RELEASE_HOST_WEIGHTS=1).
+            if getattr(self, "auto_release_host_weights", os.environ.get("NR_RELEASE_HOST_WEIGHTS") == "1"):
                 _lib.check(_lib.load().nr_net_release_host_weights(self._handle()))
             self._plan_key = key
             self._ctx_key = None         # _on_plan allocates fresh staging buffers: the cached context must be copied again

@@ -1,0 +1,27 @@
+"""The N > 1 launch of bench.py on real RCCL, as far as a single-GPU box can take it: `python -m torch.distributed.run --nproc-per-node 1`
+with NR_DIST_FORCE=1 runs the SAME calls as N > 1 (init_process_group("nccl"), plan + export on rank 0, broadcast_object_list of the
+manifest, ONE device broadcast of each packed bf16 arena, barrier-bracketed timing, MAX all-reduce of the elapsed time) with a world of one.
+The receiving side (import into a fresh network, bit-identical pipeline) is tests/test_fullsize_gpu.py's replay; the rank logic at
+world_size 2 runs on gloo in tests/test_distributed_gloo.py."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_single_rank_through_rccl():
+    env = dict(os.environ, NR_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--ddim-steps", "4",
+           "--no-cpu-baseline", "--no-psnr"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["output_finite"]
+    assert d["scaling"] == "weak"
