@@ -274,10 +274,24 @@ def main():
             ctx=torch.randn(2 * Bc, 77, ucfg.cross_attention_dim, generator=g, device=dev),
             cimg=torch.randn(Bc, 4, 1, L, L, generator=g, device=dev) * 0.18215))
 
+    # NR_BENCH_STEP_EVENTS=1 (diagnostic): one event per DDIM step through the pipeline's callback; the per-step milliseconds of the last
+    # clip go to stderr after the timed region (where inside a clip the time goes: first step, group boundaries, steady state)
+    step_events = [] if os.environ.get("NR_BENCH_STEP_EVENTS") == "1" else None
+
+    def _mark(i, t, lat):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        step_events.append(e)
+
     def run_clip(c):
+        extra = {}
+        if step_events is not None:
+            step_events.clear()
+            _mark(-1, None, None)
+            extra = dict(callback=_mark, callback_steps=1)
         return pipe([""] * Bc if Bc > 1 else "", video_length=F, height=L * 8, width=L * 8, num_inference_steps=args.ddim_steps, guidance_scale=8.5,
                     latents=c["latents"], noise=c["noise"], text_embeddings=c["ctx"], controlnet_images=c["cimg"],
-                    controlnet_image_index=[0], low_strength=0.3, output_type="latent").videos
+                    controlnet_image_index=[0], low_strength=0.3, output_type="latent", **extra).videos
 
     for i in range(args.warmup):
         run_clip(clips[i])
@@ -295,6 +309,10 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t1
     elapsed = max_over_ranks(elapsed, device=dev)
+    if step_events:
+        ms = [step_events[i].elapsed_time(step_events[i + 1]) for i in range(len(step_events) - 1)]
+        print("per-step ms of the last clip (first entry: call start -> end of step 0): " + " ".join(f"{m:.2f}" for m in ms) +
+              f" | sum {sum(ms):.1f} ms, wall per clip {1e3 * elapsed / args.steps:.1f} ms", file=sys.stderr)
     finite = bool(torch.isfinite(out).all().item())
 
     result = None

@@ -73,6 +73,9 @@ __device__ __forceinline__ int fdiv_small(int a, int d) {
   return q;
 }
 
+#ifndef NR_ABLATE
+#define NR_ABLATE 0      // timing ablations of the k-loop (experiments build only, results wrong): 2 no LDS-DMA in the loop, 4 fragment reads in the
+#endif                   // first iteration only, 8 no MFMAs (tools/conv_halo_potential.py)
 #ifdef NR_STAMP
 // Diagnostic build only (make stamp -> libneurons_amd_stamp.so, tools/igemm_timeline.py): shader-clock stamps of wave 0 of the first
 // 512 workgroups.  The stamps go to a buffer of their own; no output value depends on them.
@@ -246,6 +249,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, (LNF && WGM * WGN == 8) ? 4 : 1) vo
     bf16* sB = sA + BM * BK;
     if constexpr (ADMA) {
       const unsigned la = lds_addr(sA + wave * GA * 8 * BK), lb = lds_addr(sB + wave * GB * 8 * BK);
+#ifdef NR_ABLATE_A
+      // timing ablation (wrong results): the activation tile is fetched for one tap in nine only -- what a halo tile held in LDS would
+      // leave of the A traffic of a tap-inner 3x3 conv (tools/conv_halo_potential.py; 2-stage instantiations wait with vmcnt(0), so the
+      // barrier protocol stays valid)
+      if (!tap_inner || st_tap == 0)
+#endif
 #pragma unroll
       for (int j = 0; j < GA; ++j) glds16_asm(ap[j], la + (unsigned)(j * 8 * BK * (int)sizeof(bf16)));
 #pragma unroll
@@ -298,6 +307,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, (LNF && WGM * WGN == 8) ? 4 : 1) vo
     if (kt_begin + s0 < kt_end) stage(s0);
   int cur = 0;
   NR_STAMP_AT(1);
+#if NR_ABLATE & 4
+  bf16x8 wf[2][NT], xf[2][MT];
+#endif
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     // tile kt must have landed; the younger (NS-2) tiles may stay outstanding (vmcnt counts in issue order)
     if (kt + (NS - 2) < kt_end) wait_vmcnt<(NS - 2) * G>(); else wait_vmcnt<0>();
@@ -307,7 +319,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, (LNF && WGM * WGN == 8) ? 4 : 1) vo
     const bf16* sB = sA + BM * BK;
     // fragment reads of k-step 0 go out FIRST, so their LDS latency is covered by the staging code below
     // (pointer bumps + LDS-DMA issue for tile kt+NS-1) instead of sitting exposed in front of the MFMAs
+#if !(NR_ABLATE & 4)
     bf16x8 wf[2][NT], xf[2][MT];
+#else
+    if (kt == kt_begin) {
+#endif
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int row = wn * WN + i * 16 + fr;
@@ -318,13 +334,19 @@ __global__ __launch_bounds__(64 * WGM * WGN, (LNF && WGM * WGN == 8) ? 4 : 1) vo
       const int row = wm * WM + j * 16 + fr;
       xf[0][j] = *(const bf16x8*)(sA + row * BK + ((fg ^ (row & 7)) << 3));
     }
+#if NR_ABLATE & 4
+    }
+#endif
     __builtin_amdgcn_sched_barrier(0);
     {
       const int nxt = kt + NS - 1;           // refill the buffer tile kt-1 occupied
       int nb = cur + NS - 1; if (nb >= NS) nb -= NS;
-      if (nxt < kt_end) stage(nb);
+      if (nxt < kt_end && !(NR_ABLATE & 2)) stage(nb);
     }
     __builtin_amdgcn_sched_barrier(0);
+#if NR_ABLATE & 4
+    if (kt == kt_begin) {
+#endif
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int row = wn * WN + i * 16 + fr;
@@ -335,13 +357,20 @@ __global__ __launch_bounds__(64 * WGM * WGN, (LNF && WGM * WGN == 8) ? 4 : 1) vo
       const int row = wm * WM + j * 16 + fr;
       xf[1][j] = *(const bf16x8*)(sA + row * BK + (((4 + fg) ^ (row & 7)) << 3));
     }
+#if NR_ABLATE & 4
+    }
+#endif
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j)
+#if NR_ABLATE & 8
+          asm volatile("" : : "v"(wf[ks][i]), "v"(xf[ks][j]));
+#else
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], xf[ks][j], acc[i][j], 0, 0, 0);
+#endif
     if constexpr (LNF) {
       const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
 #pragma unroll
