@@ -1727,7 +1727,16 @@ struct nr_net {
   void ensure_streams() {
     if (!own_stream) {
       // (a lowest-priority stream for SparseCtrl, meant to fill only the CUs the U-Net leaves free, measured neutral: 16.56 vs 16.53 frames/s)
-      HIP_OK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+      // NR_STREAM_PRIO=1 (A/B): SparseCtrl on the lowest-priority queue, the U-Net on the highest, so that under the grouped schedule the
+      // pending group only takes the CUs the U-Net's small launches leave free
+      static const bool prio = getenv("NR_STREAM_PRIO") && getenv("NR_STREAM_PRIO")[0] == '1';
+      if (prio) {
+        int lo = 0, hi = 0;
+        HIP_OK(hipDeviceGetStreamPriorityRange(&lo, &hi));     // lo = numerically greatest = lowest priority
+        HIP_OK(hipStreamCreateWithPriority(&own_stream, hipStreamNonBlocking, cfg.kind == NR_KIND_SPARSECTRL ? lo : hi));
+      } else {
+        HIP_OK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+      }
       HIP_OK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
       HIP_OK(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
       HIP_OK(hipEventCreateWithFlags(&ev_adds, hipEventDisableTiming));
