@@ -758,6 +758,10 @@ extern "C" int nr_launch_igemm256(const NrGemmParams* pp, float* workspace, int 
 // smallm.hip: panel-resident kernel for the small-M Linears (weights straight into registers, no staged k-loop) (NR_SMALLM=1|2)
 extern "C" int nr_smallm_plan(const NrGemmParams* pp, int* ks_out, int* npass_out);
 extern "C" int nr_launch_smallm(const NrGemmParams* pp, hipStream_t stream);
+// gemmws.hip: four MFMA waves + one LDS-DMA wave per 128 x 128 tile (NR_IGEMM_WS=1|2)
+extern "C" int nr_igemm_ws_plan(const NrGemmParams* pp, int* splitk_out);
+extern "C" size_t nr_igemm_ws_workspace_bytes(const NrGemmParams* pp);
+extern "C" int nr_launch_igemm_ws(const NrGemmParams* pp, float* workspace, int m_fast, int* splitk_used, hipStream_t stream);
 #endif
 
 // fp32 scratch (bytes) a launch of this shape needs for split-K slabs (0 if none)
@@ -766,6 +770,7 @@ extern "C" size_t nr_igemm_workspace_bytes(const NrGemmParams* pp) {
   if (nr_rowpanel_eligible(pp)) return 0;
 #ifdef NR_EXPERIMENTS
   if (pp->K == pp->ksize * pp->ksize * (pp->c0 + pp->c1) && nr_smallm_plan(pp, nullptr, nullptr)) return 0;
+  if (nr_igemm_ws_plan(pp, nullptr)) return nr_igemm_ws_workspace_bytes(pp);
   if (nr_igemm256_plan(pp, nullptr, nullptr)) return nr_igemm256_workspace_bytes(pp);
 #endif
   Plan pl = choose_plan(*pp);
@@ -784,6 +789,20 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
 #ifdef NR_EXPERIMENTS
   // M <= 512 Linears with K a multiple of 640: the panel-resident kernel (smallm.hip)
   if (p.K == p.ksize * p.ksize * Cin && !getenv("NR_IGEMM_FORCE") && nr_smallm_plan(pp, nullptr, nullptr)) return nr_launch_smallm(pp, stream);
+  if (!getenv("NR_IGEMM_FORCE") && nr_igemm_ws_plan(pp, nullptr)) {
+    const double w_e = (double)p.N * p.K, a_e = (double)p.M * Cin;
+    int mf = w_e > a_e ? 1 : 0;
+    const int ntm_ = (p.M + 127) / 128, ntn_ = (p.N + 127) / 128;
+    if (ntm_ >= 8 && ntn_ >= 4 && w_e >= 3.0e6) mf = 8;
+    int used = 1;
+    const int rc = nr_launch_igemm_ws(pp, workspace, mf, &used, stream);
+    if (rc) return rc;
+    if (used > 1) {
+      const long long total = (long long)p.M * (p.N / 4);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p, used, (const float*)workspace);
+    }
+    return 0;
+  }
   {
     int bn256 = 0, sk256 = 1;
     if (nr_igemm256_plan(pp, &bn256, &sk256)) {
