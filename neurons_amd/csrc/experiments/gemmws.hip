@@ -46,6 +46,15 @@ __device__ __forceinline__ int fdiv_small(int a, int d) {      // exact for 0 <=
   return q;
 }
 
+#ifdef NR_STAMP
+// diagnostic build (make experiments STAMP=1, tools/ws_timeline.py): per workgroup, cycles summed over the k-loop of producer 0 and consumer 0,
+// split at the two barriers: [role][0] waiting at A, [1] issue / fragment reads, [2] waiting at B, [3] landing wait / MFMAs
+__device__ unsigned long long ws_stamp_buf[512][2][4];
+#define WS_T() __builtin_amdgcn_s_memtime()
+#else
+#define WS_T() 0ull
+#endif
+
 // NPROD: LDS-DMA waves per workgroup (a lone wave issues one piece per ~80 cycles; the CU accepts one per ~18 from four); NS: LDS stages
 // NCONS: MFMA waves (4: 64 x 64 outputs each, 8: 64 x 32)
 template <int NCONS, int NPROD, int NS>
@@ -174,15 +183,27 @@ __global__ __launch_bounds__(64 * (NCONS + NPROD)) void igemm_ws_kernel(NrGemmPa
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t) if (t < nk) issue_tile(t);
     if (nk >= NS - 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(VMW2) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_assert(NS >= 3, "the single-barrier protocol refills the stage released one iteration earlier");
     int buf = NS - 1;
+    unsigned long long acc_t[4] = {0, 0, 0, 0};
+    unsigned long long t0 = WS_T();
     for (int kt = 0; kt < nk; ++kt) {
-      __builtin_amdgcn_s_barrier();                     // A(kt): tile kt has landed
+      // X(kt): tile kt has landed (this wave waited for it below) and every consumer has left tile kt - 1 (its fragment reads were
+      // drained before its MFMAs), so the stage of tile kt - 1 is free for tile kt + NS - 1
+      __builtin_amdgcn_s_barrier();
+      const unsigned long long t1 = WS_T();
       const bool more = kt + NS - 1 < nk;
       if (more) issue_tile(buf);
       buf = buf + 1 == NS ? 0 : buf + 1;
-      __builtin_amdgcn_s_barrier();                     // B(kt): the consumers hold tile kt's fragments
+      const unsigned long long t2 = WS_T();
       if (more) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(VMW2) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long t4 = WS_T();
+      acc_t[0] += t1 - t0; acc_t[1] += t2 - t1; acc_t[3] += t4 - t2;
+      t0 = t4;
     }
+#ifdef NR_STAMP
+    if (pq == 0 && lane == 0 && blockIdx.x < 512) for (int i = 0; i < 4; ++i) ws_stamp_buf[blockIdx.x][0][i] = acc_t[i];
+#endif
     return;
   }
 
@@ -204,8 +225,11 @@ __global__ __launch_bounds__(64 * (NCONS + NPROD)) void igemm_ws_kernel(NrGemmPa
     for (int j = 0; j < MT; ++j) { const int row = wm * 64 + j * 16 + fr; offx[ks][j] = row * BK + (((4 * ks + fg) ^ (row & 7)) << 3); }
   }
   int cbuf = 0;
+  unsigned long long acc_t[4] = {0, 0, 0, 0};
+  unsigned long long t0 = WS_T();
   for (int kt = 0; kt < nk; ++kt) {
-    __builtin_amdgcn_s_barrier();                       // A(kt)
+    __builtin_amdgcn_s_barrier();                       // X(kt): tile kt has landed
+    const unsigned long long t1 = WS_T();
     const bf16* st = smem + cbuf * TILE;
     cbuf = cbuf + 1 == NS ? 0 : cbuf + 1;
     bf16x8 wf[2][NT], xf[2][MT];
@@ -217,7 +241,8 @@ __global__ __launch_bounds__(64 * (NCONS + NPROD)) void igemm_ws_kernel(NrGemmPa
       for (int j = 0; j < MT; ++j) xf[ks][j] = *(const bf16x8*)(st + offx[ks][j]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                       // B(kt)
+    const unsigned long long t2 = WS_T();
+    const unsigned long long t3 = t2;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -225,7 +250,16 @@ __global__ __launch_bounds__(64 * (NCONS + NPROD)) void igemm_ws_kernel(NrGemmPa
       for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], xf[ks][j], acc[i][j], 0, 0, 0);
+#ifdef NR_STAMP
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t4 = WS_T();
+    acc_t[0] += t1 - t0; acc_t[1] += t2 - t1; acc_t[2] += t3 - t2; acc_t[3] += t4 - t3;
+    t0 = t4;
+#endif
   }
+#ifdef NR_STAMP
+  if (wave == 0 && lane == 0 && blockIdx.x < 512) for (int i = 0; i < 4; ++i) ws_stamp_buf[blockIdx.x][1][i] = acc_t[i];
+#endif
 
   // ---- epilogue: lane holds out[m = .. + fr][n = .. + 4 fg + r] ----
   if (partial) {
@@ -313,19 +347,21 @@ extern "C" int nr_launch_igemm_ws(const NrGemmParams* pp, float* workspace, int 
   const unsigned grid = (unsigned)(((p.M + 127) / 128) * ((p.N + 127) / 128) * sk);
   float* partial = sk > 1 ? workspace : nullptr;
   const int nprod = getenv("NR_IGEMM_WS_NPROD") ? atoi(getenv("NR_IGEMM_WS_NPROD")) : 2;
-  const int ns = getenv("NR_IGEMM_WS_NS") ? atoi(getenv("NR_IGEMM_WS_NS")) : 2;
+  const int ns = getenv("NR_IGEMM_WS_NS") ? atoi(getenv("NR_IGEMM_WS_NS")) : 3;
   const int ncons = getenv("NR_IGEMM_WS_NCONS") ? atoi(getenv("NR_IGEMM_WS_NCONS")) : 8;
   typedef void (*kern_t)(NrGemmParams, int, float*, int);
   kern_t k = nullptr;
-  int np = 4, nc = 8, nsl = ns < 2 ? 2 : (ns > 4 ? 4 : ns);
+  int np = 4, nc = 8;
+  const int nsl = ns <= 3 ? 3 : 4;
   if (ncons == 4) {
     nc = 4;
-    if (nprod == 1) { np = 1; k = nsl == 2 ? igemm_ws_kernel<4, 1, 2> : (nsl == 3 ? igemm_ws_kernel<4, 1, 3> : igemm_ws_kernel<4, 1, 4>); }
-    else if (nprod == 2) { np = 2; k = nsl == 2 ? igemm_ws_kernel<4, 2, 2> : (nsl == 3 ? igemm_ws_kernel<4, 2, 3> : igemm_ws_kernel<4, 2, 4>); }
-    else k = nsl == 2 ? igemm_ws_kernel<4, 4, 2> : (nsl == 3 ? igemm_ws_kernel<4, 4, 3> : igemm_ws_kernel<4, 4, 4>);
+    if (nprod <= 2) { np = 2; k = nsl == 3 ? igemm_ws_kernel<4, 2, 3> : igemm_ws_kernel<4, 2, 4>; }
+    else if (nprod <= 4) { np = 4; k = nsl == 3 ? igemm_ws_kernel<4, 4, 3> : igemm_ws_kernel<4, 4, 4>; }
+    else { np = 8; k = nsl == 3 ? igemm_ws_kernel<4, 8, 3> : igemm_ws_kernel<4, 8, 4>; }
   } else {
-    if (nprod == 2) { np = 2; k = nsl == 2 ? igemm_ws_kernel<8, 2, 2> : (nsl == 3 ? igemm_ws_kernel<8, 2, 3> : igemm_ws_kernel<8, 2, 4>); }
-    else k = nsl == 2 ? igemm_ws_kernel<8, 4, 2> : (nsl == 3 ? igemm_ws_kernel<8, 4, 3> : igemm_ws_kernel<8, 4, 4>);
+    if (nprod <= 2) { np = 2; k = nsl == 3 ? igemm_ws_kernel<8, 2, 3> : igemm_ws_kernel<8, 2, 4>; }
+    else if (nprod <= 4) { np = 4; k = nsl == 3 ? igemm_ws_kernel<8, 4, 3> : igemm_ws_kernel<8, 4, 4>; }
+    else { np = 8; k = nsl == 3 ? igemm_ws_kernel<8, 8, 3> : igemm_ws_kernel<8, 8, 4>; }
   }
   const size_t shm = (size_t)nsl * (128 + 128) * 64 * 2;
   if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return 2;
@@ -333,3 +369,13 @@ extern "C" int nr_launch_igemm_ws(const NrGemmParams* pp, float* workspace, int 
   if (splitk_used) *splitk_used = sk;
   return 0;
 }
+
+#ifdef NR_STAMP
+extern "C" int nr_ws_stamp_read(void* dst, size_t bytes, int clear) {
+  const size_t n = bytes < sizeof(ws_stamp_buf) ? bytes : sizeof(ws_stamp_buf);
+  int rc = 0;
+  if (dst) rc = (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(ws_stamp_buf), n, 0, hipMemcpyDeviceToHost);
+  if (clear) { void* d = nullptr; (void)hipGetSymbolAddress(&d, HIP_SYMBOL(ws_stamp_buf)); (void)hipMemset(d, 0, sizeof(ws_stamp_buf)); }
+  return rc;
+}
+#endif

@@ -33,7 +33,7 @@ def ab(name, run, out, flops):
     ref = out.float().clone()
     t0 = bench(run)
     line = f"{name:44s} igemm {t0*1e3:7.1f}us {flops/t0/1e9:5.0f}TF |"
-    for (ncons, nprod, ns) in ((4, 4, 2), (8, 2, 2), (8, 4, 2), (8, 4, 3), (8, 4, 4)):
+    for (ncons, nprod, ns) in ((4, 4, 3), (4, 8, 3), (8, 4, 3), (8, 8, 3), (8, 8, 4)):
         os.environ["NR_IGEMM_WS"] = "2"
         os.environ["NR_IGEMM_WS_NCONS"] = str(ncons)
         os.environ["NR_IGEMM_WS_NPROD"] = str(nprod)
