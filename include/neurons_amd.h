@@ -47,6 +47,10 @@ typedef struct nr_net nr_net;
                                  (sgm/models/autoencoder.py:468-488 = diffusers AutoencoderKL.encode)         */
 #define NR_KIND_CLIP_TEXT 5   /* transformers CLIPTextModel as called by _encode_prompt (pipeline_neuroclips.py:153-240) */
 
+/* test hooks: ONE reference module as a network of its own (see nr_leaf_forward below) */
+#define NR_KIND_LEAF_TRANSFORMER3D 6 /* animatediff/models/attention.py:31 Transformer3DModel (one BasicTransformerBlock)          */
+#define NR_KIND_LEAF_TEMPORAL 7      /* animatediff/models/motion_module.py:48 VanillaTemporalModule -> TemporalTransformer3DModel */
+
 #define NR_MAX_LEVELS 4
 
 /* Mirrors the constructor arguments that reach the hot path (unet.py:42-90; SD-1.5 unet/config.json +
@@ -275,6 +279,19 @@ int32_t nr_net_num_taps(const nr_net* h);
 const char* nr_net_tap_name(const nr_net* h, int32_t i);
 /* copies tap i (bf16 channels-last [rows][C]) to host as fp32; rows and C receive the shape */
 nr_status nr_net_read_tap(nr_net* h, int32_t i, float* host_out, int64_t capacity, int32_t* rows, int32_t* C);
+
+/* the launch plan of the current nr_net_plan(): one description string per enqueued op ("igemm ks=1 ... M= N= K=", "tattn_fused M= ...",
+ * "ff_fused M= ...", "groupnorm ...", "" for boundary kernels); tests assert WHICH kernel serves a layer at a given shape */
+int32_t nr_net_num_ops(const nr_net* h);
+const char* nr_net_op_desc(const nr_net* h, int32_t i);
+
+/* Leaf-module handles (kinds NR_KIND_LEAF_TRANSFORMER3D / NR_KIND_LEAF_TEMPORAL): Transformer3DModel.forward (attention.py:95-142) or
+ * VanillaTemporalModule.forward (motion_module.py:79-86 -> TemporalTransformer3DModel.forward :134-158) on the reference's own tensors,
+ * running exactly the launch sequence the engine uses for that module inside the U-Net at this shape.  Config: block_out_channels[0] = C,
+ * num_levels 1, num_heads / cross_attention_dim / norm_num_groups (transformer) or motion_num_heads / motion_num_attention_blocks /
+ * motion_pe_max_len (temporal).  State-dict keys: "m." + the module's own keys.  plan(batch, frames, h, w, ctx_len [0 for temporal]).
+ *   x_dev fp32 [batch][C][F][h][w]; ctx_dev fp32 [batch][ctx_len][cross_attention_dim] (transformer only); out_dev like x_dev. */
+nr_status nr_leaf_forward(nr_net* h, nr_stream stream, const float* x_dev, const float* ctx_dev, int32_t ctx_len, float* out_dev);
 
 /* ---- single-op entry points (used by tests/ to check each kernel against the oracle) --------- */
 nr_status nr_op_gemm(nr_stream stream, const void* a_dev, int32_t lda, const void* w_dev, const float* bias_dev,

@@ -18,6 +18,8 @@ NR_KIND_SGM_UNET = 2
 NR_KIND_VAE_DECODER = 3
 NR_KIND_VAE_ENCODER = 4
 NR_KIND_CLIP_TEXT = 5
+NR_KIND_LEAF_TRANSFORMER3D = 6
+NR_KIND_LEAF_TEMPORAL = 7
 NR_MAX_LEVELS = 4
 
 
@@ -96,6 +98,9 @@ SYMBOLS = {
     "nr_net_num_taps": (_I32, [_VP]),
     "nr_net_tap_name": (C.c_char_p, [_VP, _I32]),
     "nr_net_read_tap": (_I32, [_VP, _I32, _VP, _I64, C.POINTER(_I32), C.POINTER(_I32)]),
+    "nr_net_num_ops": (_I32, [_VP]),
+    "nr_net_op_desc": (C.c_char_p, [_VP, _I32]),
+    "nr_leaf_forward": (_I32, [_VP, _VP, _VP, _VP, _I32, _VP]),
     "nr_op_gemm": (_I32, [_VP, _VP, _I32, _VP, _VP, _VP, _I32, _VP, _I32, _I32, _I32, _I32, _I32]),
     "nr_op_ln_gemm": (_I32, [_VP, _VP, _I32, _VP, _VP, _VP, C.c_float, _VP, _I32, _VP, _I32, _I32, _I32, _I32, _I32, _I32]),
     "nr_op_gemm_ex": (_I32, [_VP, _VP, _I32, _VP, _VP, _VP, C.c_float, _VP, _I32, _I32, _I32, _VP, _I32, _VP, _I32, _I32, _I32, _I32, _I32, _I32,

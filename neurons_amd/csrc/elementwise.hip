@@ -358,6 +358,42 @@ __global__ __launch_bounds__(256) void fold_linear_pair_kernel(const float* __re
 
 }  // namespace
 
+// test-hook layout converts of the leaf-module handles (engine.hip build_leaf): fp32 "b c f h w" <-> bf16 channels-last frame-images
+// [b*F + f][hw][C].  One thread per (image, pixel, channel); sized for fixtures, not for speed.
+static __global__ void ncfhw_to_nhwc_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int C, int F, int HW, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const long long pix = i / C;
+  const int p = (int)(pix % HW);
+  const long long n = pix / HW;
+  const int f = (int)(n % F);
+  const long long b = n / F;
+  dst[i] = (bf16)src[((b * C + c) * F + f) * HW + p];
+}
+static __global__ void nhwc_to_ncfhw_kernel(const bf16* __restrict__ src, float* __restrict__ dst, int C, int F, int HW, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int p = (int)(i % HW);
+  long long r = i / HW;
+  const int f = (int)(r % F);
+  r /= F;
+  const int c = (int)(r % C);
+  const long long b = r / C;
+  dst[i] = (float)src[((b * F + f) * HW + p) * C + c];
+}
+
+extern "C" int nr_launch_ncfhw_to_nhwc(const float* src, bf16* dst, int B, int C, int F, int HW, hipStream_t stream) {
+  const long long total = (long long)B * C * F * HW;
+  hipLaunchKernelGGL(ncfhw_to_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, dst, C, F, HW, total);
+  return 0;
+}
+extern "C" int nr_launch_nhwc_to_ncfhw(const bf16* src, float* dst, int B, int C, int F, int HW, hipStream_t stream) {
+  const long long total = (long long)B * C * F * HW;
+  hipLaunchKernelGGL(nhwc_to_ncfhw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, dst, C, F, HW, total);
+  return 0;
+}
+
 extern "C" int nr_launch_fold_linear_pair(const float* w2, const float* w1, const float* b2, const float* b1, int C, int J, bf16* wc,
                                           float* bc, hipStream_t stream) {
   hipLaunchKernelGGL(fold_linear_pair_kernel, dim3((unsigned)((C + J + 255) / 256), (unsigned)C), dim3(256), 0, stream, w2, w1, b2, b1, C, J,

@@ -58,6 +58,8 @@ int nr_launch_cfg_ddim_step(const float* eps, const float* x, float* x_out, long
 int nr_launch_add_bf16(const bf16* a, const bf16* b, bf16* out, long long n, hipStream_t stream);
 int nr_launch_f32_to_bf16(const float* a, bf16* out, long long n, hipStream_t stream);
 int nr_launch_add_bf16_multi(const NrAddMulti* p, hipStream_t stream);
+int nr_launch_ncfhw_to_nhwc(const float* src, bf16* dst, int B, int C, int F, int HW, hipStream_t stream);
+int nr_launch_nhwc_to_ncfhw(const bf16* src, float* dst, int B, int C, int F, int HW, hipStream_t stream);
 int nr_groupnorm_launches(const NrGnParams* p);
 int nr_launch_fold_linear_pair(const float* w2, const float* w1, const float* b2, const float* b1, int C, int J, bf16* wc, float* bc,
                                hipStream_t stream);
@@ -1452,7 +1454,47 @@ struct nr_net {
     res_shapes.clear();
   }
 
+  // ------------------------------------------------------------------ leaf modules (test hooks)
+  // ONE reference module as a network of its own, so that the reference classes' own outputs (tests/golden/leaf_ops.npz) can be
+  // compared at the row counts where the engine picks its fused kernels:
+  //   NR_KIND_LEAF_TRANSFORMER3D  Transformer3DModel.forward      (attention.py:95-142; state-dict keys "m.<reference key>")
+  //   NR_KIND_LEAF_TEMPORAL       VanillaTemporalModule.forward   (motion_module.py:79-86,134-158; keys "m.temporal_transformer...")
+  // Input / output are the reference's fp32 "b c f h w" tensors; the plan between the two layout converts is exactly the one
+  // spatial_transformer() / temporal_module() emit inside the U-Net.
+  void build_leaf() {
+    const int C = cfg.block_out_channels[0];
+    const int nimg = B2 * F;
+    ctx_persist.clear(); ops.clear(); ctx_ops.clear(); op_meta.clear(); taps.clear(); arena.reset(); parena.reset();
+    ctx_dirty = true;
+    temb_slots.clear(); temb_total = 0; temb_all = nullptr;
+    t_dev = new_scratch<float>(NR_MAX_BATCH);
+    Act x = new_act(nimg, H, W, C);
+    {
+      bf16* xp = x.ptr; const int b2n = B2, Fn = F, hw = H * W;
+      emit([=, this](hipStream_t s) { LAUNCH_OK(nr_launch_ncfhw_to_nhwc(io.sample, xp, b2n, C, Fn, hw, s)); });
+    }
+    Act y;
+    if (cfg.kind == NR_KIND_LEAF_TRANSFORMER3D) {
+      Act ctx_bf = new_act_persistent(1, 1, B2 * ctx_len, cfg.cross_attention_dim);
+      bf16* cp = ctx_bf.ptr; const long long n = (long long)B2 * ctx_len * cfg.cross_attention_dim;
+      building_ctx = true;
+      emit([this, cp, n](hipStream_t s) { LAUNCH_OK(nr_launch_f32_to_bf16(io.ctx, cp, n, s)); });
+      building_ctx = false;
+      ctx_persist.push_back(ctx_bf);
+      y = spatial_transformer(x, ctx_bf, "m");
+    } else {
+      y = temporal_module(x, "m");
+    }
+    {
+      const bf16* yp = y.ptr; const int b2n = B2, Fn = F, hw = H * W;
+      emit([=, this](hipStream_t s) { LAUNCH_OK(nr_launch_nhwc_to_ncfhw(yp, io.out, b2n, C, Fn, hw, s)); });
+    }
+    n_res = 0;
+    res_shapes.clear();
+  }
+
   void build() {
+    if (cfg.kind == NR_KIND_LEAF_TRANSFORMER3D || cfg.kind == NR_KIND_LEAF_TEMPORAL) { build_leaf(); return; }
     if (cfg.kind == NR_KIND_CLIP_TEXT) { build_clip(); return; }
     if (cfg.kind == NR_KIND_VAE_ENCODER) { build_vae_enc(); return; }
     if (cfg.kind == NR_KIND_SGM_UNET) { build_sgm(); return; }
@@ -1691,9 +1733,10 @@ struct nr_net {
   }
 
   void plan(int batch, int frames, int h, int w, int ctxl) {
-    const bool vae = cfg.kind == NR_KIND_VAE_DECODER || cfg.kind == NR_KIND_VAE_ENCODER || cfg.kind == NR_KIND_CLIP_TEXT;
+    const bool leaf = cfg.kind == NR_KIND_LEAF_TRANSFORMER3D || cfg.kind == NR_KIND_LEAF_TEMPORAL;
+    const bool vae = cfg.kind == NR_KIND_VAE_DECODER || cfg.kind == NR_KIND_VAE_ENCODER || cfg.kind == NR_KIND_CLIP_TEXT || cfg.kind == NR_KIND_LEAF_TEMPORAL;
     if (batch <= 0 || batch > NR_MAX_BATCH || frames <= 0 || h <= 0 || w <= 0 || (ctxl <= 0 && !vae)) throw NrError(NR_ERR_ARG, "plan: bad shape");
-    const int down = (cfg.kind == NR_KIND_VAE_DECODER || cfg.kind == NR_KIND_CLIP_TEXT) ? 1 : 1 << (cfg.num_levels - 1);
+    const int down = (cfg.kind == NR_KIND_VAE_DECODER || cfg.kind == NR_KIND_CLIP_TEXT || leaf) ? 1 : 1 << (cfg.num_levels - 1);
     if (h % down != 0 || w % down != 0)
       throw NrError(NR_ERR_ARG, "plan: latent h,w must be multiples of " + std::to_string(down));
     HIP_OK(hipDeviceSynchronize());
@@ -1862,8 +1905,9 @@ extern "C" const char* nr_last_error(void) { return g_err.c_str(); }
 extern "C" nr_status nr_net_create(const nr_net_config* cfg, nr_net** out) {
   NR_TRY
   if (!cfg || !out) throw NrError(NR_ERR_ARG, "null argument");
-  if (cfg->num_levels < 2 || cfg->num_levels > NR_MAX_LEVELS) throw NrError(NR_ERR_ARG, "num_levels must be 2..4");
-  if (cfg->kind < NR_KIND_UNET3D || cfg->kind > NR_KIND_CLIP_TEXT) throw NrError(NR_ERR_ARG, "bad kind");
+  if (cfg->kind < NR_KIND_UNET3D || cfg->kind > NR_KIND_LEAF_TEMPORAL) throw NrError(NR_ERR_ARG, "bad kind");
+  const bool leaf_kind = cfg->kind == NR_KIND_LEAF_TRANSFORMER3D || cfg->kind == NR_KIND_LEAF_TEMPORAL;
+  if (cfg->num_levels < (leaf_kind ? 1 : 2) || cfg->num_levels > NR_MAX_LEVELS) throw NrError(NR_ERR_ARG, "num_levels must be 2..4");
   if (cfg->kind == NR_KIND_CLIP_TEXT) {
     const int C = cfg->block_out_channels[0];
     if (C % 64 != 0 || cfg->num_heads <= 0 || C % cfg->num_heads != 0 || (C / cfg->num_heads) % 8 != 0 || C / cfg->num_heads > 160 ||
@@ -2355,6 +2399,28 @@ extern "C" nr_status nr_sgm_unet_forward(nr_net* h, nr_stream stream, const floa
   h->io = io;
   h->run((hipStream_t)stream, timesteps);
   NR_CATCH
+}
+
+extern "C" nr_status nr_leaf_forward(nr_net* h, nr_stream stream, const float* x_dev, const float* ctx_dev, int32_t ctx_len, float* out_dev) {
+  NR_TRY
+  if (!h || (h->cfg.kind != NR_KIND_LEAF_TRANSFORMER3D && h->cfg.kind != NR_KIND_LEAF_TEMPORAL)) throw NrError(NR_ERR_ARG, "handle is not a leaf module");
+  if (!h->planned) throw NrError(NR_ERR_STATE, "nr_net_plan() has not been called (or weights changed since)");
+  check_device(h);
+  if (!x_dev || !out_dev) throw NrError(NR_ERR_ARG, "null tensor argument");
+  if (h->cfg.kind == NR_KIND_LEAF_TRANSFORMER3D && (!ctx_dev || ctx_len != h->ctx_len)) throw NrError(NR_ERR_ARG, "context missing or ctx_len differs from the planned value");
+  IO io;
+  std::memset(&io, 0, sizeof(io));
+  io.sample = x_dev; io.ctx = ctx_dev; io.out = out_dev; io.in_scale = 1.f; io.scale = 1.f; io.cond_batch = 1;
+  h->io = io;
+  const float zeros[NR_MAX_BATCH] = {0};
+  h->run((hipStream_t)stream, zeros);
+  NR_CATCH
+}
+
+extern "C" int32_t nr_net_num_ops(const nr_net* h) { return h ? (int32_t)h->op_meta.size() : 0; }
+extern "C" const char* nr_net_op_desc(const nr_net* h, int32_t i) {
+  if (!h || i < 0 || i >= (int)h->op_meta.size()) return "";
+  return h->op_meta[i].desc.c_str();
 }
 
 extern "C" nr_status nr_vae_decode(nr_net* h, nr_stream stream, const float* z_dev, float z_scale, float out_mul, float out_add,

@@ -229,3 +229,80 @@ def tattn_fused(t, nbatch, hw, gamma, beta, wq, wk, wv, wo, bo, eps=1e-5, reuse_
     _lib.check(_lib.load().nr_op_tattn_fused(_stream(), _ptr(t), nbatch, hw, None if reuse_stream else _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]),
                                              _ptr(ws[3]), _ptr(gamma.float().contiguous()), _ptr(gb), _ptr(bo.float().contiguous()), float(eps)))
     return t
+
+
+# ---------------------------------------------------------------------------------------------------
+# Leaf-module handles (test hooks): ONE reference module planned as a network of its own, so the reference classes' own
+# outputs (tests/golden/leaf_ops.npz) can be replayed at the row counts where the engine picks its fused kernels.
+# ---------------------------------------------------------------------------------------------------
+class NativeLeaf:
+    """``kind='transformer3d'``: Transformer3DModel.forward (attention.py:95-142); ``kind='temporal'``: VanillaTemporalModule.forward
+    (motion_module.py:79-86,134-158).  ``load_state_dict`` takes the module's own key names; ``forward`` takes / returns the
+    reference's fp32 ``b c f h w`` tensors; ``op_descriptions()`` lists the launch plan (which kernel serves which layer)."""
+
+    def __init__(self, kind, channels=320, heads=8, cross_attention_dim=768, norm_num_groups=32, num_attention_blocks=2, pe_max_len=24):
+        import ctypes as C
+        from .unet3d import _motion_keys, _transformer_keys
+        assert kind in ("transformer3d", "temporal")
+        self.kind = kind
+        c = _lib.NrNetConfig()
+        c.kind = _lib.NR_KIND_LEAF_TRANSFORMER3D if kind == "transformer3d" else _lib.NR_KIND_LEAF_TEMPORAL
+        c.in_channels = c.out_channels = channels
+        c.num_levels = 1
+        c.block_out_channels[0] = channels
+        c.num_heads = heads
+        c.cross_attention_dim = cross_attention_dim
+        c.norm_num_groups = norm_num_groups
+        c.norm_eps = 1e-5
+        c.use_motion_module = 1
+        c.motion_num_heads = heads
+        c.motion_num_attention_blocks = num_attention_blocks
+        c.motion_pe_max_len = pe_max_len
+        self._cconf = c
+        self._schema = _transformer_keys("m", channels, cross_attention_dim) if kind == "transformer3d" else _motion_keys("m", channels, num_attention_blocks)
+        self._h = C.c_void_p()
+        self._plan_key = None
+        _lib.check(_lib.load().nr_net_create(C.byref(c), C.byref(self._h)))
+
+    def load_state_dict(self, sd):
+        import ctypes as C
+        import numpy as np
+        lib = _lib.load()
+        want = {k[2:]: v for k, v in self._schema.items()}
+        missing = [k for k in want if k not in sd]
+        assert not missing, missing
+        for k, shape in want.items():
+            v = sd[k]
+            assert tuple(v.shape) == tuple(shape), (k, tuple(v.shape), shape)
+            a = np.ascontiguousarray(v.detach().to("cpu", torch.float32).numpy())
+            _lib.check(lib.nr_net_load_tensor(self._h, ("m." + k).encode(), a.ctypes.data_as(C.c_void_p), (C.c_int64 * a.ndim)(*a.shape), a.ndim))
+        self._plan_key = None
+
+    def forward(self, x, encoder_hidden_states=None, graph=True):
+        _chk_f32(x, encoder_hidden_states)
+        b, c, f, h, w = x.shape
+        ctx_len = 0 if encoder_hidden_states is None else encoder_hidden_states.shape[1]
+        lib = _lib.load()
+        key = (b, f, h, w, ctx_len)
+        if key != self._plan_key:
+            _lib.check(lib.nr_net_plan(self._h, b, f, h, w, ctx_len))
+            self._plan_key = key
+        _lib.check(lib.nr_net_set_graph(self._h, 1 if graph else 0))
+        _lib.check(lib.nr_net_invalidate_context(self._h))
+        out = torch.empty_like(x)
+        _lib.check(lib.nr_leaf_forward(self._h, _stream(), _ptr(x), _ptr(encoder_hidden_states), ctx_len, _ptr(out)))
+        return out
+
+    __call__ = forward
+
+    def op_descriptions(self):
+        lib = _lib.load()
+        return [lib.nr_net_op_desc(self._h, i).decode() for i in range(lib.nr_net_num_ops(self._h))]
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.load().nr_net_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

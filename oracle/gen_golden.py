@@ -343,6 +343,20 @@ def gen_leaf_ops(out_dir):
     t3 = fill(ref_attention.Transformer3DModel(8, 40, in_channels=320, num_layers=1, cross_attention_dim=768, norm_num_groups=32,
                                                unet_use_cross_frame_attention=False, unet_use_temporal_attention=False), "t3d320", 54)
     out["t3d320.y"] = t3(randn("t3d320.x", (1, 320, 2, 4, 4), 55), encoder_hidden_states=randn("t3d320.ctx", (1, 77, 768), 56)).sample.numpy()
+    # The same two composite modules at the row counts where the engine switches to its fused kernels (tattn.hip / ffpanel.hip need
+    # >= 4096 rows at C = 320): 16 frames x 16x16 = 4096 rows, 2 frames x 48x48 = 4608 rows.  Outputs stored as a deterministic subsample.
+    tmb = fill(ref_mm.VanillaTemporalModule(in_channels=320, num_attention_heads=8, num_transformer_block=1,
+                                            attention_block_types=("Temporal_Self", "Temporal_Self"),
+                                            temporal_position_encoding=True, temporal_position_encoding_max_len=24,
+                                            zero_initialize=False), "tm320big", 61)
+    yb = tmb(randn("tm320big.x", (1, 320, 16, 16, 16), 62), None, None)
+    out["tm320big.idx"], out["tm320big.val"] = _sub(yb, 16384)
+    out["tm320big.shape"] = np.array(yb.shape)
+    t3b = fill(ref_attention.Transformer3DModel(8, 40, in_channels=320, num_layers=1, cross_attention_dim=768, norm_num_groups=32,
+                                                unet_use_cross_frame_attention=False, unet_use_temporal_attention=False), "t3d320big", 63)
+    yb = t3b(randn("t3d320big.x", (1, 320, 2, 48, 48), 64), encoder_hidden_states=randn("t3d320big.ctx", (1, 77, 768), 65)).sample
+    out["t3d320big.idx"], out["t3d320big.val"] = _sub(yb, 16384)
+    out["t3d320big.shape"] = np.array(yb.shape)
     up = fill(ref_resnet.Upsample3D(64, use_conv=True, out_channels=64), "up64", 57)
     out["up64.y"] = up(randn("up64.x", (1, 64, 2, 3, 5), 58)).numpy()
     dn = fill(ref_resnet.Downsample3D(64, use_conv=True, out_channels=64, padding=1, name="op"), "dn64", 59)

@@ -145,6 +145,17 @@ def test_composite_modules_match_reference():
     sd = {f"t.{k}": v for k, v in _fill(shp, "t3d320", 54).items()}
     y = O.transformer3d(sd, "t", randn("t3d320.x", (1, 320, 2, 4, 4), 55), randn("t3d320.ctx", (1, 77, 768), 56), 8, 32)
     _close("t3d320", y, g["t3d320.y"])
+    # the same modules at the row counts where the engine runs its fused kernels (4096 / 4608 rows); the GPU twin is tests/test_leaf_gpu.py
+    shp = {k[len("m."):]: v for k, v in _motion_keys("m", 320, 2).items()}
+    sd = {f"m.{k}": v for k, v in _fill(shp, "tm320big", 61).items()}
+    y = O.temporal_transformer3d(sd, "m", randn("tm320big.x", (1, 320, 16, 16, 16), 62), 8, 32, 2, 24)
+    assert tuple(y.shape) == tuple(g["tm320big.shape"])
+    _close("tm320big", y.reshape(-1)[torch.from_numpy(g["tm320big.idx"])], g["tm320big.val"])
+    shp = {k[len("t."):]: v for k, v in _transformer_keys("t", 320, 768).items()}
+    sd = {f"t.{k}": v for k, v in _fill(shp, "t3d320big", 63).items()}
+    y = O.transformer3d(sd, "t", randn("t3d320big.x", (1, 320, 2, 48, 48), 64), randn("t3d320big.ctx", (1, 77, 768), 65), 8, 32)
+    assert tuple(y.shape) == tuple(g["t3d320big.shape"])
+    _close("t3d320big", y.reshape(-1)[torch.from_numpy(g["t3d320big.idx"])], g["t3d320big.val"])
 
 
 @torch.no_grad()
