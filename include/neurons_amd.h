@@ -259,6 +259,13 @@ nr_status nr_unet3d_forward_after(nr_net* unet, nr_net* ctrl, int32_t slot, nr_s
  * operands (fp32 softmax statistics and accumulation).  Off by default (bf16); changing it invalidates the plan. */
 nr_status nr_net_set_attention_fp8(nr_net* h, int32_t enable);
 
+/* Batch-independent arithmetic (default off; NR_DETERMINISTIC_BATCH=1 turns it on for new handles): every plan choice that can move a bf16
+ * rounding point or an fp32 summation order -- LayerNorm folded into the GEMM vs the separate kernel, split-K depth, row-panel / fused-kernel
+ * eligibility, GroupNorm variant and chunking, the per-workgroup weight-stream rotation of the fused kernels -- is made for the rows of ONE
+ * clip's CFG pair instead of the rows of the whole call.  A clip then gets the same result alone, in a batch of 8 (BASELINE config 4) or in
+ * any SparseCtrl group size; the price is the speed of the shapes that would have taken another plan.  Changing it invalidates the plan. */
+nr_status nr_net_set_deterministic_batch(nr_net* h, int32_t enable);
+
 /* ---- converted-weight exchange between handles (multi-GPU start-up) -----------------
  * The reference shards clips over processes and every process loads the checkpoints itself (scripts/neuroclips_video.py:
  * 94-138,238).  Here rank 0 loads + converts once (nr_net_load_tensor, nr_net_plan) and the converted bf16/fp32 device

@@ -95,6 +95,9 @@ struct NrGemmParams {
   int act;             // 0 none; 1 quick_gelu x*sigmoid(1.702x) (CLIP MLP), applied after bias/scale, before the residual
   int pad_tl0;         // 3x3 only: 1 = no top/left padding (bottom/right zero) — the VAE Downsample's F.pad (0,1,0,1)
   float* out_f32;      // non-null: write the raw fp32 accumulators to out_f32[M][N] and skip the epilogue (attention scores)
+  int plan_m;          // > 0: every choice that can change the arithmetic of a row (tile -> split-K depth, row-panel eligibility) is made as if the
+                       // launch had plan_m rows (the rows of ONE clip's CFG pair), so a clip's result does not depend on its neighbours in the
+                       // batch (NR_DETERMINISTIC_BATCH / nr_net_set_deterministic_batch); 0: use M
   int tap_inner;       // 3x3, stride 1, single source: K walks (64-channel chunk, tap) with the TAP fastest; weights [N][Cin/64][9][64].
                        // The 9 re-reads of an activation row segment then fall into 9 consecutive k-tiles (L2 hits) instead of being
                        // spread over the whole K loop (tap-major order: the working set of the tiles in flight exceeds the 4 MiB L2)
@@ -136,6 +139,7 @@ struct NrGnParams {
   const bf16* x0; const bf16* x1;   // sources: channels [0,c0) from x0, [c0,c0+c1) from x1
   int c0, c1, ld0, ld1;             // pixel strides in elements
   int nimg, hw;                     // images, pixels per image
+  int plan_nimg;                    // > 0: kernel variant / slab width / chunking chosen as for plan_nimg images (batch-independent results); 0: nimg
   int groups;
   int pix_per_blk, nchunk;          // pixel chunking: nchunk = ceil(hw / pix_per_blk)
   float* partial;                   // [nimg][nchunk][groups][2], then (large images) [nimg][groups][2] mean/rstd

@@ -68,13 +68,13 @@ size_t nr_tattn_stream_bytes(void);
 int nr_tattn_fused_eligible(int C, int heads, int frames, int hw, long long rows);
 int nr_launch_tattn_stream_pack(const bf16* wq, const bf16* wk, const bf16* wv, const bf16* wo, bf16* stream, hipStream_t s);
 int nr_launch_tattn_fused(bf16* t, int nbatch, int hw, const bf16* stream, const float* gamma, const float* gb, const float* bo, float ln_eps,
-                          hipStream_t s);
+                          int norot, hipStream_t s);
 // ffpanel.hip: fused FeedForward(GEGLU) + proj_out of the C = 320 level
 size_t nr_ff_stream_bytes(int C);
 int nr_ff_fused_eligible(int C, long long M);
 int nr_launch_ff_stream_pack(const bf16* w1, const bf16* wc, bf16* stream, hipStream_t s);
 int nr_launch_ff_fused(const bf16* t, int ldt, const bf16* x, int ldx, bf16* out, int ldo, int M, const bf16* stream, const float* gamma,
-                       const float* beta, const float* b1, const float* bc, float ln_eps, hipStream_t s);
+                       const float* beta, const float* b1, const float* bc, float ln_eps, int norot, hipStream_t s);
 }
 
 namespace {
@@ -249,6 +249,14 @@ struct nr_net {
   std::vector<OpMeta> op_meta;   // parallel to ops: kernel class + algorithmic work (for roofline reporting)
   std::vector<Tap> taps;
   bool keep_all = false;
+  // nr_net_set_deterministic_batch / NR_DETERMINISTIC_BATCH=1: every plan choice that can move a rounding point or a summation order (LayerNorm
+  // folded vs separate, split-K depth, row-panel / fused-kernel eligibility, GroupNorm variant and chunking, the weight-stream rotation of
+  // the fused kernels) is made for the rows of ONE clip's CFG pair, so a clip's result does not depend on how many clips share the call
+  bool det_batch = false;
+  long long det_rows(long long rows) const {       // rows of this op that belong to one clip's CFG pair (rows itself when not in that mode)
+    if (!det_batch || B2 <= 2) return rows;
+    return rows / B2 * 2;
+  }
   bool attn_fp8 = false;         // nr_net_set_attention_fp8: spatial / cross attention on e4m3 MFMA operands (config 5)
   IO io;
   int n_res = 0;
@@ -326,6 +334,16 @@ struct nr_net {
     dev_bytes[name] = bytes;
     weight_bytes += bytes;
     return d;
+  }
+  // frees a converted buffer that only fed another conversion (the packed weight streams of the fused kernels): it then neither stays
+  // resident nor travels in the exported arena
+  void drop(const std::string& name) {
+    auto it = dev.find(name);
+    if (it == dev.end()) return;
+    if (!in_import(it->second)) (void)hipFree(it->second);
+    auto ib = dev_bytes.find(name);
+    if (ib != dev_bytes.end()) { weight_bytes -= ib->second; dev_bytes.erase(ib); }
+    dev.erase(it);
   }
   template <class Fn>
   void* cached(const std::string& name, Fn make) {
@@ -456,7 +474,7 @@ struct nr_net {
   // concatenated operand [t | g]: Wc = [Wpo | Wpo Wff2] ([C][5C] bf16), bc = bpo + Wpo bff2.  The C x C x 4C product runs on the device
   // in fp32 (fold_linear_pair_kernel), once per plan of new weights.
   struct FoldW { const bf16* w; const float* b; };
-  FoldW w_fold_ff_proj(const std::string& ff2, const std::string& po, int C) {
+  FoldW w_fold_ff_proj(const std::string& ff2, const std::string& po, int C, bool need_w = true) {
     const int J = 4 * C;
     check_shape(ff2 + ".weight", need(ff2 + ".weight"), {C, J});
     check_shape(ff2 + ".bias", need(ff2 + ".bias"), {C});
@@ -467,7 +485,9 @@ struct nr_net {
     const std::string nw = "foldw:" + po + ".weight|" + po + ".bias|" + ff2 + ".weight|" + ff2 + ".bias";
     const std::string nb = "foldb:" + po + ".weight|" + po + ".bias|" + ff2 + ".weight|" + ff2 + ".bias";
     auto it = dev.find(nw);
-    if (it != dev.end()) { r.w = (const bf16*)it->second; r.b = (const float*)dev.at(nb); return r; }
+    auto itb = dev.find(nb);
+    if (itb != dev.end() && (it != dev.end() || !need_w)) { r.w = it != dev.end() ? (const bf16*)it->second : nullptr; r.b = (const float*)itb->second; return r; }
+    if (itb != dev.end()) drop(nb);                                  // bias kept, matrix dropped after a stream pack: rebuild both
     const HostTensor& W2 = data_of(po + ".weight");
     const HostTensor& B2 = data_of(po + ".bias");
     const HostTensor& W1 = data_of(ff2 + ".weight");
@@ -662,6 +682,7 @@ struct nr_net {
     p.bias = o.bias; p.rowvec = o.rowvec; p.rowvec_div = o.rowvec_div; p.rowvec_ld = o.rowvec_ld; p.rowvec_mod = o.rowvec_mod;
     p.out_scale = o.scale; p.geglu = o.geglu; p.pad_tl0 = o.pad_tl0; p.act = o.act; p.ln_c = o.ln_c; p.ln_eps = 1e-5f;
     p.tap_inner = o.tap_inner;
+    p.plan_m = det_batch ? (int)det_rows(p.M) : 0;
     const int outC = o.geglu ? Cout / 2 : Cout;
     Act out = o.out ? *o.out : new_act(x0.nimg, OH, OW, outC);
     if (out.C != outC || out.rows() != p.M) throw NrError(NR_ERR_STATE, "conv: output shape mismatch");
@@ -697,7 +718,10 @@ struct nr_net {
     p.nimg = x0.nimg; p.hw = x0.H * x0.W; p.groups = cfg.norm_num_groups;
     p.gamma = w_f32(prefix + ".weight", C); p.beta = w_f32(prefix + ".bias", C);
     p.eps = eps; p.silu = silu;
-    const int nfl = nr_gn_workspace_floats(p.nimg, p.hw, p.groups, nullptr, nullptr);
+    p.plan_nimg = det_batch ? (int)det_rows(p.nimg) : 0;
+    int nch = 0;
+    (void)nr_gn_workspace_floats(p.plan_nimg > 0 ? p.plan_nimg : p.nimg, p.hw, p.groups, nullptr, &nch);   // chunking as the launcher will choose it
+    const int nfl = p.nimg * (nch * p.groups * 2 + p.groups * 2);
     auto ws = new_tmp((size_t)nfl * sizeof(float));
     p.partial = at<float>(ws->off);
     Act out = new_act(x0.nimg, x0.H, x0.W, C);
@@ -845,7 +869,7 @@ struct nr_net {
     // Every n-tile block of the fused GEMM recomputes the row statistics (~1-2 us per block round), so the fusion pays
     // when the LayerNorm launch it removes costs more than that: small M (latency-bound LN) or narrow N.  Measured on
     // BASELINE config 2 (profiles/README.md): wide GEMMs at the 32x32 / 16x16 levels are faster with the separate LN.
-    const long long M = x.rows();
+    const long long M = det_rows(x.rows());
     bool fuse = !((M >= 8192 && N >= 4 * K) || (M >= 32768 && N >= 3 * K));
     // K = 320 on >= 4096 rows runs on the row-panel kernel (rowpanel.hip): the row statistics come from the register panel once
     // per workgroup, so the folded LayerNorm is free there
@@ -900,32 +924,40 @@ struct nr_net {
       GemmOpt op; op.bias = w_f32(pre + ".proj_out.bias", C); op.res = &x;
       return linear(t, w_linear(pre + ".proj_out.weight", C, C), C, op);
     }
-    if (nr_ff_fused_eligible(C, t.rows()) && t.ld == C && x.ld == C) {
+    if (nr_ff_fused_eligible(C, det_rows(t.rows())) && t.ld == C && x.ld == C) {
       // C = 320, >= 4096 rows: LayerNorm + GEGLU projection + the folded GEMM in ONE launch (ffpanel.hip); the 4C-wide hidden activation
       // stays in registers; LayerNorm is applied to the register panel.  The weights travel as one pre-arranged stage stream.
-      const bf16* w1 = w_geglu(ff + ".net.0.proj.weight", inner, C);
+      check_shape(ff + ".net.0.proj.weight", need(ff + ".net.0.proj.weight"), {2 * inner, C});
       const float* b1 = b_geglu(ff + ".net.0.proj.bias", inner);
       const float* gamma = w_f32(ln + ".weight", C);
       const float* beta = w_f32(ln + ".bias", C);
-      const FoldW fw = w_fold_ff_proj(ff + ".net.2", pre + ".proj_out", C);
       const std::string sname = "ffs:" + ff + ".net.0.proj.weight|" + ff + ".net.2.weight|" + ff + ".net.2.bias|" + pre + ".proj_out.weight|" + pre +
                                 ".proj_out.bias";
       const bf16* stream = (const bf16*)cached(sname, [&]() {
         void* d = nullptr;
         const size_t nb = nr_ff_stream_bytes(C);
+        // the two matrices the stream is packed from are only its inputs: the fused launch never reads them, so they are freed again
+        // (they neither stay resident nor travel in the exported arena); the folded bias stays
+        const bool had_w1 = dev.count("geglu:" + ff + ".net.0.proj.weight") != 0;
+        const bf16* w1 = w_geglu(ff + ".net.0.proj.weight", inner, C);
+        const FoldW fwm = w_fold_ff_proj(ff + ".net.2", pre + ".proj_out", C, true);
         HIP_OK(hipMalloc(&d, nb));
-        LAUNCH_OK(nr_launch_ff_stream_pack(w1, fw.w, (bf16*)d, nullptr));
+        LAUNCH_OK(nr_launch_ff_stream_pack(w1, fwm.w, (bf16*)d, nullptr));
         HIP_OK(hipDeviceSynchronize());
         dev[sname] = d; dev_bytes[sname] = nb; weight_bytes += nb;
+        if (!had_w1) drop("geglu:" + ff + ".net.0.proj.weight");
+        drop("foldw:" + pre + ".proj_out.weight|" + pre + ".proj_out.bias|" + ff + ".net.2.weight|" + ff + ".net.2.bias");
         return d;
       });
+      const FoldW fw = w_fold_ff_proj(ff + ".net.2", pre + ".proj_out", C, false);
       Act out = new_act(x.nimg, x.H, x.W, C);
       const bf16* tp = t.ptr; const bf16* xp = x.ptr; bf16* op = out.ptr;
       const int M = (int)t.rows();
       const float* bc = fw.b;
       char d[160];
       snprintf(d, sizeof(d), "ff_fused M=%d C=%d (LN + GEGLU 8C + folded net.2|proj_out 5C)", M, C);
-      emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_ff_fused(tp, C, xp, C, op, C, M, stream, gamma, beta, b1, bc, 1e-5f, s)); }, NR_PROF_IGEMM,
+      const int norot = det_batch ? 1 : 0;
+      emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_ff_fused(tp, C, xp, C, op, C, M, stream, gamma, beta, b1, bc, 1e-5f, norot, s)); }, NR_PROF_IGEMM,
            2.0 * M * (double)C * (8.0 * C + 5.0 * C), 2.0 * (3.0 * M * (double)C + 13.0 * C * (double)C), d);
       op_tap("ff_fused", out);
       return out;
@@ -991,22 +1023,24 @@ struct nr_net {
     const std::string b = pre + ".transformer_blocks.0";
     for (int k = 0; k < cfg.motion_num_attention_blocks; ++k) {
       const std::string ab = b + ".attention_blocks." + std::to_string(k);
-      if (nr_tattn_fused_eligible(C, heads, F, x.H * x.W, t.rows()) && t.ld == C) {
+      if (nr_tattn_fused_eligible(C, heads, F, x.H * x.W, det_rows(t.rows())) && t.ld == C) {
         // C = 320, F = 16: the whole block (LayerNorm + PE, q|k|v, 16 x 16 attention per pixel and head, to_out + residual) in ONE launch
         // that updates t in place (tattn.hip); q|k|v and the attention output never reach HBM
         const std::string nrm = b + ".norms." + std::to_string(k);
-        const bf16* wq = w_linear(ab + ".to_q.weight", C, C);
-        const bf16* wk = w_linear(ab + ".to_k.weight", C, C);
-        const bf16* wv = w_linear(ab + ".to_v.weight", C, C);
-        const bf16* wo = w_linear(ab + ".to_out.0.weight", C, C);
+        for (const char* wn : {".to_q.weight", ".to_k.weight", ".to_v.weight", ".to_out.0.weight"}) check_shape(ab + wn, need(ab + wn), {C, C});
         const std::string sname = "tas:" + ab + ".to_q.weight|" + ab + ".to_k.weight|" + ab + ".to_v.weight|" + ab + ".to_out.0.weight";
         const bf16* stream = (const bf16*)cached(sname, [&]() {
           void* d = nullptr;
           const size_t nb = nr_tattn_stream_bytes();
+          // the four Linear matrices are only the inputs of the packed stream: freed again once it exists (unless another plan made them)
+          bool had[4]; const bf16* wm[4];
+          const char* wn[4] = {".to_q.weight", ".to_k.weight", ".to_v.weight", ".to_out.0.weight"};
+          for (int i = 0; i < 4; ++i) { had[i] = dev.count("lin:" + ab + wn[i]) != 0; wm[i] = w_linear(ab + wn[i], C, C); }
           HIP_OK(hipMalloc(&d, nb));
-          LAUNCH_OK(nr_launch_tattn_stream_pack(wq, wk, wv, wo, (bf16*)d, nullptr));
+          LAUNCH_OK(nr_launch_tattn_stream_pack(wm[0], wm[1], wm[2], wm[3], (bf16*)d, nullptr));
           HIP_OK(hipDeviceSynchronize());
           dev[sname] = d; dev_bytes[sname] = nb; weight_bytes += nb;
+          for (int i = 0; i < 4; ++i) if (!had[i]) drop("lin:" + ab + wn[i]);
           return d;
         });
         // gb[f][c] = LayerNorm bias + sinusoidal positional encoding of frame f (motion_module.py:225-243)
@@ -1030,7 +1064,8 @@ struct nr_net {
         const double M = (double)t.rows();
         char d[160];
         snprintf(d, sizeof(d), "tattn_fused M=%d C=%d F=%d (LN+PE, q|k|v, attention, to_out + residual)", (int)t.rows(), C, F);
-        emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_tattn_fused(tp, nb2, hw, stream, gamma, gb, bo, 1e-5f, s)); }, NR_PROF_IGEMM,
+        const int norot = det_batch ? 1 : 0;
+        emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_tattn_fused(tp, nb2, hw, stream, gamma, gb, bo, 1e-5f, norot, s)); }, NR_PROF_IGEMM,
              2.0 * M * C * 4.0 * C + 4.0 * (M / F) * heads * (double)F * F * (C / heads), 2.0 * (2.0 * M * C + 4.0 * C * (double)C), d);
         op_tap("tattn_fused", t);
         continue;
@@ -1237,6 +1272,7 @@ struct nr_net {
     std::memset(&p, 0, sizeof(p));
     p.a0 = a; p.c0 = K; p.lda0 = lda; p.H = p.W = p.OH = p.OW = 1; p.ksize = 1; p.stride = 1;
     p.w = w; p.M = M; p.N = N; p.K = K; p.bias = bias; p.out = out; p.ldo = ldo; p.out_scale = 1.f; p.out_f32 = out32;
+    p.plan_m = det_batch ? (int)det_rows(M) : 0;
     const size_t wsb = nr_igemm_workspace_bytes(&p);
     float* ws = nullptr;
     std::shared_ptr<Buf> wsbuf;
@@ -1645,6 +1681,7 @@ struct nr_net {
         p.ksize = 1; p.stride = 1; p.w = w_linear(key + ".weight", src.C, src.C);
         p.M = (int)src.rows(); p.N = src.C; p.K = src.C; p.bias = w_f32(key + ".bias", src.C);
         p.ldo = src.C; p.out_scale = 1.f;
+        p.plan_m = det_batch ? (int)det_rows(p.M) : 0;
         const size_t wsb = nr_igemm_workspace_bytes(&p);
         float* ws = nullptr;
         std::shared_ptr<Buf> wsbuf;
@@ -1918,6 +1955,7 @@ extern "C" nr_status nr_net_create(const nr_net_config* cfg, nr_net** out) {
     nr_net* h = new nr_net();
     h->cfg = *cfg;
     h->device = dev;
+    h->det_batch = getenv("NR_DETERMINISTIC_BATCH") && getenv("NR_DETERMINISTIC_BATCH")[0] == '1';
     *out = h;
     return NR_OK;
   }
@@ -1941,6 +1979,7 @@ extern "C" nr_status nr_net_create(const nr_net_config* cfg, nr_net** out) {
   nr_net* h = new nr_net();
   h->cfg = *cfg;
   h->device = dev;
+  h->det_batch = getenv("NR_DETERMINISTIC_BATCH") && getenv("NR_DETERMINISTIC_BATCH")[0] == '1';
   *out = h;
   NR_CATCH
 }
@@ -2129,6 +2168,13 @@ extern "C" nr_status nr_net_set_graph(nr_net* h, int32_t enable) {
   NR_TRY
   if (!h) throw NrError(NR_ERR_ARG, "null handle");
   h->use_graph = enable != 0;
+  NR_CATCH
+}
+
+extern "C" nr_status nr_net_set_deterministic_batch(nr_net* h, int32_t enable) {
+  NR_TRY
+  if (!h) throw NrError(NR_ERR_ARG, "null handle");
+  if (h->det_batch != (enable != 0)) { h->det_batch = enable != 0; h->planned = false; }
   NR_CATCH
 }
 
@@ -2682,7 +2728,7 @@ extern "C" nr_status nr_op_ff_fused(nr_stream stream, const void* t_dev, const v
   // w1 == NULL: reuse the stage stream packed by the previous call (timing loops)
   if (w1_geglu_dev) LAUNCH_OK(nr_launch_ff_stream_pack((const bf16*)w1_geglu_dev, (const bf16*)wc_dev, (bf16*)ws, (hipStream_t)stream));
   LAUNCH_OK(nr_launch_ff_fused((const bf16*)t_dev, C, (const bf16*)x_dev, C, (bf16*)out_dev, C, M, (const bf16*)ws, gamma_dev, beta_dev,
-                               b1_geglu_dev, bc_dev, ln_eps, (hipStream_t)stream));
+                               b1_geglu_dev, bc_dev, ln_eps, getenv("NR_DETERMINISTIC_BATCH") && getenv("NR_DETERMINISTIC_BATCH")[0] == '1', (hipStream_t)stream));
   NR_CATCH
 }
 
@@ -2698,6 +2744,7 @@ extern "C" nr_status nr_op_tattn_fused(nr_stream stream, void* t_dev, int32_t nb
   // wq == NULL: reuse the stream packed by the previous call (timing loops)
   if (wq_dev) LAUNCH_OK(nr_launch_tattn_stream_pack((const bf16*)wq_dev, (const bf16*)wk_dev, (const bf16*)wv_dev, (const bf16*)wo_dev, (bf16*)ws,
                                                     (hipStream_t)stream));
-  LAUNCH_OK(nr_launch_tattn_fused((bf16*)t_dev, nbatch, hw, (const bf16*)ws, gamma_dev, gb_dev, bo_dev, ln_eps, (hipStream_t)stream));
+  LAUNCH_OK(nr_launch_tattn_fused((bf16*)t_dev, nbatch, hw, (const bf16*)ws, gamma_dev, gb_dev, bo_dev, ln_eps,
+                                  getenv("NR_DETERMINISTIC_BATCH") && getenv("NR_DETERMINISTIC_BATCH")[0] == '1', (hipStream_t)stream));
   NR_CATCH
 }

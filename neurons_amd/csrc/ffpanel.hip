@@ -5,8 +5,8 @@
 // i.e. BasicTransformerBlock's / TemporalTransformerBlock's last FeedForward with its residual add, followed by the transformer's
 // proj_out with ITS residual add (reference: animatediff/models/attention.py:129-140,297-299; motion_module.py:150-158,219-221;
 // FeedForward / GEGLU motion_module_new.py:441-518), in ONE launch.  Wc = [Wpo | Wpo Wff2] and bc = bpo + Wpo bff2 are the folded
-// net.2 + proj_out of engine.hip (w_fold_ff_proj); W1 carries the LayerNorm fold of w_ln_linear (gamma-scaled rows, value/gate
-// interleave).  Until round 3 this was two launches (GEGLU projection 84 us + K = 5C GEMM 53 us at M = 32768) with the 4C-wide hidden
+// net.2 + proj_out of engine.hip (w_fold_ff_proj); W1 is the plain net.0 weight in the value/gate row interleave of w_geglu (the kernel
+// applies the LayerNorm gamma / beta to its register panel explicitly, it is NOT folded into W1).  Until round 3 this was two launches (GEGLU projection 84 us + K = 5C GEMM 53 us at M = 32768) with the 4C-wide hidden
 // activation written to and re-read from HBM (2 x 84 MB per block); here the hidden activation never leaves the registers.
 //
 // Structure (256-thread workgroup = 4 waves, one per SIMD, 128 rows per workgroup):
@@ -53,6 +53,7 @@ struct NrFFParams {
   const bf16* x; int ldx;        // [M][C] transformer input (outer residual)
   bf16* out; int ldo;            // [M][C]
   int M;
+  int norot;                     // 1: every workgroup walks the weight stream from triple 0 (results independent of the row position: NR_DETERMINISTIC_BATCH)
   const bf16* stream;            // 65 stages x 40 KiB (ff_stream_pack_kernel)
   const float* gamma;            // [C] LayerNorm weight
   const float* beta;             // [C] LayerNorm bias
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(NrFFParams p) {
   // walks them from its own starting triple: the 32 workgroups of an XCD then read 20 different regions of the stream instead of all
   // hammering the same 40 KiB (the same few L2 channels) in lockstep.  blockIdx % 8 labels the XCD (speed only; results depend on blockIdx
   // alone, so they are reproducible run to run). ----
-  const int pair0 = (int)((blockIdx.x >> 3) % FF_PAIRS);
+  const int pair0 = p.norot ? 0 : (int)((blockIdx.x >> 3) % FF_PAIRS);
   const char* wsrc = reinterpret_cast<const char*>(p.stream) + (size_t)wave * (FF_DMA * 1024) + (size_t)lane * 16;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lptr_t)smem) + (unsigned)wave * (FF_DMA * 1024);
   // logical stage s (order of execution) -> stage of the stream
@@ -412,11 +413,11 @@ extern "C" int nr_launch_ff_stream_pack(const bf16* w1, const bf16* wc, bf16* st
 }
 
 extern "C" int nr_launch_ff_fused(const bf16* t, int ldt, const bf16* x, int ldx, bf16* out, int ldo, int M, const bf16* stream,
-                                  const float* gamma, const float* beta, const float* b1, const float* bc, float ln_eps, hipStream_t s) {
+                                  const float* gamma, const float* beta, const float* b1, const float* bc, float ln_eps, int norot, hipStream_t s) {
   if (M <= 0 || ldt % 8 != 0 || ldx % 4 != 0 || ldo % 4 != 0) return 1;
   NrFFParams p;
   p.t = t; p.ldt = ldt; p.x = x; p.ldx = ldx; p.out = out; p.ldo = ldo; p.M = M; p.stream = stream; p.gamma = gamma; p.beta = beta; p.b1 = b1; p.bc = bc;
-  p.ln_eps = ln_eps;
+  p.ln_eps = ln_eps; p.norot = norot;
   static const int dbg = getenv("NR_FUSED_DBG") ? atoi(getenv("NR_FUSED_DBG")) : 0;
   p.dbg = dbg;
   constexpr size_t shm = (size_t)FF_NS * FF_STAGE * sizeof(bf16) + (size_t)8 * FF_C * sizeof(float);

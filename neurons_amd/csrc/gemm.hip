@@ -662,6 +662,13 @@ Plan choose_plan(const NrGemmParams& p) {
   return pl;
 }
 
+// the shape the plan is chosen for: plan_m rows when the caller asks for batch-independent arithmetic (common.h), else the real M
+inline NrGemmParams plan_view(const NrGemmParams& p) {
+  NrGemmParams q = p;
+  if (p.plan_m > 0 && p.plan_m < p.M) q.M = p.plan_m;
+  return q;
+}
+
 // hipFuncSetAttribute is per device: one bit per device ordinal and instantiation
 inline bool attr_needed(unsigned long long& mask) {
   int dev = 0;
@@ -773,7 +780,7 @@ extern "C" size_t nr_igemm_workspace_bytes(const NrGemmParams* pp) {
   if (nr_igemm_ws_plan(pp, nullptr)) return nr_igemm_ws_workspace_bytes(pp);
   if (nr_igemm256_plan(pp, nullptr, nullptr)) return nr_igemm256_workspace_bytes(pp);
 #endif
-  Plan pl = choose_plan(*pp);
+  Plan pl = choose_plan(plan_view(*pp));
   int mf = 0;
   apply_override(*pp, pl, mf);
   return pl.splitk > 1 ? (size_t)pl.splitk * pp->M * pp->N * sizeof(float) : 0;
@@ -827,7 +834,7 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
   if (p.K != p.ksize * p.ksize * Cin) return 3;
   if (p.ksize != 1 && p.ksize != 3) return 4;
   if (p.tap_inner && (p.ksize != 3 || p.stride != 1 || p.ups || p.pad_tl0 || p.a1)) return 5;
-  Plan pl = choose_plan(p);
+  Plan pl = choose_plan(plan_view(p));
   const double w_elems = (double)p.N * p.K;
   const double a_elems = (double)p.M * Cin * (p.ksize == 3 ? (p.stride == 2 ? 4.0 : (p.ups ? 0.25 : 1.0)) : 1.0);
   int m_fast = w_elems > a_elems ? 1 : 0;

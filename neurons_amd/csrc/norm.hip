@@ -475,6 +475,7 @@ extern "C" int nr_groupnorm_launches(const NrGnParams* pp) {
 static int gn_launch_impl(NrGnParams* pp, hipStream_t stream, bool count_only, int* nlaunch) {
   NrGnParams p = *pp;
   const int C = p.c0 + p.c1;
+  const int pn = p.plan_nimg > 0 && p.plan_nimg < p.nimg ? p.plan_nimg : p.nimg;   // images the variant choices are made for (common.h)
   if (C % 8 != 0 || C % p.groups != 0 || p.groups > 64) return 1;
   if (p.x1 && p.c0 % 8 != 0) return 2;
   {
@@ -489,7 +490,7 @@ static int gn_launch_impl(NrGnParams* pp, hipStream_t stream, bool count_only, i
       }
       // widen the slab (better line use) while the chip stays filled and the registers suffice
       while (GS && GS * 2 <= 8 && p.groups % (GS * 2) == 0 && GS * 2 * cg / 8 <= 64 &&
-             (long long)p.nimg * (p.groups / (GS * 2)) >= 256 &&
+             (long long)pn * (p.groups / (GS * 2)) >= 256 &&
              ((long long)p.hw + (512 / (GS * 2 * cg / 8)) - 1) / (512 / (GS * 2 * cg / 8)) <= 32) GS *= 2;
       if (GS && p.hw > 64) {       // hw <= 64: the one-workgroup-per-group kernel below is as fast or faster (measured, tools/gn_ab.sh)
         const int cpp = GS * cg / 8;
@@ -530,7 +531,7 @@ static int gn_launch_impl(NrGnParams* pp, hipStream_t stream, bool count_only, i
       return 0;
     }
   }
-  nr_gn_workspace_floats(p.nimg, p.hw, p.groups, &p.pix_per_blk, &p.nchunk);
+  nr_gn_workspace_floats(pn, p.hw, p.groups, &p.pix_per_blk, &p.nchunk);     // chunking as for pn images (the engine sizes `partial` for it)
   const int CP = C / 8;
   const int PL = CP <= 256 ? 256 / CP : 1;
   const size_t shm_stats = (size_t)2 * PL * C * sizeof(float);

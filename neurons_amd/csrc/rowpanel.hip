@@ -387,7 +387,7 @@ extern "C" int nr_rowpanel_eligible(const NrGemmParams* pp) {
   static const bool off = getenv("NR_ROWPANEL") && getenv("NR_ROWPANEL")[0] == '0';   // A/B switch
   if (off) return 0;
   if (p.ksize != 1 || p.a1 || p.c1 != 0 || p.out_f32) return 0;
-  if (p.K != 320 || p.N % 64 != 0 || p.N > 4096 || p.M < 4096) return 0;
+  if (p.K != 320 || p.N % 64 != 0 || p.N > 4096 || (p.plan_m > 0 && p.plan_m < p.M ? p.plan_m : p.M) < 4096) return 0;
   if (p.act || (p.geglu && p.rowvec)) return 0;
   if (p.ln_c && p.rowvec && p.res) return 0;            // the one epilogue combination that does not fit 256 VGPRs (and never occurs)
   if (p.lda0 % 8 != 0 || p.ldo % 8 != 0 || (p.res && p.ldr % 8 != 0)) return 0;

@@ -53,6 +53,7 @@ constexpr int TA_NS = 3;
 struct NrTAttnParams {
   bf16* t;                 // [B2 * F * hw][C], updated in place
   int hw, nbatch;          // pixels per frame-image, CFG batch
+  int norot;               // 1: every workgroup walks the heads from head 0 (results independent of the row position: NR_DETERMINISTIC_BATCH)
   const bf16* stream;      // 8 heads x (q | k | v | o) stages (tattn_stream_pack_kernel)
   const float* gamma;      // [C] LayerNorm weight
   const float* gb;         // [F][C] LayerNorm bias + positional encoding of the frame
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void tattn_fused_kernel(NrTAttnParams p) {
   // ---- weight stream.  The heads are independent up to the order of the fp32 accumulation of the out tile, so every workgroup walks them
   // from its own starting head: the 32 workgroups of an XCD then read 8 different regions of the stream instead of all hammering the same
   // 32 KiB (the same few L2 channels) in lockstep.  blockIdx % 8 labels the XCD (speed only; results depend on blockIdx alone). ----
-  const int head0 = (int)((blockIdx.x >> 3) & (TA_HEADS - 1));
+  const int head0 = p.norot ? 0 : (int)((blockIdx.x >> 3) & (TA_HEADS - 1));
   const char* wsrc = reinterpret_cast<const char*>(p.stream) + (size_t)lane * 16;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lptr_t)smem);
   // Stage order: q k v o per head.  (Running the o stage one head late, so that its 80 MFMAs cover the shuffle / exp latency chain of the next
@@ -402,10 +403,10 @@ extern "C" int nr_launch_tattn_stream_pack(const bf16* wq, const bf16* wk, const
 }
 
 extern "C" int nr_launch_tattn_fused(bf16* t, int nbatch, int hw, const bf16* stream, const float* gamma, const float* gb, const float* bo,
-                                     float ln_eps, hipStream_t s) {
+                                     float ln_eps, int norot, hipStream_t s) {
   if (nbatch <= 0 || hw <= 0 || hw % 8 != 0) return 1;
   NrTAttnParams p;
-  p.t = t; p.hw = hw; p.nbatch = nbatch; p.stream = stream; p.gamma = gamma; p.gb = gb; p.bo = bo; p.ln_eps = ln_eps;
+  p.t = t; p.hw = hw; p.nbatch = nbatch; p.stream = stream; p.gamma = gamma; p.gb = gb; p.bo = bo; p.ln_eps = ln_eps; p.norot = norot;
   p.scale_log2e = 1.4426950408889634f / sqrtf((float)TA_D);
   static const int dbg = getenv("NR_FUSED_DBG") ? atoi(getenv("NR_FUSED_DBG")) : 0;
   p.dbg = dbg;

@@ -369,22 +369,37 @@ class NativeOpenAIWrapper:
         return iter(())
 
 
-def _closure_objects(fn):
-    """Objects a python callable closes over (closure cells, bound ``self``, functools.partial arguments): used only to RECOGNISE the
-    ``denoiser`` closure utils.unclip_recon builds (utils.py:337-338) around a native engine; anything else takes the generic path."""
-    seen = []
-    for cell in getattr(fn, "__closure__", None) or ():
-        try:
-            seen.append(cell.cell_contents)
-        except ValueError:
-            pass
-    if getattr(fn, "__self__", None) is not None:
-        seen.append(fn.__self__)
-    if hasattr(fn, "func") and hasattr(fn, "args"):            # functools.partial
-        seen.extend(fn.args)
-        seen.extend((fn.keywords or {}).values())
-        seen.extend(_closure_objects(fn.func))
-    return seen
+def _canonical_denoiser(engine):
+    def denoiser(x, sigma, c):
+        return engine.denoiser(engine.model, x, sigma, c)
+    return denoiser
+
+
+def _closure_engine(fn):
+    """The object ``fn`` closes over IF ``fn`` is, instruction for instruction, the one-liner utils.unclip_recon builds (utils.py:337-338)::
+
+        def denoiser(x, sigma, c):
+            return diffusion_engine.denoiser(diffusion_engine.model, x, sigma, c)
+
+    i.e. a plain function of three positional arguments with ONE free variable whose bytecode, attribute names and constants equal the
+    canonical closure's (variable names do not enter the bytecode).  Anything else -- a closure that post-processes the output, passes
+    additional inputs, changes cond or sigma, a bound method, a functools.partial -- returns None and takes the sampler's generic path,
+    which calls it as the reference's loop does."""
+    import types
+    if not isinstance(fn, types.FunctionType) or fn.__defaults__ or fn.__kwdefaults__:
+        return None
+    cells = fn.__closure__ or ()
+    if len(cells) != 1:
+        return None
+    ref = _canonical_denoiser(None).__code__
+    c = fn.__code__
+    if (c.co_code != ref.co_code or c.co_names != ref.co_names or c.co_consts != ref.co_consts or c.co_argcount != 3 or
+            c.co_kwonlyargcount != 0 or c.co_flags != ref.co_flags or len(c.co_freevars) != 1 or c.co_nlocals != ref.co_nlocals):
+        return None
+    try:
+        return cells[0].cell_contents
+    except ValueError:
+        return None
 
 
 class EulerEDMSampler:
@@ -394,7 +409,8 @@ class EulerEDMSampler:
         samples = sampler(denoiser, x, cond=c, uc=uc)        # denoiser(x, sigma, c) -> denoised      (utils.py:337-340)
 
     ``denoiser`` may be
-      * the closure utils.unclip_recon builds around a ``NativeDiffusionEngine`` (recognised by what it closes over), a
+      * the closure utils.unclip_recon builds around a ``NativeDiffusionEngine`` (recognised by its code: exactly
+        ``engine.denoiser(engine.model, x, sigma, c)``, nothing more), ``engine.native_denoiser()`` (the explicit opt-in), a
         ``NativeDiffusionEngine`` / ``NativeOpenAIWrapper`` / ``NativeSGMUNet``: the FUSED path — the network evaluation with ``c_in`` folded
         into its boundary conv, then ONE HIP kernel (nr_edm_cfg_euler_step) for c_out / c_skip, CFG combine, to_d and the Euler update;
       * any other callable ``denoiser(x, sigma, c)``: the generic path, statement for statement the reference's loop (guider.prepare_inputs
@@ -438,10 +454,15 @@ class EulerEDMSampler:
             return denoiser.diffusion_model
         if isinstance(denoiser, NativeDiffusionEngine):
             return denoiser.model.diffusion_model
-        if callable(denoiser):
-            for obj in _closure_objects(denoiser):
-                if isinstance(obj, NativeDiffusionEngine) and (self._engine is None or obj is self._engine) and obj.is_native():
-                    return obj.model.diffusion_model
+        # opt-in tag: NativeDiffusionEngine.native_denoiser() hands out a callable carrying the engine it belongs to
+        tagged = getattr(denoiser, "_nr_native", None)
+        if isinstance(tagged, NativeDiffusionEngine) and tagged.is_native():
+            return tagged.model.diffusion_model
+        # utils.unclip_recon's own closure, recognised by its CODE (not by what it merely references): any variation of it is a
+        # different function and is called through the generic loop
+        obj = _closure_engine(denoiser)
+        if isinstance(obj, NativeDiffusionEngine) and (self._engine is None or obj is self._engine) and obj.is_native():
+            return obj.model.diffusion_model
         return None
 
     def __call__(self, denoiser, x, cond: Dict[str, torch.Tensor], uc: Optional[Dict[str, torch.Tensor]] = None,
@@ -511,6 +532,13 @@ class NativeDiffusionEngine:
         self.use_ema = False
         self.conditioner = None
         self._native_denoiser, self._native_model = self.denoiser, self.model
+
+    def native_denoiser(self):
+        """The explicit opt-in to the sampler's fused HIP path: ``engine.sampler(engine.native_denoiser(), x, cond=c, uc=uc)``.  Called
+        directly it is the reference's closure (utils.py:337-338)."""
+        fn = _canonical_denoiser(self)
+        fn._nr_native = self
+        return fn
 
     def is_native(self):
         """False once a caller has swapped .denoiser / .model for foreign objects: the sampler then takes the generic path."""

@@ -351,6 +351,13 @@ class _NativeNet:
         self._plan_key = None
         return self
 
+    def set_deterministic_batch(self, flag=True):
+        """Batch-independent arithmetic (``nr_net_set_deterministic_batch``): plan choices are made per clip, so a clip's result does not
+        depend on how many clips share the call.  Default off (``NR_DETERMINISTIC_BATCH=1`` turns it on for new handles)."""
+        _lib.check(_lib.load().nr_net_set_deterministic_batch(self._handle(), 1 if flag else 0))
+        self._plan_key = None
+        return self
+
     def state_dict_keys(self):
         return list(self._schema.keys())
 

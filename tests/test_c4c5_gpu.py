@@ -131,3 +131,91 @@ def test_c5_32_frames_64x64_one_evaluation(cuda, nets, fp8):
     rel, psnr = metrics(f"C5 ({tag}): eps of SparseCtrl + U-Net, (2,4,32,64,64), full width", eps, ref)
     gate = FWD_REL_L2_FP8 if fp8 else FWD_REL_L2
     assert rel <= gate and psnr >= 30.0, (rel, psnr)
+
+
+def test_c5_configured_batch_of_four_clips_one_evaluation(cuda, nets):
+    """BASELINE config 5 at its CONFIGURED batch: one evaluation of both full-width networks at (2*4, 4, 32, 64, 64) --
+    1 048 576 level-0 rows, 256 frame-images -- (a) against four independent B = 1 evaluations of the same clips (layout / offset-width /
+    arena-reuse bugs show up exactly here and nowhere smaller), (b) clips 0 and 3 against the fp32 oracle evaluated one clip at a time.
+    Largest element offsets at this shape: 1 048 576 rows x 1280 channels (GEGLU output, K = 5C operand halves) = 1.34e9 < 2^31 elements,
+    2.7e9 BYTES (> 2^31: every kernel forms byte addresses in 64 bits; the row-panel kernel's 32-bit buffer offsets are gated by
+    nr_rowpanel_eligible).  fdiv_small's dividends stay below 2^24 (exact float conversion): 1 048 576 rows, 9 x 5 = 45 k-tiles."""
+    n = nets
+    O, unet, ctrl = n["O"], n["unet"], n["ctrl"]
+    unet.set_attention_fp8(False)
+    ctrl.set_attention_fp8(False)
+    B, F, L = 4, 32, 64
+    g = torch.Generator(device=cuda).manual_seed(5004)
+    x = torch.randn(B, 4, F, L, L, generator=g, device=cuda)
+    ctx_u = torch.randn(B, 77, n["ucfg"].cross_attention_dim, generator=g, device=cuda)
+    ctx_t = torch.randn(B, 77, n["ucfg"].cross_attention_dim, generator=g, device=cuda)
+    cond = torch.zeros(B, 4, F, L, L, device=cuda)
+    cond[:, :, 0] = torch.randn(B, 4, L, L, generator=g, device=cuda) * 0.18215
+    mask = torch.zeros(B, 1, F, L, L, device=cuda)
+    mask[:, :, 0] = 1
+    t = 481
+    xin, ctx = torch.cat([x] * 2), torch.cat([ctx_u, ctx_t])
+    down, mid = ctrl(xin, t, encoder_hidden_states=ctx, controlnet_cond=cond, conditioning_mask=mask, return_dict=False)
+    eps = unet(xin, t, encoder_hidden_states=ctx, down_block_additional_residuals=down, mid_block_additional_residual=mid).sample.clone()
+    mid = mid.float().clone()
+    assert torch.isfinite(eps).all() and tuple(eps.shape) == (2 * B, 4, F, L, L)
+    del down
+    worst_db, worst_rel = 1e9, 0.0
+    for i in range(B):
+        xi, ci = torch.cat([x[i:i + 1]] * 2), torch.cat([ctx_u[i:i + 1], ctx_t[i:i + 1]])
+        d1, m1 = ctrl(xi, t, encoder_hidden_states=ci, controlnet_cond=cond[i:i + 1], conditioning_mask=mask[i:i + 1], return_dict=False)
+        e1 = unet(xi, t, encoder_hidden_states=ci, down_block_additional_residuals=d1, mid_block_additional_residual=m1).sample
+        both = torch.cat([eps[i:i + 1], eps[B + i:B + i + 1]])
+        rel, psnr = metrics(f"C5 B=4: eps of clip {i} in the batch vs the same clip alone", both, e1)
+        worst_db, worst_rel = min(worst_db, psnr), max(worst_rel, rel)
+        relm, _ = metrics(f"C5 B=4: SparseCtrl mid residual of clip {i} in the batch vs alone", torch.cat([mid[i:i + 1], mid[B + i:B + i + 1]]), m1.float())
+        worst_rel = max(worst_rel, relm)
+        if i in (0, B - 1):
+            with torch.no_grad():
+                rd, rm = O.sparse_controlnet_forward(n["csd"], n["oc"], xi, t, ci, cond[i:i + 1], mask[i:i + 1], 1.0)
+                ref = O.unet3d_forward(n["usd"], n["ou"], xi, t, ci, rd, rm)
+            del rd, rm
+            r2, p2 = metrics(f"C5 B=4: eps of clip {i} of the batched evaluation vs the fp32 oracle", both, ref)
+            assert r2 <= FWD_REL_L2 and p2 >= 30.0, (i, r2, p2)
+            del ref
+        del d1, m1, e1
+    assert worst_db >= BATCH_VS_SINGLE_DB and worst_rel <= BATCH_VS_SINGLE_REL, (worst_db, worst_rel)
+
+
+def test_deterministic_batch_mode_makes_a_clip_independent_of_its_neighbours(cuda, nets):
+    """nr_net_set_deterministic_batch (NR_DETERMINISTIC_BATCH=1): the LayerNorm-fold / split-K / fused-kernel / GroupNorm-variant choices are
+    made for the rows of ONE clip, so the C4 comparison 'clip i of a batch of 8 vs clip i alone' -- 40 dB in the default mode, where those
+    choices follow M -- must close to >= 60 dB (every kernel is then row-position independent, so the expectation is
+    bit equality, which the test reports).  Full width, (8,4,16,32,32), SparseCtrl on (grouped), CFG 8.5, 6 DDIM steps."""
+    from neurons_amd import DDIMScheduler, NeuroclipsPipeline
+    n = nets
+    unet, ctrl = n["unet"], n["ctrl"]
+    unet.set_attention_fp8(False)
+    ctrl.set_attention_fp8(False)
+    unet.set_deterministic_batch(True)
+    ctrl.set_deterministic_batch(True)
+    try:
+        sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
+        pipe = NeuroclipsPipeline(vae=None, text_encoder=None, tokenizer=None, unet=unet, scheduler=sched, controlnet=ctrl).to(cuda)
+        B, F, L, steps = 8, 16, 32, 6
+        g = torch.Generator(device=cuda).manual_seed(1001)
+        lat = torch.randn(B, 4, F, L, L, generator=g, device=cuda)
+        noise = torch.randn(B, 4, F, L, L, generator=g, device=cuda)
+        ctx_u = torch.randn(B, 77, n["ucfg"].cross_attention_dim, generator=g, device=cuda)
+        ctx_t = torch.randn(B, 77, n["ucfg"].cross_attention_dim, generator=g, device=cuda)
+        cimg = torch.randn(B, 4, 1, L, L, generator=g, device=cuda) * 0.18215
+        kw = dict(video_length=F, height=L * 8, width=L * 8, num_inference_steps=steps, guidance_scale=8.5, controlnet_image_index=[0],
+                  low_strength=0.3, output_type="latent")
+        both = pipe([""] * B, latents=lat, noise=noise, text_embeddings=torch.cat([ctx_u, ctx_t]), controlnet_images=cimg, **kw).videos.clone()
+        worst, nequal = 1e9, 0
+        for i in (0, 3, 7):
+            one = pipe("", latents=lat[i:i + 1], noise=noise[i:i + 1], text_embeddings=torch.cat([ctx_u[i:i + 1], ctx_t[i:i + 1]]),
+                       controlnet_images=cimg[i:i + 1], **kw).videos
+            nequal += int(torch.equal(both[i:i + 1], one))
+            _, psnr = metrics(f"deterministic-batch mode: clip {i} of a batch of {B} vs the same clip alone ({steps} steps)", both[i:i + 1], one)
+            worst = min(worst, psnr)
+        print(f"[deterministic-batch] bit-identical clips: {nequal} of 3; worst PSNR {worst:.1f} dB")
+        assert worst >= 60.0, worst
+    finally:
+        unet.set_deterministic_batch(False)
+        ctrl.set_deterministic_batch(False)

@@ -239,3 +239,97 @@ def test_controlnet_group_size_rule():
     for n in range(1, 60):
         g = gs(n, 2, 16, 32, 32)
         assert 1 <= g <= min(5, n)
+
+
+def test_sgm_sampler_recognises_only_the_canonical_denoiser_closure():
+    """the fused HIP path of EulerEDMSampler is taken for utils.unclip_recon's EXACT closure (utils.py:337-338), for the
+    explicit opt-in ``engine.native_denoiser()`` and for native objects passed directly; every variation of the closure (post-processing,
+    changed sigma / cond, extra inputs, bound methods, partials, closures that merely reference an engine) is called through the generic
+    loop, i.e. gets the reference's ``sampler(denoiser, ...)`` contract."""
+    import functools
+    from neurons_amd import sgm
+    from tiny_configs import tiny_sgm_config, tiny_vae_config
+
+    def build():                       # the engine must be a closure variable, as `diffusion_engine` is inside utils.unclip_recon
+        diffusion_engine = sgm.NativeDiffusionEngine(tiny_sgm_config(), tiny_vae_config(), num_steps=4)
+
+        def denoiser(x, sigma, c):
+            return diffusion_engine.denoiser(diffusion_engine.model, x, sigma, c)
+
+        def scaled(x, sigma, c):
+            return diffusion_engine.denoiser(diffusion_engine.model, x, sigma, c) * 1.0
+
+        def other_sigma(x, sigma, c):
+            return diffusion_engine.denoiser(diffusion_engine.model, x, sigma * 1, c)
+
+        def extra_inputs(x, sigma, c):
+            return diffusion_engine.denoiser(diffusion_engine.model, x, sigma, c, foo=1)
+
+        def swapped_cond(x, sigma, c):
+            return diffusion_engine.denoiser(diffusion_engine.model, x, sigma, dict(c))
+
+        def default_arg(x, sigma, c=None):
+            return diffusion_engine.denoiser(diffusion_engine.model, x, sigma, c)
+
+        return diffusion_engine, denoiser, [scaled, other_sigma, extra_inputs, swapped_cond, default_arg]
+
+    eng, canonical, variants = build()
+    net = eng.model.diffusion_model
+    rec = eng.sampler._native_network
+    assert rec(canonical) is net
+    assert rec(eng.native_denoiser()) is net
+    assert rec(eng) is net and rec(eng.model) is net and rec(net) is net
+    for v in variants:
+        assert rec(v) is None, v.__name__
+    assert rec(functools.partial(canonical)) is None
+    assert rec(eng.decode_first_stage) is None                 # a bound method of the engine
+    assert rec(lambda x, sigma, c: eng.denoiser(eng.model, x, sigma, c) + 0) is None
+    other = sgm.NativeDiffusionEngine(tiny_sgm_config(), tiny_vae_config(), num_steps=4)
+    assert rec(other.native_denoiser()) is other.model.diffusion_model        # a tagged denoiser names its own engine
+    eng.denoiser = lambda *a: None                               # a swapped-out denoiser is no longer the native one
+    assert rec(canonical) is None
+
+
+def test_shipped_library_contains_no_packed_fp32_valu_ops():
+    """The two-stream corruption of round 2 was bisected to the packed-fp32 code generation of norm.o (profiles/r03_race_*) and
+    is NOT root-caused; the product's protection is the library-wide `-packed-fp32-ops` target feature (csrc/Makefile).  A toolchain or
+    flag change that re-introduces v_pk_{add,mul,fma}_f32 would give no compile-time signal, so disassemble every gfx950 code object of
+    the shipped .so and look.  Needs llvm-objcopy / llvm-objdump of the ROCm image, no GPU."""
+    import shutil
+    import struct
+    import subprocess
+    import tempfile
+    from neurons_amd import _lib
+    llvm = "/opt/rocm/lib/llvm/bin"
+    objcopy, objdump = os.path.join(llvm, "llvm-objcopy"), os.path.join(llvm, "llvm-objdump")
+    if not (os.path.exists(objcopy) and os.path.exists(objdump)):
+        pytest.skip("ROCm llvm tools not present")
+    tmp = tempfile.mkdtemp(prefix="nr_pkchk_")
+    try:
+        fat = os.path.join(tmp, "fat.bin")
+        subprocess.run([objcopy, "--dump-section", f".hip_fatbin={fat}", _lib.LIB_PATH, os.path.join(tmp, "copy.so")], check=True)
+        d = open(fat, "rb").read()
+        magic, pos, objs = b"__CLANG_OFFLOAD_BUNDLE__", 0, 0
+        mfma = packed = 0
+        while True:
+            i = d.find(magic, pos)
+            if i < 0:
+                break
+            nb, o = struct.unpack_from("<Q", d, i + 24)[0], i + 32
+            for _ in range(nb):
+                off, size, tl = struct.unpack_from("<QQQ", d, o)
+                o += 24
+                triple = d[o:o + tl].decode()
+                o += tl
+                if "gfx950" in triple and size:
+                    co = os.path.join(tmp, f"co{objs}.o")
+                    open(co, "wb").write(d[i + off:i + off + size])
+                    objs += 1
+                    asm = subprocess.run([objdump, "-d", "--mcpu=gfx950", co], check=True, capture_output=True, text=True).stdout
+                    mfma += asm.count("v_mfma_")
+                    packed += sum(asm.count(op) for op in ("v_pk_add_f32", "v_pk_mul_f32", "v_pk_fma_f32"))
+            pos = i + 24
+        assert objs >= 8 and mfma > 1000, (objs, mfma)            # the disassembly really is the library's kernels
+        assert packed == 0, f"{packed} packed fp32 VALU instructions in {_lib.LIB_PATH}: was the -packed-fp32-ops flag dropped?"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
