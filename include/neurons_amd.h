@@ -292,6 +292,10 @@ nr_status nr_net_read_tap(nr_net* h, int32_t i, float* host_out, int64_t capacit
 int32_t nr_net_num_ops(const nr_net* h);
 const char* nr_net_op_desc(const nr_net* h, int32_t i);
 
+/* which GEMM kernel serves the big launches (gemm8p.hip, the 256-row ping-pong kernel): 0 never, 1 the shipped heuristic (default; env
+ * NR_G8P), 2 whenever the shape is supported.  Process-wide; plan choices are read at nr_net_plan / launch time.  A/B tools and tests. */
+void nr_g8p_set_mode(int32_t mode);
+
 /* Leaf-module handles (kinds NR_KIND_LEAF_TRANSFORMER3D / NR_KIND_LEAF_TEMPORAL): Transformer3DModel.forward (attention.py:95-142) or
  * VanillaTemporalModule.forward (motion_module.py:79-86 -> TemporalTransformer3DModel.forward :134-158) on the reference's own tensors,
  * running exactly the launch sequence the engine uses for that module inside the U-Net at this shape.  Config: block_out_channels[0] = C,
@@ -304,6 +308,11 @@ nr_status nr_leaf_forward(nr_net* h, nr_stream stream, const float* x_dev, const
 nr_status nr_op_gemm(nr_stream stream, const void* a_dev, int32_t lda, const void* w_dev, const float* bias_dev,
                      const void* res_dev, int32_t ldr, void* out_dev, int32_t ldo, int32_t M, int32_t N, int32_t K,
                      int32_t geglu);
+/* out = [a0 | a1] . w^T (+bias) (+res): the two-source operand of the engine's conv(x, &skip, ...) / folded FeedForward as a 1x1 GEMM;
+ * a0 [M][lda0] supplies channels [0, c0), a1 [M][lda1] channels [c0, c0 + c1); w bf16 [N][c0 + c1] */
+nr_status nr_op_gemm2(nr_stream stream, const void* a0_dev, int32_t c0, int32_t lda0, const void* a1_dev, int32_t c1, int32_t lda1,
+                      const void* w_dev, const float* bias_dev, const void* res_dev, int32_t ldr, void* out_dev, int32_t ldo, int32_t M,
+                      int32_t N);
 /* LayerNorm folded into the GEMM (engine: ln_linear): w_scaled[n][k] = gamma[k] W[n][k] (bf16), ln_c[n] = sum_k w_scaled[n][k],
  * bias_folded[n] = bias[n] + sum_k beta[k] W[n][k]; out = rstd_m (a . w_scaled^T - mean_m ln_c) + bias_folded with the row
  * statistics of `a` accumulated inside the kernel.  act: 0 none, 1 quick_gelu. */

@@ -2599,6 +2599,20 @@ extern "C" nr_status nr_op_gemm(nr_stream stream, const void* a, int32_t lda, co
   NR_CATCH
 }
 
+// two-source operand [a0 | a1] (the skip concat of unet_blocks.py:634,740 as a 1x1 GEMM; the [t | g] operand of the folded FeedForward)
+extern "C" nr_status nr_op_gemm2(nr_stream stream, const void* a0, int32_t c0, int32_t lda0, const void* a1, int32_t c1, int32_t lda1,
+                                 const void* w, const float* bias, const void* res, int32_t ldr, void* out, int32_t ldo, int32_t M, int32_t N) {
+  NR_TRY
+  NrGemmParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.a0 = (const bf16*)a0; p.c0 = c0; p.lda0 = lda0; p.a1 = (const bf16*)a1; p.c1 = a1 ? c1 : 0; p.lda1 = lda1;
+  p.H = p.W = p.OH = p.OW = 1; p.ksize = 1; p.stride = 1;
+  p.w = (const bf16*)w; p.M = M; p.N = N; p.K = p.c0 + p.c1; p.bias = bias; p.res = (const bf16*)res; p.ldr = ldr;
+  p.out = (bf16*)out; p.ldo = ldo; p.out_scale = 1.f; p.rowvec_div = 1;
+  LAUNCH_OK(nr_launch_igemm(&p, op_workspace(p), (hipStream_t)stream));
+  NR_CATCH
+}
+
 extern "C" nr_status nr_op_ln_gemm(nr_stream stream, const void* a, int32_t lda, const void* w_scaled, const float* ln_c,
                                    const float* bias_folded, float eps, const void* res, int32_t ldr, void* out, int32_t ldo,
                                    int32_t M, int32_t N, int32_t K, int32_t geglu, int32_t act) {

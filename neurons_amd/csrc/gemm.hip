@@ -755,6 +755,9 @@ void apply_override(const NrGemmParams& p, Plan& pl, int& m_fast) {
 
 extern "C" int nr_rowpanel_eligible(const NrGemmParams* pp);
 extern "C" int nr_launch_rowpanel(const NrGemmParams* pp, hipStream_t stream);
+// gemm8p.hip: 256-row ping-pong kernel for the big launches (SparseCtrl groups, several clips per call, 32-frame clips, the VAE)
+extern "C" int nr_g8p_plan(const NrGemmParams* pp);
+extern "C" int nr_launch_g8p(const NrGemmParams* pp, int m_fast, hipStream_t stream);
 #ifdef NR_EXPERIMENTS
 // Rejected experiments (csrc/experiments/, built only by `make experiments` into libneurons_amd_exp.so for the A/B tools; never the product):
 // gemm256.hip: 256-row tiles with role-alternating wave groups for the long-K convs / Linears (NR_IGEMM256=2)
@@ -775,6 +778,7 @@ extern "C" int nr_launch_igemm_ws(const NrGemmParams* pp, float* workspace, int 
 extern "C" size_t nr_igemm_workspace_bytes(const NrGemmParams* pp) {
   if (pp->out_f32 || pp->ln_c) return 0;
   if (nr_rowpanel_eligible(pp)) return 0;
+  if (nr_g8p_plan(pp)) return 0;
 #ifdef NR_EXPERIMENTS
   if (pp->K == pp->ksize * pp->ksize * (pp->c0 + pp->c1) && nr_smallm_plan(pp, nullptr, nullptr)) return 0;
   if (nr_igemm_ws_plan(pp, nullptr)) return nr_igemm_ws_workspace_bytes(pp);
@@ -793,6 +797,15 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
   const int Cin = p.c0 + p.c1;
   // K = 320 Linears on >= 4096 rows: the register-resident row-panel kernel (rowpanel.hip)
   if (p.K == p.ksize * p.ksize * Cin && nr_rowpanel_eligible(pp)) return nr_launch_rowpanel(pp, stream);
+  if (const int nt8 = nr_g8p_plan(pp)) {
+    // tile order as below: the bigger operand is the one neighbouring tiles share; 8 x 4 blocks of tiles per XCD for weight-heavy shapes
+    const double w_e = (double)p.N * p.K;
+    const double a_e = (double)p.M * Cin;
+    int mf = w_e > a_e ? 1 : 0;
+    const int ntm_ = (p.M + 255) / 256, ntn_ = (p.N + 64 * nt8 - 1) / (64 * nt8);
+    if (ntm_ >= 8 && ntn_ >= 4 && w_e >= 3.0e6) mf = 8;
+    return nr_launch_g8p(pp, mf, stream);
+  }
 #ifdef NR_EXPERIMENTS
   // M <= 512 Linears with K a multiple of 640: the panel-resident kernel (smallm.hip)
   if (p.K == p.ksize * p.ksize * Cin && !getenv("NR_IGEMM_FORCE") && nr_smallm_plan(pp, nullptr, nullptr)) return nr_launch_smallm(pp, stream);

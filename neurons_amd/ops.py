@@ -42,6 +42,23 @@ def gemm(a, w, bias=None, res=None, geglu=False):
     return out
 
 
+def gemm2(a0, a1, w, bias=None, res=None):
+    """out[M, N] = cat([a0, a1], dim=1) @ w[N, c0 + c1]^T (+bias) (+res) without materialising the concat (engine: two-source igemm)."""
+    _chk_bf16(a0, a1, w, res)
+    _chk_f32(bias)
+    M, c0 = a0.shape
+    c1 = a1.shape[1]
+    N = w.shape[0]
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=a0.device)
+    _lib.check(_lib.load().nr_op_gemm2(_stream(), _ptr(a0), c0, c0, _ptr(a1), c1, c1, _ptr(w), _ptr(bias), _ptr(res), N, _ptr(out), N, M, N))
+    return out
+
+
+def g8p_mode(mode):
+    """0: never use the 256-row ping-pong kernel (gemm8p.hip), 1: shipped heuristic, 2: whenever the shape is supported (tests, A/B)."""
+    _lib.load().nr_g8p_set_mode(int(mode))
+
+
 def ln_gemm(a, w, gamma, beta, bias=None, res=None, eps=1e-5, act=0):
     """out = Linear(LayerNorm(a)) with the LayerNorm folded into the GEMM (engine: ln_linear).  The folding of gamma / beta
     into (w_scaled, ln_c, bias_folded) is done here on the host exactly as engine.hip's w_ln_linear does."""

@@ -4,7 +4,9 @@
 // full-range RANDOM operands, each arm run for >= 1.5 s back to back so that the chip settles on the clock it holds under that load.
 // Per arm: wall TFLOP/s, the in-kernel shader clock (delta s_memtime / delta s_memrealtime x 100 MHz, median over workgroups, stamped once
 // around the loop: MI355X_MICROARCH.md "DVFS give-back" item 6) and cycles per MFMA per SIMD (16 = back-to-back issue).
-//   build: hipcc --offload-arch=gfx950 -O3 -o mfma_clock mfma_clock.hip      run: ./mfma_clock
+//   build: hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form -o mfma_clock mfma_clock.hip      run: ./mfma_clock
+//   (without -amdgpu-mfma-vgpr-form hipcc rotates the 20 accumulators of this loop through AGPRs: ~95 v_accvgpr_* copies per k-tile, 21.6
+//   instead of 16.x cycles per MFMA -- not what gemm.hip compiles to: its hot loops carry no such copies; check with -save-temps)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -39,6 +41,15 @@ __global__ __launch_bounds__(256) void kloop(const bf16x8* __restrict__ in, floa
   __builtin_amdgcn_s_waitcnt(0xC07F);
   for (int kt = 0; kt < ktiles; ++kt) {
     if constexpr (MODE & 1) __builtin_amdgcn_s_barrier();
+    if constexpr (!(MODE & 2)) {             // operands stay in registers but are opaque per k-tile (same code shape as the loop that re-reads them)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(wf[ks][i]));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(xf[ks][j]));
+      }
+    }
     if constexpr (MODE & 2) {
       asm volatile("" ::: "memory");         // the fragment reads are re-issued every k-tile (not hoisted out of the loop)
 #pragma unroll
