@@ -47,7 +47,10 @@ def parse():
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--latent", type=int, default=32, help="latent side (pixels/8)")
-    ap.add_argument("--batch", type=int, default=1, help="clips per pipeline call (BASELINE config 4 runs 8 clips/GPU; headline = 1)")
+    ap.add_argument("--batch", type=int, default=1, help="clips per pipeline call (BASELINE config 4 runs 8 clips/GPU; headline = 1); "
+                                                         "--workload keyframe: keyframes per Euler loop (utils.unclip_recon's num_samples)")
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="skip the end-to-end leg of the headline run (native CLIP _encode_prompt -> loop -> native VAE decode -> .videos, SURVEY 8d)")
     ap.add_argument("--attn-fp8", action="store_true", help="BASELINE config 5: spatial/cross attention on OCP e4m3 MFMA operands (bf16 is the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true", help="skip the reference-fixture PSNR run (profiling passes: keeps tiny-network launches out)")
@@ -55,9 +58,10 @@ def parse():
     ap.add_argument("--no-op-profile", action="store_true",
                     help="skip the per-launch HIP-event pass (rocprofv3 runs: keeps the launch counts of the trace at exactly the timed steps); "
                          "the roofline object is then omitted")
-    ap.add_argument("--workload", choices=["video", "keyframe", "vae"], default="video",
+    ap.add_argument("--workload", choices=["video", "keyframe", "vae", "enhance"], default="video",
                     help="video = BASELINE config 2 (headline); keyframe = config 3: sgm unCLIP U-Net, Euler-EDM + CFG 5.0; "
-                         "vae = the first-stage round trip of one clip (SURVEY 8f rank 1): encode 16 frames + decode 16 frames")
+                         "vae = the first-stage round trip of one clip (SURVEY 8f rank 1): encode 16 frames + decode 16 frames; "
+                         "enhance = one GPU's share of BASELINE config 4: --batch keyframes in one Euler loop, then --batch clips in one call, decoded")
     ap.add_argument("--keyframe-steps", type=int, default=50)
     ap.add_argument("--keyframe-latent", type=int, default=64, help="64 = BASELINE config 3 (512 px); 96 = reference-faithful (768 px, 38 steps)")
     return ap.parse_args()
@@ -142,12 +146,13 @@ def keyframe_main(args):
     if args.no_cpu_baseline:
         del sd
     L = args.keyframe_latent
+    B = args.batch          # keyframes per Euler loop = CFG batch 2B (utils.unclip_recon's num_samples, utils.py:302-303,316-321)
     sampler = EulerEDMSampler(num_steps=args.keyframe_steps, scale=5.0)
     items = []
     for _ in range(args.warmup + args.steps):
-        items.append(dict(z=torch.randn(1, 4, L, L, generator=g, device=dev),
-                          c={"crossattn": torch.randn(1, 256, 1664, generator=g, device=dev), "vector": torch.randn(1, 1024, generator=g, device=dev)},
-                          uc={"crossattn": torch.randn(1, 256, 1664, generator=g, device=dev), "vector": torch.randn(1, 1024, generator=g, device=dev)}))
+        items.append(dict(z=torch.randn(B, 4, L, L, generator=g, device=dev),
+                          c={"crossattn": torch.randn(B, 256, 1664, generator=g, device=dev), "vector": torch.randn(B, 1024, generator=g, device=dev)},
+                          uc={"crossattn": torch.randn(B, 256, 1664, generator=g, device=dev), "vector": torch.randn(B, 1024, generator=g, device=dev)}))
     for it in items[:args.warmup]:
         sampler(net, it["z"], cond=it["c"], uc=it["uc"])
     torch.cuda.synchronize()
@@ -164,9 +169,9 @@ def keyframe_main(args):
         # scaled by the step count only
         from oracle import sgm_oracle as S
         it = items[-1]
-        x2 = torch.cat([it["z"], it["z"]]).cpu()
-        ctx2 = torch.cat([it["uc"]["crossattn"], it["c"]["crossattn"]]).cpu()
-        y2 = torch.cat([it["uc"]["vector"], it["c"]["vector"]]).cpu()
+        x2 = torch.cat([it["z"][:1], it["z"][:1]]).cpu()
+        ctx2 = torch.cat([it["uc"]["crossattn"][:1], it["c"]["crossattn"][:1]]).cpu()
+        y2 = torch.cat([it["uc"]["vector"][:1], it["c"]["vector"][:1]]).cpu()
         ts = torch.full((2,), 500.0)
         with torch.no_grad():
             t0 = time.perf_counter()
@@ -177,15 +182,16 @@ def keyframe_main(args):
                          f"x {args.keyframe_steps} steps"}
         del sd
     res = {
-        "metric": "unCLIP keyframes/sec (sgm UNetModel, Euler-EDM, CFG 5.0)", "value": round(args.steps / el, 4), "unit": "keyframes/s",
+        "metric": "unCLIP keyframes/sec (sgm UNetModel, Euler-EDM, CFG 5.0)", "value": round(args.steps * B / el, 4), "unit": "keyframes/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"BASELINE config 3: (1,4,{L},{L}) latent, {args.keyframe_steps} Euler steps, context 256x1664, "
-                               f"2 501 M-parameter UNetModel, random-init weights",
-                   "ms_per_euler_step": round(1e3 * el / args.steps / args.keyframe_steps, 3), "output_finite": bool(torch.isfinite(out).all())},
+        "config": {"workload": f"BASELINE config 3: {B} keyframe(s) per Euler loop, ({B},4,{L},{L}) latent (CFG batch {2 * B}), {args.keyframe_steps} Euler steps, "
+                               f"context 256x1664, 2 501 M-parameter UNetModel, random-init weights",
+                   "keyframes_per_call": B, "ms_per_euler_step": round(1e3 * el / args.steps / args.keyframe_steps, 3),
+                   "ms_per_keyframe_step": round(1e3 * el / args.steps / args.keyframe_steps / B, 3), "output_finite": bool(torch.isfinite(out).all())},
         "roofline": {"bound": "mfma", "kernel": "igemm_bf16_kernel", "achieved": round(ig["flops"] / (ig["ms"] * 1e-3) / 1e12, 2),
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ig["flops"] / (ig["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-                     "traffic": None, "per_class_ms_per_step": {k: round(v["ms"], 3) for k, v in p.items()},
+                     "traffic": keyframe_traffic(B, L), "per_class_ms_per_step": {k: round(v["ms"], 3) for k, v in p.items()},
                      "launches_per_step": int(sum(v["launches"] for v in p.values())),
                      "algorithmic_gbytes_per_step": round(sum(v["bytes"] for v in p.values()) / 1e9, 2),
                      "algorithmic_tflop_per_step": round(sum(v["flops"] for v in p.values()) / 1e12, 3)}}
@@ -196,6 +202,164 @@ def keyframe_main(args):
 
 from neurons_amd.synth import gpu_random_state_dict  # noqa: E402
 
+class _BenchTokenizer:
+    """Stand-in for the CLIP BPE tokenizer (no vocabulary files offline): fixed-length ids, BOS / EOS framing, one hashed id per word.
+    Tokenisation is host string work outside the measured path; what the pipeline needs is the call surface (pipeline_neuroclips.py:156-166)."""
+    model_max_length = 77
+
+    def __call__(self, text, padding=None, max_length=None, truncation=None, return_tensors=None):
+        import types
+        import zlib
+        texts = [text] if isinstance(text, str) else list(text)
+        L = self.model_max_length
+        ids = torch.full((len(texts), L), 49407, dtype=torch.long)
+        for i, t in enumerate(texts):
+            words = [1000 + zlib.crc32(w.encode()) % 40000 for w in t.split()][:L - 2]
+            ids[i, 0] = 49406
+            if words:
+                ids[i, 1:1 + len(words)] = torch.tensor(words)
+        return types.SimpleNamespace(input_ids=ids, attention_mask=torch.ones_like(ids))
+
+    def batch_decode(self, ids):
+        return ["" for _ in ids]
+
+
+def build_text_and_vae(dev):
+    """native CLIP text encoder (f3) and first-stage decoder (f1) at SD-1.5 size with seeded random weights"""
+    from neurons_amd.clip import CLIPTextConfig, NativeCLIPTextModel, clip_state_dict_schema
+    from neurons_amd.vae import NativeVAEDecoder, VAEDecoderConfig, vae_decoder_state_dict_schema
+    tcfg, vcfg = CLIPTextConfig(), VAEDecoderConfig()
+    te, vae = NativeCLIPTextModel(tcfg).to(dev), NativeVAEDecoder(vcfg).to(dev)
+    te.load_state_dict({k: v.cpu() for k, v in gpu_random_state_dict(clip_state_dict_schema(tcfg), 7, dev).items()})
+    vae.load_state_dict({k: v.cpu() for k, v in gpu_random_state_dict(vae_decoder_state_dict_schema(vcfg), 8, dev).items()})
+    return te, vae
+
+
+def end_to_end_leg(args, dev, unet, ctrl, sched, clips):
+    """SURVEY 8d "also report end-to-end (__call__) time separately": the reference call includes _encode_prompt (pipeline_neuroclips.py:373-375)
+    and decode_latents (:492, :242-255) around the denoising loop.  Same clips, same networks, all three stages native: CLIP text encoder ->
+    50-step loop -> VAE decode -> .videos (a CPU fp32 tensor, as the reference returns it: the D2H copy of the pixels is inside)."""
+    from neurons_amd import NeuroclipsPipeline
+    F, L, Bc = args.frames, args.latent, args.batch
+    te, vae = build_text_and_vae(dev)
+    pipe = NeuroclipsPipeline(vae=vae, text_encoder=te, tokenizer=_BenchTokenizer(), unet=unet, scheduler=sched, controlnet=ctrl).to(dev)
+    prompt = "a man rides a bicycle along the beach at sunset while seagulls circle above the waves"
+
+    def run(c):
+        return pipe([prompt] * Bc if Bc > 1 else prompt, video_length=F, height=L * 8, width=L * 8, num_inference_steps=args.ddim_steps,
+                    guidance_scale=8.5, negative_prompt=None, latents=c["latents"], noise=c["noise"], controlnet_images=c["cimg"],
+                    controlnet_image_index=[0], low_strength=0.3, output_type="tensor").videos
+
+    run(clips[0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for c in clips[args.warmup:]:
+        vid = run(c)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / max(1, len(clips) - args.warmup)
+    # stage shares (device time, events on the current stream)
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    e[0].record()
+    pipe._encode_prompt(prompt, dev, 1, True, None)
+    e[1].record()
+    lat = clips[-1]["latents"]
+    e[2].record()
+    pipe.decode_latents(lat)
+    e[3].record()
+    torch.cuda.synchronize()
+    return {"frames_per_s": round(Bc * F / el, 4), "ms_per_clip": round(1e3 * el, 2),
+            "stages_ms": {"clip_text_encode_2x77_tokens": round(e[0].elapsed_time(e[1]), 3),
+                          "vae_decode_incl_d2h_copy": round(e[2].elapsed_time(e[3]), 3)},
+            "videos_shape": list(vid.shape), "videos_finite": bool(torch.isfinite(vid).all()),
+            "what": "NeuroclipsPipeline.__call__(prompt, ..., output_type='tensor'): native CLIP _encode_prompt -> SparseCtrl + U-Net loop -> native VAE decode "
+                    "-> .videos on the host (pipeline_neuroclips.py:321-501); random-init SD-1.5-size CLIP / VAE"}
+
+
+def keyframe_traffic(B, L):
+    """HBM bytes per Euler step of the keyframe path from the committed rocprofv3 --pmc passes (a profiler measurement of the same
+    command, not a live counter read), or null when no pass of this batch / latent size is committed."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_keyframe_b{B}_l{L}_traffic_pmc.json")), reverse=True):
+        d = json.load(open(f))
+        return {"hbm_gbytes_per_euler_step": round(d["whole_step_hbm_bytes"] / 1e9, 2),
+                "igemm_hbm_gbytes_per_euler_step": round(d["igemm_hbm_bytes_per_ddim_step"] / 1e9, 2), "source": os.path.basename(f),
+                "measured_in_this_run": False}
+    return None
+
+
+def enhance_main(args):
+    """One GPU's share of BASELINE config 4 ("8 clips per GPU, 'enhance' inference mode end to end"), all stages native and resident on ONE
+    GPU: B keyframes in ONE Euler loop (recon_keyframe_neurons_enhance.py:458-462 loops one image at a time; utils.unclip_recon's
+    num_samples makes it a batch) + their first-stage decode, then the B clips in ONE pipeline call (CLIP -> loop -> VAE decode -> .videos).
+    Wall times per stage; `value` = clips per second of the whole chain."""
+    import numpy as np
+    from neurons_amd import _lib, DDIMScheduler, NativeSparseCtrl, NativeUNet3D, NeuroclipsPipeline
+    from neurons_amd.sgm import EulerEDMSampler, NativeSGMUNet, SGMUNetConfig, sgm_state_dict_schema
+    from neurons_amd.sparsectrl import controlnet_config_from_unet
+    from neurons_amd.unet3d import UNet3DConfig, state_dict_schema
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    B = args.batch if args.batch > 1 else 8
+    F, L, KL = args.frames, args.latent, args.keyframe_latent
+    t_setup = time.time()
+    scfg = SGMUNetConfig()
+    knet = NativeSGMUNet(scfg).to(dev)
+    knet.load_state_dict({k: v.cpu() for k, v in gpu_random_state_dict(sgm_state_dict_schema(scfg), 3, dev).items()})
+    ucfg = UNet3DConfig()
+    ccfg = controlnet_config_from_unet(ucfg, dict(
+        set_noisy_sample_input_to_zero=True, use_simplified_condition_embedding=True, conditioning_channels=4,
+        motion_module_kwargs=dict(attention_block_types=["Temporal_Self"], temporal_position_encoding_max_len=32)))
+    unet, ctrl = NativeUNet3D(ucfg).to(dev), NativeSparseCtrl(ccfg).to(dev)
+    unet.load_state_dict({k: v.cpu() for k, v in gpu_random_state_dict(state_dict_schema(ucfg, _lib.NR_KIND_UNET3D), 1, dev).items()})
+    ctrl.load_state_dict({k: v.cpu() for k, v in gpu_random_state_dict(state_dict_schema(ccfg, _lib.NR_KIND_SPARSECTRL), 2, dev).items()})
+    te, vae = build_text_and_vae(dev)
+    torch.cuda.empty_cache()
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
+    pipe = NeuroclipsPipeline(vae=vae, text_encoder=te, tokenizer=_BenchTokenizer(), unet=unet, scheduler=sched, controlnet=ctrl).to(dev)
+    sampler = EulerEDMSampler(num_steps=args.keyframe_steps, scale=5.0)
+    g = torch.Generator(device=dev).manual_seed(11)
+    prompt = "a man rides a bicycle along the beach at sunset while seagulls circle above the waves"
+
+    def chain():
+        ts = [time.perf_counter()]
+        z = torch.randn(B, 4, KL, KL, generator=g, device=dev)
+        c = {"crossattn": torch.randn(B, 256, 1664, generator=g, device=dev), "vector": torch.randn(B, 1024, generator=g, device=dev)}
+        uc = {"crossattn": torch.randn(B, 256, 1664, generator=g, device=dev), "vector": torch.randn(B, 1024, generator=g, device=dev)}
+        kz = sampler(knet, z, cond=c, uc=uc)
+        torch.cuda.synchronize(); ts.append(time.perf_counter())
+        kimg = vae.decode_keyframe(kz)                                   # utils.py:343-348
+        torch.cuda.synchronize(); ts.append(time.perf_counter())
+        # the keyframe enters the video stage as its latent (scripts/neuroclips_video_enhance.py:268,283 encode it; here the sampled latent is used directly)
+        cimg = (kz[:, :, :L, :L] if KL >= L else torch.nn.functional.interpolate(kz, size=(L, L))).unsqueeze(2).contiguous() * 0.18215
+        vid = pipe([prompt] * B, video_length=F, height=L * 8, width=L * 8, num_inference_steps=args.ddim_steps, guidance_scale=8.5,
+                   latents=torch.randn(B, 4, F, L, L, generator=g, device=dev), noise=torch.randn(B, 4, F, L, L, generator=g, device=dev),
+                   controlnet_images=cimg, controlnet_image_index=[0], low_strength=0.3, output_type="tensor").videos
+        torch.cuda.synchronize(); ts.append(time.perf_counter())
+        return ts, kimg, vid
+
+    setup_s = time.time() - t_setup
+    for _ in range(args.warmup):
+        chain()
+    tot, stages = 0.0, np.zeros(3)
+    for _ in range(args.steps):
+        ts, kimg, vid = chain()
+        tot += ts[-1] - ts[0]
+        stages += np.diff(ts)
+    tot /= args.steps
+    stages /= args.steps
+    print(json.dumps({
+        "metric": "'enhance' chain clips/sec on one GPU (keyframes + video, BASELINE config 4 share)", "value": round(B / tot, 4), "unit": "clips/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * tot, 1), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"BASELINE config 4, one GPU's share: {B} keyframes ({KL}x{KL} latent, {args.keyframe_steps} Euler steps, CFG 5.0) in one loop + decode, "
+                               f"then {B} clips ({F} f, {L}x{L} latent, {args.ddim_steps} DDIM steps, CFG 8.5, SparseCtrl) in one call incl. CLIP and VAE decode",
+                   "stage_s": {"keyframes_euler_loop": round(float(stages[0]), 3), "keyframes_vae_decode": round(float(stages[1]), 3),
+                               "video_call_clip_loop_vae": round(float(stages[2]), 3)},
+                   "video_frames_per_s_incl_keyframes": round(B * F / tot, 2), "setup_s": round(setup_s, 1),
+                   "output_finite": bool(torch.isfinite(vid).all() and torch.isfinite(kimg).all()),
+                   "resident_weight_gb": round((knet.weight_bytes() + unet.weight_bytes() + ctrl.weight_bytes() + te.weight_bytes() + vae.weight_bytes()) / 1e9, 2)}}))
+
+
 
 def main():
     args = parse()
@@ -203,6 +367,8 @@ def main():
         return keyframe_main(args)
     if args.workload == "vae":
         return vae_main(args)
+    if args.workload == "enhance":
+        return enhance_main(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -381,6 +547,9 @@ def main():
         result["config"]["psnr_c2_vs_fp32_oracle_db"] = psnr_headline(dev, host_sd, ucfg, ccfg, pipe, clips[-1], args) if (oracle_leg and not args.no_psnr) else None
         if oracle_leg:
             result["cpu_baseline"] = cpu_baseline(host_sd, ucfg, ccfg, args)
+        # end-to-end __call__ (CLIP -> loop -> VAE decode -> .videos) beside the loop-only headline; N = 1 only
+        if world == 1 and not args.no_end_to_end and not args.attn_fp8:
+            result["end_to_end"] = end_to_end_leg(args, dev, unet, ctrl, sched, clips)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -19,8 +19,8 @@
 //     (weights of t+1 landed) and one after phase 3 (activations of t+1 landed), each followed by the phase's closing barrier, one
 //     interval before the first read (RAW: wait -> barrier -> read; WAR: a region is re-staged only after a barrier that follows the
 //     lgkmcnt(0) of its last readers).  Two LDS buffers of (256 + 64 NT) x 128 B.
-//   * epilogue through LDS in four 64-row rounds (fp32 tile, XOR-swizzled), 16-byte coalesced bias / row-vector / residual / output
-//     accesses, identical arithmetic to gemm.hip's staged epilogue (incl. GEGLU for even NT).
+//   * epilogue through LDS in two (NT <= 4) or four rounds (fp32 tile, XOR-swizzled; both wave groups park their rows side by side), 16-byte
+//     coalesced bias / row-vector / residual / output accesses, identical arithmetic to gemm.hip's staged epilogue (incl. GEGLU, even NT).
 // Not here (the launcher falls back to gemm.hip): split-K, the LayerNorm-folded variant, raw fp32 output, strided / upsampling /
 // tap-major 3x3 convs, grids that would leave the chip under-filled.
 #include "common.h"
@@ -270,47 +270,49 @@ __global__ __launch_bounds__(512, 2) void g8p_kernel(NrGemmParams p, int m_fast)
   }
   if (g == 0) __builtin_amdgcn_s_barrier();            // re-align the two groups
 
-  // ---- epilogue: four 64-row rounds through LDS (fp32, 16-byte chunks XOR-swizzled with row & 7) ----
+  // ---- epilogue through LDS (fp32, 16-byte chunks XOR-swizzled with row & 7): per round BOTH groups park RT of their 8 row tiles (so the
+  // GEGLU gate / the stores of all eight waves run side by side), then all 512 threads walk the 2 x RT x 16 rows in 16-byte pieces ----
+  constexpr int RT = NT <= 4 ? 4 : 2;                  // row tiles per group and round: 2 x RT x 16 x BN fp32 must fit the operand ring
+  static_assert((size_t)2 * RT * 16 * BN * sizeof(float) <= (size_t)2 * STAGE, "epilogue tile exceeds the LDS ring");
   float* sC = reinterpret_cast<float*>(smem);
   const int bno = p.geglu ? BN / 2 : BN;
   const int c8n = bno >> 3;
   const int nout = p.geglu ? p.N / 2 : p.N;
   const int nb0 = p.geglu ? n0 / 2 : n0;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < 8 / RT; ++r) {
     __syncthreads();                                   // r = 0: every wave has left the operand ring; r > 0: the previous round was read
-    if (g == (r >> 1)) {
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int j = (r & 1) * 4 + jj;
-        const int row = jj * 16 + fr;
-        if (!p.geglu) {
+    for (int jj = 0; jj < RT; ++jj) {
+      const int j = r * RT + jj;
+      const int row = (g * RT + jj) * 16 + fr;
+      if (!p.geglu) {
 #pragma unroll
-          for (int i = 0; i < NT; ++i) {
-            const int c4 = ((wn * WN + i * 16) >> 2) + fg;
-            *(f32x4*)(sC + row * BN + ((c4 ^ (row & 7)) << 2)) = acc[i][j];
-          }
-        } else {
-          if constexpr (NT % 2 == 0) {
+        for (int i = 0; i < NT; ++i) {
+          const int c4 = ((wn * WN + i * 16) >> 2) + fg;
+          *(f32x4*)(sC + row * BN + ((c4 ^ (row & 7)) << 2)) = acc[i][j];
+        }
+      } else {
+        if constexpr (NT % 2 == 0) {
 #pragma unroll
-            for (int i = 0; i < NT; i += 2) {
-              const int nv = n0 + wn * WN + i * 16 + 4 * fg;
-              f32x4 v = acc[i][j], gt = acc[i + 1][j];
-              if (p.bias && nv < p.N) { v += *(const f32x4*)(p.bias + nv); gt += *(const f32x4*)(p.bias + nv + 16); }
-              f32x4 o;
+          for (int i = 0; i < NT; i += 2) {
+            const int nv = n0 + wn * WN + i * 16 + 4 * fg;
+            f32x4 v = acc[i][j], gt = acc[i + 1][j];
+            if (p.bias && nv < p.N) { v += *(const f32x4*)(p.bias + nv); gt += *(const f32x4*)(p.bias + nv + 16); }
+            f32x4 o;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = v[e] * gelu_erf_fast(gt[e]);
-              const int c4 = (((wn * WN + i * 16) >> 1) >> 2) + fg;
-              *(f32x4*)(sC + row * BN + ((c4 ^ (row & 7)) << 2)) = o;
-            }
+            for (int e = 0; e < 4; ++e) o[e] = v[e] * gelu_erf_fast(gt[e]);
+            const int c4 = (((wn * WN + i * 16) >> 1) >> 2) + fg;
+            *(f32x4*)(sC + row * BN + ((c4 ^ (row & 7)) << 2)) = o;
           }
         }
       }
     }
     __syncthreads();
-    for (int idx = tid; idx < 64 * c8n; idx += 512) {
+    for (int idx = tid; idx < 2 * RT * 16 * c8n; idx += 512) {
       const int row = idx / c8n, c8 = idx - row * c8n;
-      const int m = m0 + r * 64 + row, n = nb0 + c8 * 8;
+      const int gg = row / (RT * 16), lrow = row - gg * (RT * 16);
+      const int m = m0 + gg * 128 + r * (RT * 16) + lrow, n = nb0 + c8 * 8;
       if (m >= p.M || n >= nout) continue;
       f32x4 va = *(const f32x4*)(sC + row * BN + (((2 * c8) ^ (row & 7)) << 2));
       f32x4 vb = *(const f32x4*)(sC + row * BN + (((2 * c8 + 1) ^ (row & 7)) << 2));
@@ -386,16 +388,22 @@ extern "C" int nr_g8p_plan(const NrGemmParams* pp) {
   if (p.rowvec && p.rowvec_ld % 4 != 0) return 0;
   const long long Mp = p.plan_m > 0 && p.plan_m < p.M ? p.plan_m : p.M;     // batch-independent choice (common.h): as for one clip
   const long long ntm = (Mp + G8_BM - 1) / G8_BM;
-  // widest tile whose grid keeps the chip filled: rounds of 256 workgroups, >= 80 % of the last round's slots used
+  const int nk = p.K / 64;
+  // Where it pays (tools/g8p_ab.py on MI355X, profiles/r04_g8p_ab_*.txt): long-K launches whose grid fills the chip in whole rounds of 256
+  // workgroups -- 1.2-1.3x the tiled igemm on the 3x3 convs of the SparseCtrl groups / configs 4 / 5 / the VAE (1.22-1.34 PFLOP/s).  With
+  // one workgroup per CU the prologue (first tiles from HBM) and the epilogue are exposed once per tile, so short-K Linears (K = 640: 10
+  // k-tiles) only win on very large grids, narrow tiles (N = 128: 8 MFMAs per phase) lose to the load section, and under-filled grids lose
+  // to the tiled kernel's 2 x 256 slots.
   static const int min_tiles = getenv("NR_G8P_MIN_TILES") ? atoi(getenv("NR_G8P_MIN_TILES")) : 200;
   int best = 0;
   double best_score = 0.0;
   for (int nt = 5; nt >= 2; --nt) {
     if (p.geglu && nt % 2) continue;
+    if (mode != 2 && nt < 4) continue;
     const int bn = 64 * nt;
     const long long ntn = (p.N + bn - 1) / bn;
     const long long tiles = ntm * ntn;
-    if (mode != 2 && tiles < min_tiles) continue;
+    if (mode != 2 && tiles < (nk >= 16 ? min_tiles : 512)) continue;
     const double fill = (double)tiles / (double)(((tiles + 255) / 256) * 256);            // wave quantisation
     const double used = (double)p.N / (double)(ntn * bn) * (double)Mp / (double)(ntm * G8_BM);   // padded outputs
     const double width = nt >= 4 ? 1.0 : (nt == 3 ? 0.9 : 0.8);                         // narrower tiles stage more bytes per FLOP
@@ -403,6 +411,8 @@ extern "C" int nr_g8p_plan(const NrGemmParams* pp) {
     if (score > best_score) { best_score = score; best = nt; }
   }
   if (mode != 2 && best_score < 0.70) return 0;
+  static const int geglu_ok = getenv("NR_G8P_GEGLU") ? atoi(getenv("NR_G8P_GEGLU")) : 0;
+  if (mode != 2 && p.geglu && !geglu_ok) return 0;
   return best;
 }
 

@@ -218,3 +218,58 @@ def test_a18_unclip_recon_harness_matches_reference_fixture(cuda):
     print(f"[a18 unclip_recon -> keyframe pixels vs reference] psnr={psnr:.1f} dB  mean {img.mean().item():.4f} (ref {float(g['samples_mean']):.4f})")
     assert psnr >= 35.0, psnr
     assert abs(img.double().mean().item() - float(g["samples_mean"])) < 5e-3
+
+
+def test_c2_end_to_end_call_videos_vs_oracle(c2, cuda):
+    """The whole reference call at full size (VERDICT r3 missing #3; pipeline_neuroclips.py:321-501): prompt -> native CLIP text encoder
+    (_encode_prompt, both CFG halves) -> SparseCtrl + U-Net DDIM loop -> native VAE decode -> `.videos`, against the oracle chain
+    clip_oracle -> neuroclips_denoise -> vae_oracle.decode_latents on the same weights, token ids, latents and noise.  SD-1.5-size CLIP
+    (12 layers, 768) and VAE decoder (ch 128, mult 1-2-4-4) with seeded random weights; 12 DDIM steps bound the oracle's time.
+    Tolerance: PSNR >= 40 dB on the [0, 1] pixels (the north-star bar), measured in the test output."""
+    from neurons_amd import DDIMScheduler, NeuroclipsPipeline
+    from neurons_amd.clip import CLIPTextConfig, NativeCLIPTextModel, clip_state_dict_schema
+    from neurons_amd.synth import gpu_random_state_dict
+    from neurons_amd.vae import NativeVAEDecoder, VAEDecoderConfig, vae_decoder_state_dict_schema
+    from oracle import clip_oracle as CO
+    from oracle import vae_oracle as V
+    O, inp, F, L = c2["O"], c2["inp"], c2["F"], c2["L"]
+    steps = 12
+    tcfg, vcfg = CLIPTextConfig(), VAEDecoderConfig()
+    tsd = gpu_random_state_dict(clip_state_dict_schema(tcfg), 31, cuda)
+    for k in tsd:
+        if "embedding" in k:
+            tsd[k] = tsd[k] * 14.0            # N(0, 1/768) rows -> O(0.5) embeddings, the scale of tests/test_clip_gpu.py
+    vsd = gpu_random_state_dict(vae_decoder_state_dict_schema(vcfg), 32, cuda)
+    te, vae = NativeCLIPTextModel(tcfg).to(cuda), NativeVAEDecoder(vcfg).to(cuda)
+    te.load_state_dict({k: v.cpu() for k, v in tsd.items()})
+    vae.load_state_dict({k: v.cpu() for k, v in vsd.items()})
+
+    class Tok:
+        model_max_length = 77
+
+        def __call__(self, prompt, padding=None, max_length=None, truncation=None, return_tensors=None):
+            prompt = [prompt] if isinstance(prompt, str) else prompt
+            rows = []
+            for p in prompt:
+                t = [49406] + [1 + (ord(ch) * 37 % 40000) for ch in p][:75] + [49407]
+                rows.append(t + [49407] * (77 - len(t)))
+            return type("Enc", (), {"input_ids": torch.tensor(rows), "attention_mask": torch.ones(len(rows), 77)})()
+
+        def batch_decode(self, x):
+            return [""]
+
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
+    pipe = NeuroclipsPipeline(vae=vae, text_encoder=te, tokenizer=Tok(), unet=c2["unet"], scheduler=sched, controlnet=c2["ctrl"]).to(cuda)
+    prompt = "a dog runs across a field"
+    out = pipe(prompt, video_length=F, height=L * 8, width=L * 8, num_inference_steps=steps, guidance_scale=8.5, latents=inp["lat"],
+               noise=inp["noise"], controlnet_images=inp["cimg"], controlnet_image_index=[0], low_strength=0.3, output_type="tensor")
+    vid = out.videos
+    assert tuple(vid.shape) == (1, 3, F, L * 8, L * 8) and vid.dtype == torch.float32 and not vid.is_cuda       # the reference returns host pixels
+    tok = Tok()
+    with torch.no_grad():
+        ctx = torch.cat([CO.clip_text_forward(tsd, tok("").input_ids.to(cuda), tcfg.num_hidden_layers, tcfg.num_attention_heads),
+                         CO.clip_text_forward(tsd, tok(prompt).input_ids.to(cuda), tcfg.num_hidden_layers, tcfg.num_attention_heads)])
+        lat, _ = O.neuroclips_denoise(c2["usd"], c2["ou"], c2["csd"], c2["oc"], inp["lat"], inp["noise"], ctx, inp["cimg"], (0,), steps, 8.5)
+        ref = V.decode_latents(vsd, lat, len(vcfg.ch_mult), vcfg.num_res_blocks)
+    rel, psnr = metrics(f"C2 end to end: .videos of __call__(prompt) vs the oracle chain (CLIP -> {steps}-step loop -> VAE decode)", vid, ref.cpu())
+    assert psnr >= LOOP_PSNR_DB, psnr
