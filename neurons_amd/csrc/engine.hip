@@ -606,8 +606,9 @@ struct nr_net {
   }
 
   // ------------------------------------------------------------------ plan helpers
+  // (integer arithmetic: during the sizing pass arena_base is null and the pointers are never used; `null + offset` on a pointer is UB)
   template <class T>
-  T* at(size_t off) const { return (T*)(arena_base + off); }
+  T* at(size_t off) const { return reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(arena_base) + off); }
 
   Act new_act(int nimg, int h, int w, int C) {
     Act a;
@@ -622,7 +623,7 @@ struct nr_net {
     const size_t bytes = (size_t)nimg * h * w * C * sizeof(bf16);
     auto b = std::make_shared<Buf>();
     b->arena = &parena; b->bytes = bytes; b->off = parena.alloc(bytes); b->keep = true;
-    a.buf = b; a.ptr = (bf16*)(arena_base + main_high + b->off); a.nimg = nimg; a.H = h; a.W = w; a.C = C; a.ld = C;
+    a.buf = b; a.ptr = at<bf16>(main_high + b->off); a.nimg = nimg; a.H = h; a.W = w; a.C = C; a.ld = C;
     return a;
   }
   // raw pinned scratch (lives for the whole plan)

@@ -324,3 +324,45 @@ def test_two_stream_schedules_are_bit_reproducible_50x(cuda):
     assert pipe.last_controlnet_group > 1
     for rep in range(50):
         assert torch.equal(ref, pipe("", **kw).videos), f"grouped schedule differs at repetition {rep}"
+
+
+def test_plan_without_buffer_reuse_gives_bit_identical_results(cuda):
+    """The plan-time arena hands a buffer's bytes to a later activation as soon as its last reader has been EMITTED (first-fit free list,
+    engine.hip Arena / Buf).  A buffer released one op too early would be overwritten while a kernel still reads it -- silently, and only
+    for some shapes.  nr_net_set_debug(1) plans every activation into its own memory (no reuse at all): if the two plans do not agree bit
+    for bit, some lifetime in the reusing plan is too short.  Tiny full-topology networks (both kinds, with the ControlNet residuals) and
+    the full-width C = 320 leaf modules at the row counts of the fused kernels."""
+    from neurons_amd import _lib
+    from neurons_amd.ops import NativeLeaf
+    from neurons_amd.synth import randn
+    from neurons_amd.unet3d import _motion_keys, _transformer_keys
+    from test_leaf_gpu import _fill
+    g = np.load(os.path.join(GOLD, "tiny_networks.npz"))
+    sample, ctx = torch.from_numpy(g["sample"]).cuda(), torch.from_numpy(g["ctx"]).cuda()
+    cond, mask = torch.from_numpy(g["cond"]).cuda(), torch.from_numpy(g["mask"]).cuda()
+    lib = _lib.load()
+
+    def run(debug):
+        unet, ctrl = _tiny()
+        for n in (unet, ctrl):
+            _lib.check(lib.nr_net_set_debug(n._handle(), 1 if debug else 0))
+        down, mid = ctrl(sample, int(g["t"]), encoder_hidden_states=ctx, controlnet_cond=cond, conditioning_mask=mask, return_dict=False)
+        eps = unet(sample, int(g["t"]), encoder_hidden_states=ctx, down_block_additional_residuals=down, mid_block_additional_residual=mid).sample
+        return [d.float().clone() for d in down] + [mid.float().clone(), eps.clone()], unet.workspace_bytes()
+
+    a, ws_a = run(False)
+    b, ws_b = run(True)
+    assert ws_b > ws_a, "debug mode must not reuse memory"
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x, y), f"tensor {i} differs between the reusing plan and the no-reuse plan"
+    for kind, keys, tag, seed, shape, has_ctx in (("temporal", _motion_keys("m", 320, 2), "tm320big", 61, (1, 320, 16, 16, 16), False),
+                                                   ("transformer3d", _transformer_keys("m", 320, 768), "t3d320big", 63, (1, 320, 2, 48, 48), True)):
+        outs = []
+        for debug in (0, 1):
+            leaf = NativeLeaf(kind, channels=320, heads=8, cross_attention_dim=768, num_attention_blocks=2, pe_max_len=24)
+            _lib.check(lib.nr_net_set_debug(leaf._h, debug))
+            leaf.load_state_dict(_fill({k[2:]: v for k, v in keys.items()}, tag, seed))
+            x = randn(f"{tag}.x", shape, seed + 1).cuda()
+            c = randn(f"{tag}.ctx", (1, 77, 768), seed + 2).cuda() if has_ctx else None
+            outs.append(leaf(x, c).clone())
+        assert torch.equal(outs[0], outs[1]), f"{kind}: reusing plan differs from the no-reuse plan"
