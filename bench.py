@@ -421,6 +421,11 @@ def main():
                 from neurons_amd.pipeline import controlnet_group_size
                 grp0 = controlnet_group_size(args.ddim_steps, 2 * args.batch, F, L, L,
                                              int(os.environ["NR_CTRL_GROUP"]) if os.environ.get("NR_CTRL_GROUP") else "auto")
+                if kind == _lib.NR_KIND_SPARSECTRL and os.environ.get("NR_CTRL_DEDUP", "1") != "0":
+                    # the plan every rank will run: condition on frame 0 only (controlnet_image_index=[0]) -> identical-frame evaluation
+                    import ctypes
+                    _lib.check(_lib.load().nr_sparsectrl_set_condition_frames(net._handle(), (ctypes.c_int32 * 1)(0), 1))
+                    net._cframes = (0,)
                 net._ensure_plan(2 * args.batch * (grp0 if kind == _lib.NR_KIND_SPARSECTRL else 1), F, L, L, 77)
         if use_dist:
             broadcast_native_weights(net, src=0)

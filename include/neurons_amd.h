@@ -259,6 +259,14 @@ nr_status nr_unet3d_forward_after(nr_net* unet, nr_net* ctrl, int32_t slot, nr_s
  * operands (fp32 softmax statistics and accumulation).  Off by default (bf16); changing it invalidates the plan. */
 nr_status nr_net_set_attention_fp8(nr_net* h, int32_t enable);
 
+/* SparseCtrl: tell the engine which frames carry a condition (controlnet_cond / conditioning_mask not all zero there;
+ * pipeline_neuroclips.py:447-458 fills only controlnet_image_index).  With set_noisy_sample_input_to_zero every other frame enters the
+ * network as the same constant image, so down_blocks[0].resnets[0] + attentions[0] are evaluated on the conditioned frames plus ONE
+ * representative and broadcast before the first motion module (sparse_controlnet.py:517-545, unet_blocks.py:382-421): same results, 1/8
+ * of the work of those two modules for one condition frame in sixteen.  The CALLER guarantees the zero frames (NativeSparseCtrl derives
+ * the list from the tensors themselves).  n < 0 switches back to the full evaluation (default).  Invalidates the plan when it changes. */
+nr_status nr_sparsectrl_set_condition_frames(nr_net* h, const int32_t* frames, int32_t n);
+
 /* Batch-independent arithmetic (default off; NR_DETERMINISTIC_BATCH=1 turns it on for new handles): every plan choice that can move a bf16
  * rounding point or an fp32 summation order -- LayerNorm folded into the GEMM vs the separate kernel, split-K depth, row-panel / fused-kernel
  * eligibility, GroupNorm variant and chunking, the per-workgroup weight-stream rotation of the fused kernels -- is made for the rows of ONE

@@ -383,6 +383,27 @@ static __global__ void nhwc_to_ncfhw_kernel(const bf16* __restrict__ src, float*
   dst[i] = (float)src[((b * F + f) * HW + p) * C + c];
 }
 
+// dst[b][fd][:] = src[b][map[fd]][:]  (frame-images of frame_elems bf16, 16-byte pieces): the reduce / expand steps of SparseCtrl's
+// identical-frame evaluation (engine.hip build(): frames without a condition are identical until the first motion module)
+struct NrFrameMap { int v[64]; };
+static __global__ __launch_bounds__(256) void frame_gather_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int Fs, int Fd, long long f16,
+                                                                   NrFrameMap map, long long total16) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total16) return;
+  const long long img = i / f16, r = i - img * f16;
+  const long long b = img / Fd;
+  const int fd = (int)(img - b * Fd);
+  dst[i] = src[(b * Fs + map.v[fd]) * f16 + r];
+}
+extern "C" int nr_launch_frame_gather(const bf16* src, bf16* dst, int B, int Fs, int Fd, long long frame_elems, const int* map, hipStream_t stream) {
+  if (Fd > 64 || frame_elems % 8 != 0) return 1;
+  NrFrameMap m;
+  for (int i = 0; i < 64; ++i) m.v[i] = i < Fd ? map[i] : 0;
+  const long long f16 = frame_elems / 8, total16 = (long long)B * Fd * f16;
+  hipLaunchKernelGGL(frame_gather_kernel, dim3((unsigned)((total16 + 255) / 256)), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, Fs, Fd, f16, m, total16);
+  return 0;
+}
+
 extern "C" int nr_launch_ncfhw_to_nhwc(const float* src, bf16* dst, int B, int C, int F, int HW, hipStream_t stream) {
   const long long total = (long long)B * C * F * HW;
   hipLaunchKernelGGL(ncfhw_to_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, dst, C, F, HW, total);

@@ -58,6 +58,7 @@ int nr_launch_cfg_ddim_step(const float* eps, const float* x, float* x_out, long
 int nr_launch_add_bf16(const bf16* a, const bf16* b, bf16* out, long long n, hipStream_t stream);
 int nr_launch_f32_to_bf16(const float* a, bf16* out, long long n, hipStream_t stream);
 int nr_launch_add_bf16_multi(const NrAddMulti* p, hipStream_t stream);
+int nr_launch_frame_gather(const bf16* src, bf16* dst, int B, int Fs, int Fd, long long frame_elems, const int* map, hipStream_t stream);
 int nr_launch_ncfhw_to_nhwc(const float* src, bf16* dst, int B, int C, int F, int HW, hipStream_t stream);
 int nr_launch_nhwc_to_ncfhw(const bf16* src, float* dst, int B, int C, int F, int HW, hipStream_t stream);
 int nr_groupnorm_launches(const NrGnParams* p);
@@ -257,6 +258,13 @@ struct nr_net {
     if (!det_batch || B2 <= 2) return rows;
     return rows / B2 * 2;
   }
+  // SparseCtrl only (nr_sparsectrl_set_condition_frames): the frames whose condition / mask is not all zero.  With the noisy sample zeroed
+  // (sparse_controlnet.py:468-469) every OTHER frame enters the network as the same constant image (conv_in(0) + cond_embedding(0) =
+  // the two biases, :513-521), so until the first motion module mixes frames (unet_blocks.py:382-421: resnet -> attention -> motion
+  // module) all of them carry identical activations: down_blocks[0].resnets[0] + attentions[0] run on the conditioned frames plus ONE
+  // representative of the rest and are broadcast before motion_modules[0].  Exact (per-frame operators, identical inputs); < 0 = off.
+  int n_cond_frames = -1;
+  int cond_frames[64] = {0};
   bool attn_fp8 = false;         // nr_net_set_attention_fp8: spatial / cross attention on e4m3 MFMA operands (config 5)
   IO io;
   int n_res = 0;
@@ -1638,10 +1646,56 @@ struct nr_net {
     // ---- down blocks ----
     std::vector<Act> skips;
     skips.push_back(x);
+    // SparseCtrl identical-frame evaluation (see n_cond_frames): distinct frames = the conditioned ones + one representative of the rest
+    int nd = 0, fmap_reduce[64], fmap_expand[64];
+    if (cfg.kind == NR_KIND_SPARSECTRL && cfg.set_noisy_sample_input_to_zero && cfg.use_motion_module && n_cond_frames >= 0 && !keep_all && F <= 64) {
+      int rep = -1;
+      for (int f = 0; f < F && rep < 0; ++f) {
+        bool is_c = false;
+        for (int k = 0; k < n_cond_frames; ++k) is_c = is_c || cond_frames[k] == f;
+        if (!is_c) rep = f;
+      }
+      int nc = 0;
+      for (int k = 0; k < n_cond_frames; ++k) if (cond_frames[k] < F) fmap_reduce[nc++] = cond_frames[k];
+      if (rep >= 0 && nc + 1 < F) {
+        fmap_reduce[nc] = rep;
+        nd = nc + 1;
+        for (int f = 0; f < F; ++f) {
+          fmap_expand[f] = nc;
+          for (int k = 0; k < nc; ++k) if (fmap_reduce[k] == f) fmap_expand[f] = k;
+        }
+      }
+    }
     for (int i = 0; i < L; ++i) {
       const int Cout = cfg.block_out_channels[i];
       const std::string bp = "down_blocks." + std::to_string(i);
       for (int j = 0; j < cfg.layers_per_block; ++j) {
+        if (i == 0 && j == 0 && nd > 0) {
+          // reduce -> resnet + attention on B2 x nd frame-images -> broadcast
+          const long long fe = (long long)x.H * x.W * x.C;
+          Act xr = new_act(B2 * nd, x.H, x.W, x.C);
+          {
+            const bf16* sp = x.ptr; bf16* dp = xr.ptr; const int b2n = B2, Fs = F, Fd = nd;
+            std::vector<int> mp(fmap_reduce, fmap_reduce + nd);
+            emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_frame_gather(sp, dp, b2n, Fs, Fd, fe, mp.data(), s)); });
+          }
+          const int Fsave = F;
+          F = nd;                                           // rows per sample (time-embedding row vector, context per sample) follow the reduced set
+          xr = resnet(xr, nullptr, bp + ".resnets.0", Cout);
+          if (cfg.down_block_has_attn[0]) xr = spatial_transformer(xr, ctx_bf, bp + ".attentions.0");
+          F = Fsave;
+          Act xe = new_act(nimg, xr.H, xr.W, xr.C);
+          {
+            const long long fe2 = (long long)xr.H * xr.W * xr.C;
+            const bf16* sp = xr.ptr; bf16* dp = xe.ptr; const int b2n = B2, Fs = nd, Fd = F;
+            std::vector<int> mp(fmap_expand, fmap_expand + F);
+            emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_frame_gather(sp, dp, b2n, Fs, Fd, fe2, mp.data(), s)); });
+          }
+          x = xe;
+          x = temporal_module(x, bp + ".motion_modules.0");
+          skips.push_back(x);
+          continue;
+        }
         x = resnet(x, nullptr, bp + ".resnets." + std::to_string(j), Cout);
         if (cfg.down_block_has_attn[i]) x = spatial_transformer(x, ctx_bf, bp + ".attentions." + std::to_string(j));
         if (cfg.use_motion_module) x = temporal_module(x, bp + ".motion_modules." + std::to_string(j));
@@ -2169,6 +2223,28 @@ extern "C" nr_status nr_net_set_graph(nr_net* h, int32_t enable) {
   NR_TRY
   if (!h) throw NrError(NR_ERR_ARG, "null handle");
   h->use_graph = enable != 0;
+  NR_CATCH
+}
+
+extern "C" nr_status nr_sparsectrl_set_condition_frames(nr_net* h, const int32_t* frames, int32_t n) {
+  NR_TRY
+  if (!h || h->cfg.kind != NR_KIND_SPARSECTRL) throw NrError(NR_ERR_ARG, "handle is not a SparseCtrl");
+  if (n > 64 || (n > 0 && !frames)) throw NrError(NR_ERR_ARG, "at most 64 condition frames");
+  int v[64] = {0};
+  int m = n < 0 ? -1 : 0;
+  for (int i = 0; i < n; ++i) {
+    if (frames[i] < 0) throw NrError(NR_ERR_ARG, "negative frame index");
+    bool dup = false;
+    for (int k = 0; k < m; ++k) dup = dup || v[k] == frames[i];
+    if (!dup) v[m++] = frames[i];
+  }
+  bool same = m == h->n_cond_frames;
+  for (int i = 0; same && i < m; ++i) same = v[i] == h->cond_frames[i];
+  if (!same) {
+    h->n_cond_frames = m;
+    for (int i = 0; i < 64; ++i) h->cond_frames[i] = i < m ? v[i] : 0;
+    h->planned = false;
+  }
   NR_CATCH
 }
 

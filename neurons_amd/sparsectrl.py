@@ -6,6 +6,7 @@ Physically the tensors are channels-last bf16 views of buffers written by ``nr_s
 ``NativeUNet3D`` consumes them with zero copies; any other consumer sees ordinary (non-contiguous) tensors.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass, replace
 from typing import List, Optional
 
@@ -56,6 +57,31 @@ class NativeSparseCtrl(_NativeNet):
     def from_unet(cls, unet, controlnet_additional_kwargs: Optional[dict] = None):
         return cls(controlnet_config_from_unet(unet.config, controlnet_additional_kwargs))
 
+    # ---- identical-frame evaluation (C ABI nr_sparsectrl_set_condition_frames) ---------------------------------------------------------
+    def _sync_condition_frames(self, controlnet_cond, conditioning_mask):
+        """Frames whose condition or mask is not all zero, read from the tensors themselves (one small reduction + host read per NEW
+        condition tensor: identity + in-place version are cached, so a clip's 50 steps / 10 groups pay it once).  Every other frame is
+        exactly zero, which is what makes the engine's shortcut exact; with the noisy sample NOT zeroed frames differ anyway: off."""
+        if os.environ.get("NR_CTRL_DEDUP", "1") == "0" or not self.config.set_noisy_sample_input_to_zero:
+            frames = None
+        else:
+            key = (controlnet_cond.data_ptr(), controlnet_cond._version, conditioning_mask.data_ptr(), conditioning_mask._version,
+                   tuple(controlnet_cond.shape))
+            if getattr(self, "_cframes_key", None) == key:
+                return
+            nz = (controlnet_cond != 0).flatten(3).any(-1).any(1).any(0) | (conditioning_mask != 0).flatten(3).any(-1).any(1).any(0)
+            frames = tuple(int(i) for i in torch.nonzero(nz).flatten().tolist())
+            self._cframes_key = key
+            self._cframes_ref = (controlnet_cond, conditioning_mask)
+        if getattr(self, "_cframes", "unset") != frames:
+            if frames is None:
+                _lib.check(_lib.load().nr_sparsectrl_set_condition_frames(self._handle(), None, -1))
+            else:
+                arr = (C.c_int32 * max(1, len(frames)))(*frames)
+                _lib.check(_lib.load().nr_sparsectrl_set_condition_frames(self._handle(), arr, len(frames)))
+            self._cframes = frames
+            self._plan_key = None           # the launch plan depends on the frame list
+
     def _on_plan(self):
         b, f, h, w, L = self._plan_key
         dev = self.device
@@ -101,6 +127,7 @@ class NativeSparseCtrl(_NativeNet):
             raise ValueError(f"controlnet_cond shape {tuple(controlnet_cond.shape)} does not match sample {tuple(sample.shape)}")
         if b % cb != 0 or conditioning_mask.shape[0] != cb:
             raise ValueError("controlnet_cond batch must divide the sample batch (it is broadcast over the CFG halves)")
+        self._sync_condition_frames(controlnet_cond, conditioning_mask)
         self._ensure_plan(b, f, h, w, ctx.shape[1])
         lib = _lib.load()
         self._set_context(ctx)
@@ -155,6 +182,7 @@ class NativeSparseCtrl(_NativeNet):
         cb, _, f, h, w = controlnet_cond.shape
         if ctx.shape[0] != b or b % cb != 0 or conditioning_mask.shape[0] != cb:
             raise ValueError("forward_async: context batch must equal len(timesteps); the condition batch must divide it")
+        self._sync_condition_frames(controlnet_cond, conditioning_mask)
         self._ensure_plan(b, f, h, w, ctx.shape[1])
         self._set_context(ctx)
         if self._io_cond is None or self._io_cond.shape[0] != cb:

@@ -623,6 +623,7 @@ class NativeUNet3D(_NativeNet):
             raise RuntimeError(f"U-Net on {self.device} but SparseCtrl on {controlnet.device}")
         controlnet.to(self.device)
         self._ensure_plan(b, f, h, w, L)
+        controlnet._sync_condition_frames(controlnet_cond, conditioning_mask)
         controlnet._ensure_plan(b, f, h, w, L)
         self._io_sample.copy_(sample)
         self._set_context(ctx)

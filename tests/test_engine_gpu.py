@@ -366,3 +366,54 @@ def test_plan_without_buffer_reuse_gives_bit_identical_results(cuda):
             c = randn(f"{tag}.ctx", (1, 77, 768), seed + 2).cuda() if has_ctx else None
             outs.append(leaf(x, c).clone())
         assert torch.equal(outs[0], outs[1]), f"{kind}: reusing plan differs from the no-reuse plan"
+
+
+def _ctrl_descs(ctrl):
+    from neurons_amd import _lib
+    lib = _lib.load()
+    return [lib.nr_net_op_desc(ctrl._h, i).decode() for i in range(lib.nr_net_num_ops(ctrl._h))]
+
+
+@pytest.mark.parametrize("index", [(0,), (0, 5), (3,)])
+def test_sparsectrl_identical_frame_evaluation_is_exact(cuda, index):
+    """SparseCtrl with the noisy sample zeroed sees, on every frame WITHOUT a condition, the same constant image (sparse_controlnet.py:
+    468-469,513-521), so down_blocks[0].resnets[0] + attentions[0] are evaluated on the conditioned frames + one representative and
+    broadcast before the first motion module (nr_sparsectrl_set_condition_frames; NativeSparseCtrl reads the frame list off the tensors).
+    Must reproduce the full evaluation (NR_CTRL_DEDUP=0): every operator up to there is per frame, so the only differences are the bf16 /
+    fp32-order effects of a launch plan made for fewer rows -- gate 60 dB on every residual, and the reference golden still holds."""
+    g = np.load(os.path.join(GOLD, "tiny_networks.npz"))
+    _, ctrl = _tiny()
+    sample, ctx = torch.from_numpy(g["sample"]).cuda(), torch.from_numpy(g["ctx"]).cuda()
+    F = sample.shape[2]
+    cond = torch.zeros(1, 4, F, 8, 8, device=cuda)
+    mask = torch.zeros(1, 1, F, 8, 8, device=cuda)
+    gen = torch.Generator(device=cuda).manual_seed(77)
+    for f in index:
+        cond[:, :, f] = torch.randn(1, 4, 8, 8, generator=gen, device=cuda) * 0.18215
+        mask[:, :, f] = 1
+
+    def run(dedup):
+        os.environ["NR_CTRL_DEDUP"] = "1" if dedup else "0"
+        ctrl._cframes_key = None
+        down, mid = ctrl(sample, int(g["t"]), encoder_hidden_states=ctx, controlnet_cond=cond, conditioning_mask=mask, return_dict=False)
+        return [d.float().clone() for d in down] + [mid.float().clone()], _ctrl_descs(ctrl)
+
+    try:
+        full, d_full = run(False)
+        fast, d_fast = run(True)
+    finally:
+        os.environ.pop("NR_CTRL_DEDUP", None)
+    B2, hw = sample.shape[0], 64
+    rows_full, rows_red = B2 * F * hw, B2 * (len(index) + 1) * hw
+    assert any(f"M={rows_red} " in d for d in d_fast) and not any(f"M={rows_red} " in d for d in d_full), "the reduced-row launches are missing"
+    assert sum(f"M={rows_full} " in d for d in d_fast) < sum(f"M={rows_full} " in d for d in d_full)
+    for i, (a, b) in enumerate(zip(fast, full)):
+        rel, psnr = metrics(f"identical-frame evaluation, index {index}: residual {i} vs full evaluation", a, b)
+        assert psnr >= 60.0 or torch.equal(a, b), (i, psnr)
+    if index == (0,):       # the reference golden was recorded with the condition on frame 0 only... with ITS cond: re-run with it
+        cond0, mask0 = torch.from_numpy(g["cond"]).cuda(), torch.from_numpy(g["mask"]).cuda()
+        ctrl._cframes_key = None
+        down, mid = ctrl(sample, int(g["t"]), encoder_hidden_states=ctx, controlnet_cond=cond0, conditioning_mask=mask0, return_dict=False)
+        assert ctrl._cframes == (0,)
+        worst = max(metrics(f"dedup ctrl down_res_{i} vs reference", d, g[f"down_res_{i}"])[0] for i, d in enumerate(down))
+        assert worst < 2.5e-2

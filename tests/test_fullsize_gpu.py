@@ -273,3 +273,35 @@ def test_c2_end_to_end_call_videos_vs_oracle(c2, cuda):
         ref = V.decode_latents(vsd, lat, len(vcfg.ch_mult), vcfg.num_res_blocks)
     rel, psnr = metrics(f"C2 end to end: .videos of __call__(prompt) vs the oracle chain (CLIP -> {steps}-step loop -> VAE decode)", vid, ref.cpu())
     assert psnr >= LOOP_PSNR_DB, psnr
+
+
+def test_c2_sparsectrl_identical_frame_evaluation_full_width(c2, cuda):
+    """Full width, (2,4,16,32,32), condition on frame 0: the identical-frame evaluation (2 of 16 frames through down_blocks[0].resnets[0] +
+    attentions[0]) against the full evaluation of the same handle: >= 60 dB on all 13 residuals (two bf16 roundings of the same arithmetic:
+    the launch plan follows the row count), and against the fp32 oracle within the per-evaluation bar."""
+    O, inp, F, L, ctrl = c2["O"], c2["inp"], c2["F"], c2["L"], c2["ctrl"]
+    cond = torch.zeros(1, 4, F, L, L, device=cuda)
+    cond[:, :, 0] = inp["cimg"][:, :, 0]
+    mask = torch.zeros(1, 1, F, L, L, device=cuda)
+    mask[:, :, 0] = 1
+    xin = torch.cat([inp["lat"]] * 2)
+
+    def run(dedup):
+        os.environ["NR_CTRL_DEDUP"] = "1" if dedup else "0"
+        ctrl._cframes_key = None
+        down, mid = ctrl(xin, 481, encoder_hidden_states=inp["ctx"], controlnet_cond=cond, conditioning_mask=mask, return_dict=False)
+        return [d.float().clone() for d in down] + [mid.float().clone()]
+
+    try:
+        full = run(False)
+        fast = run(True)
+        assert ctrl._cframes == (0,)
+    finally:
+        os.environ.pop("NR_CTRL_DEDUP", None)
+        ctrl._cframes_key = None
+    worst = min(metrics(f"C2 SparseCtrl identical-frame evaluation: residual {i} vs full evaluation", a, b)[1] for i, (a, b) in enumerate(zip(fast, full)))
+    assert worst >= 60.0, worst
+    with torch.no_grad():
+        rd, rm = O.sparse_controlnet_forward(c2["csd"], c2["oc"], xin, 481, inp["ctx"], cond, mask, 1.0)
+    rel = max(metrics(f"C2 SparseCtrl identical-frame evaluation: residual {i} vs the fp32 oracle", a, b)[0] for i, (a, b) in enumerate(zip(fast, list(rd) + [rm])))
+    assert rel <= FWD_REL_L2, rel
