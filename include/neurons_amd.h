@@ -216,6 +216,17 @@ nr_status nr_gaussian_sample(nr_stream stream, const float* moments_dev, const f
 nr_status nr_edm_cfg_euler_step(nr_stream stream, const float* net_dev, const float* x_dev, float* x_out_dev, int64_t n,
                                 float cfg_scale, float sigma_quantized, float sigma, float sigma_next);
 
+/* replaces one iteration of BrainDiffusionPrior.p_sample_loop_ddpm (model_variants/BrainModel_neurons.py:324-341,363-389) behind the network
+ * call, i.e. DiffusionPrior.p_mean_variance + the ancestral update of dalle2-pytorch 1.15.6 (requirements.txt:11; NOT vendored: parity
+ * unpinned): [pred = null + (pred - null) * cond_scale]; x_start = pred (mode 0, predict_x_start: the NEURONS prior) | sqrt(ac) x -
+ * sqrt(1 - ac) pred (mode 1, v) | sqrt(1 / ac) x - sqrt(1 / ac - 1) pred (mode 2, noise; clamp = clip_denoised); x_out = coef1 x_start +
+ * coef2 x + exp(0.5 * posterior_log_variance_clipped) * noise, noise_dev == NULL at t = 0.  The per-t coefficients are formed here from
+ * (alphas_cumprod[t], alphas_cumprod[t - 1] (1 at t = 0), betas[t]) exactly as NoiseScheduler.__init__ does.  All tensors fp32 [n];
+ * x_start_out_dev may be NULL; x_out_dev may alias x_dev. */
+nr_status nr_prior_p_sample_step(nr_stream stream, const float* pred_dev, const float* pred_null_dev, const float* x_dev, const float* noise_dev,
+                                 float* x_out_dev, float* x_start_out_dev, int64_t n, float cond_scale, int32_t mode, int32_t clamp,
+                                 double alpha_cumprod_t, double alpha_cumprod_prev, double beta_t);
+
 /* replaces the CFG combine + DDIMScheduler.step (pipeline_neuroclips.py:478-483; diffusers 0.11.1 DDIM eta=0)
  *   eps_dev fp32 [2B or B][...], x_dev fp32 [B][...] -> x_out_dev (may alias x_dev); n = elements of x     */
 nr_status nr_cfg_ddim_step(nr_stream stream, const float* eps_dev, const float* x_dev, float* x_out_dev, int64_t n,

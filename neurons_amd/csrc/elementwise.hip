@@ -264,6 +264,29 @@ __global__ void cfg_ddim_step_kernel(const float* __restrict__ eps, const float*
   x_out[i] = sqrt_ap * x0 + sqrt_1map * e;
 }
 
+// One ancestral DDPM step of the diffusion prior (see nr_prior_p_sample_step in include/neurons_amd.h): network output -> x_start
+// (mode 0: the output IS x_start; 1: v-prediction; 2: noise prediction, clamped to [-1, 1] when `clamp`), classifier-free guidance
+// between the conditional and the null evaluation when pred_null != nullptr, posterior mean + sigma * noise.
+__global__ void prior_p_sample_kernel(const float* __restrict__ pred, const float* __restrict__ pred_null, const float* __restrict__ x,
+                                      const float* __restrict__ noise, float* __restrict__ x_out, float* __restrict__ x_start_out, long long total,
+                                      float cond_scale, int mode, int clamp, float sqrt_ac, float sqrt_1mac, float sqrt_recip_ac,
+                                      float sqrt_recipm1_ac, float coef1, float coef2, float sigma) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  float p = pred[i];
+  if (pred_null) { const float pn = pred_null[i]; p = pn + (p - pn) * cond_scale; }
+  const float xv = x[i];
+  float x0;
+  if (mode == 0) x0 = p;
+  else if (mode == 1) x0 = sqrt_ac * xv - sqrt_1mac * p;
+  else x0 = sqrt_recip_ac * xv - sqrt_recipm1_ac * p;
+  if (clamp) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+  if (x_start_out) x_start_out[i] = x0;
+  float o = coef1 * x0 + coef2 * xv;
+  if (noise) o += sigma * noise[i];
+  x_out[i] = o;
+}
+
 // EDM eps-scaling + vanilla CFG + Euler step (see nr_edm_cfg_euler_step in include/neurons_amd.h)
 __global__ void edm_cfg_euler_kernel(const float* __restrict__ net, const float* __restrict__ x, float* __restrict__ x_out,
                                      long long total, float scale, float sigma_q, float sigma, float sigma_next) {
@@ -518,6 +541,14 @@ extern "C" int nr_launch_cfg_ddim_step(const float* eps, const float* x, float* 
                                        hipStream_t stream) {
   hipLaunchKernelGGL(cfg_ddim_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, eps, x, x_out,
                      total, total, guidance, do_cfg, sqrt_at, sqrt_1mat, sqrt_ap, sqrt_1map);
+  return 0;
+}
+
+extern "C" int nr_launch_prior_p_sample(const float* pred, const float* pred_null, const float* x, const float* noise, float* x_out,
+                                        float* x_start_out, long long total, float cond_scale, int mode, int clamp, float sqrt_ac, float sqrt_1mac,
+                                        float sqrt_recip_ac, float sqrt_recipm1_ac, float coef1, float coef2, float sigma, hipStream_t stream) {
+  hipLaunchKernelGGL(prior_p_sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, pred, pred_null, x, noise, x_out,
+                     x_start_out, total, cond_scale, mode, clamp, sqrt_ac, sqrt_1mac, sqrt_recip_ac, sqrt_recipm1_ac, coef1, coef2, sigma);
   return 0;
 }
 

@@ -334,9 +334,9 @@ def unet3d_forward(sd: SD, cfg: OracleConfig, sample, timestep, encoder_hidden_s
 
 
 def sparse_controlnet_forward(sd: SD, cfg: OracleConfig, sample, timestep, encoder_hidden_states, controlnet_cond,
-                              conditioning_mask, conditioning_scale=1.0):
+                              conditioning_mask, conditioning_scale=1.0, taps=None):
     """SparseControlNetModel.forward — animatediff/models/sparse_controlnet.py:467-581 (simplified condition
-    embedding, concatenated mask, no guess mode)."""
+    embedding, concatenated mask, no guess mode).  ``taps`` (a dict) receives the activations by reference module name."""
     if cfg.set_noisy_sample_input_to_zero:
         sample = torch.zeros_like(sample)                                        # :468-469
     ctx = encoder_hidden_states.repeat(sample.shape[0] // encoder_hidden_states.shape[0], 1, 1)   # :491
@@ -346,8 +346,10 @@ def sparse_controlnet_forward(sd: SD, cfg: OracleConfig, sample, timestep, encod
     cond = inflated_conv3d(cond, sd["controlnet_cond_embedding.weight"], sd["controlnet_cond_embedding.bias"])
     reps = x.shape[0] // cond.shape[0]
     x = x + (cond if reps == 1 else cond.repeat(reps, 1, 1, 1, 1))             # :521 (batch-1 broadcast; B>1: SURVEY §8e)
-    x, skips = _down_blocks(sd, cfg, x, emb, ctx)
-    x = _mid_block(sd, cfg, x, emb, ctx)
+    if taps is not None:
+        taps["conv_in"] = x
+    x, skips = _down_blocks(sd, cfg, x, emb, ctx, taps)
+    x = _mid_block(sd, cfg, x, emb, ctx, taps)
     down = [inflated_conv3d(s, sd[f"controlnet_down_blocks.{i}.weight"], sd[f"controlnet_down_blocks.{i}.bias"], padding=0)
             * conditioning_scale for i, s in enumerate(skips)]                   # :551-566
     mid = inflated_conv3d(x, sd["controlnet_mid_block.weight"], sd["controlnet_mid_block.bias"], padding=0) * conditioning_scale

@@ -169,3 +169,25 @@ def test_sliced_attention_of_the_oracle_is_value_identical(tiny, monkeypatch):
     b = O.unet3d_forward(usd, ucfg, sample, int(g["t"]), ctx)
     _close("eps_plain (sliced attention)", b, g["eps_plain"])
     assert (a - b).abs().max().item() <= 1e-6 * a.abs().max().item()
+
+
+@torch.no_grad()
+def test_sparsectrl_frames_without_condition_are_identical_before_the_first_motion_module(tiny):
+    """The premise of the engine's identical-frame evaluation (nr_sparsectrl_set_condition_frames), on the reference-pinned oracle: with the
+    noisy sample zeroed, every frame whose condition and mask are zero carries THE SAME activations through conv_in + cond embedding,
+    down_blocks[0].resnets[0] and attentions[0]; the first motion module is what makes them differ (sparse_controlnet.py:468-469,513-545;
+    unet_blocks.py:382-421)."""
+    g, _, ccfg, _, csd = tiny
+    sample, ctx = torch.from_numpy(g["sample"]), torch.from_numpy(g["ctx"])
+    cond, mask = torch.from_numpy(g["cond"]), torch.from_numpy(g["mask"])          # condition on frame 0 only
+    taps = {}
+    O.sparse_controlnet_forward(csd, ccfg, sample, int(g["t"]), ctx, cond, mask, 1.0, taps=taps)
+    assert "down_blocks.0.attentions.0" in taps and "down_blocks.0.motion_modules.0" in taps, sorted(taps)[:8]
+    for name in ("conv_in", "down_blocks.0.resnets.0", "down_blocks.0.attentions.0"):
+        t = taps[name]                                       # b c f h w
+        rest = t[:, :, 1:]
+        spread = (rest - rest[:, :, :1]).abs().max().item()
+        assert spread <= 1e-6 * t.abs().max().item(), (name, spread)
+        assert (t[:, :, 0] - t[:, :, 1]).abs().max().item() > 1e-3 * t.abs().max().item(), name     # the conditioned frame does differ
+    mm = taps["down_blocks.0.motion_modules.0"]
+    assert (mm[:, :, 1:] - mm[:, :, 1:2]).abs().max().item() > 1e-4 * mm.abs().max().item()       # temporal attention mixes the frames
