@@ -54,11 +54,11 @@ __device__ __forceinline__ size_t rowvec_row(const NrGemmParams& p, int m) {
 
 constexpr int G8_BM = 256, G8_BK = 64;
 
-template <int NT, bool TAPI>
+template <int NT, bool TAPI, int NPH = 4>
 __global__ __launch_bounds__(512, 2) void g8p_kernel(NrGemmParams p, int m_fast) {
   constexpr int BN = 64 * NT, WN = 16 * NT;
   constexpr int A_BYTES = G8_BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  constexpr int NB2 = (NT + 1) / 2;                   // weight pieces issued in phase 2 (the rest in phase 3)
+  static_assert(NPH == 4 || (NPH == 2 && NT <= 4), "phases per k-tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x STAGE
 
   const int tid = threadIdx.x;
@@ -201,7 +201,13 @@ __global__ __launch_bounds__(512, 2) void g8p_kernel(NrGemmParams p, int m_fast)
   }
   if (g == 1) __builtin_amdgcn_s_barrier();            // stagger: group 1 runs one interval behind group 0
 
-  bf16x8 wf[2][NT], xf[2][2];
+  // NPH phases per k-tile: 4 (two row tiles per phase: the verified default) or 2 (four row tiles per phase: half the barriers; NT <= 4 only,
+  // the activation fragments of a phase then take 32 VGPRs).  Activation pieces go out in the first NPH / 2 phases, weight pieces in the rest.
+  constexpr int MPP = 8 / NPH;                         // row tiles per phase
+  constexpr int APP = 4 / (NPH / 2);                   // activation pieces per (early) phase
+  constexpr int WPP = (NT + NPH / 2 - 1) / (NPH / 2);  // weight pieces per (late) phase (the last one takes the remainder)
+  constexpr int W_BEFORE_LAST = WPP * (NPH / 2 - 1);   // weight pieces of t+2 already issued when the W(t+1) wait executes
+  bf16x8 wf[2][NT], xf[2][MPP];
   for (int t = 0; t < nk; ++t) {
     const int st = t & 1;
     const char* sbase = smem + st * STAGE;
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(512, 2) void g8p_kernel(NrGemmParams p, int m_fast)
     const char* ab1 = nullptr;
     if (has1) { a_select_source(t + 1); ab1 = a_base(t + 1, tap1); }
 #pragma unroll
-    for (int ph = 0; ph < 4; ++ph) {
+    for (int ph = 0; ph < NPH; ++ph) {
       // ---------------- load section ----------------
       if (!(NR_G8P_ABLATE & 2) || t == 0) {
         if (ph == 0) {
@@ -222,23 +228,26 @@ __global__ __launch_bounds__(512, 2) void g8p_kernel(NrGemmParams p, int m_fast)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int jj = 0; jj < 2; ++jj) xf[ks][jj] = *(const bf16x8*)(sbase + xrow + (2 * ph + jj) * 16 * 128 + (frag0 ^ (unsigned)(ks * 64)));
+          for (int jj = 0; jj < MPP; ++jj) xf[ks][jj] = *(const bf16x8*)(sbase + xrow + (MPP * ph + jj) * 16 * 128 + (frag0 ^ (unsigned)(ks * 64)));
       }
       __builtin_amdgcn_sched_barrier(0);
       if (!(NR_G8P_ABLATE & 1)) {
-        if (ph < 2) {
-          if (has1) { issue_a(ab1, tap1, st ^ 1, 2 * ph); issue_a(ab1, tap1, st ^ 1, 2 * ph + 1); }
-        } else if (ph == 2) {
-          if (has2) {
+        if (ph < NPH / 2) {
+          if (has1) {
 #pragma unroll
-            for (int j = 0; j < NB2; ++j) issue_w(t + 2, st, j);
+            for (int j = 0; j < APP; ++j) issue_a(ab1, tap1, st ^ 1, APP * ph + j);
           }
         } else {
           if (has2) {
 #pragma unroll
-            for (int j = NB2; j < NT; ++j) issue_w(t + 2, st, j);
+            for (int j = WPP * (ph - NPH / 2); j < (ph == NPH - 1 ? NT : WPP * (ph - NPH / 2 + 1)); ++j) issue_w(t + 2, st, j);
           }
         }
+      }
+      if constexpr (NPH == 2) {
+        // the weight region of this buffer is re-staged by the OTHER group one interval from now: retire this wave's weight-fragment reads
+        // before the barrier (they were issued ahead of the LDS-DMA code above, so this wait is normally free), so that the barrier orders them
+        if (ph == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
@@ -248,21 +257,21 @@ __global__ __launch_bounds__(512, 2) void g8p_kernel(NrGemmParams p, int m_fast)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
+        for (int jj = 0; jj < MPP; ++jj)
 #pragma unroll
           for (int i = 0; i < NT; ++i) {
 #if NR_G8P_ABLATE & 4
             asm volatile("" : : "v"(wf[ks][i]), "v"(xf[ks][jj]));
 #else
-            acc[i][2 * ph + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], xf[ks][jj], acc[i][2 * ph + jj], 0, 0, 0);
+            acc[i][MPP * ph + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], xf[ks][jj], acc[i][MPP * ph + jj], 0, 0, 0);
 #endif
           }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       if (!(NR_G8P_ABLATE & 1)) {
         // counted waits: everything but the N youngest pieces of this wave has landed (vmcnt counts in issue order)
-        if (ph == 2 && has1) { if (has2) wait_vm<4 + NB2>(); else wait_vm<4>(); }        // W(t+1) landed; A(t+1) [+ first part of W(t+2)] may fly
-        if (ph == 3 && has1) { if (has2) wait_vm<NT>(); else wait_vm<0>(); }             // A(t+1) landed; W(t+2) may fly
+        if (ph == NPH - 2 && has1) { if (has2) wait_vm<4 + W_BEFORE_LAST>(); else wait_vm<4>(); }   // W(t+1) landed; A(t+1) [+ part of W(t+2)] may fly
+        if (ph == NPH - 1 && has1) { if (has2) wait_vm<NT>(); else wait_vm<0>(); }                  // A(t+1) landed; W(t+2) may fly
       }
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -350,16 +359,23 @@ inline bool attr_needed(unsigned long long& mask) {
   return true;
 }
 
-template <int NT, bool TAPI>
-int launch_g8p(const NrGemmParams& p, int m_fast, hipStream_t stream) {
+template <int NT, bool TAPI, int NPH>
+int launch_g8p_n(const NrGemmParams& p, int m_fast, hipStream_t stream) {
   constexpr int BN = 64 * NT;
   constexpr size_t shm = (size_t)2 * (G8_BM + BN) * 128;
   static unsigned long long attr = 0;
   if (attr_needed(attr) &&
-      hipFuncSetAttribute((const void*)g8p_kernel<NT, TAPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return 20;
+      hipFuncSetAttribute((const void*)g8p_kernel<NT, TAPI, NPH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return 20;
   const unsigned grid = (unsigned)(((p.M + G8_BM - 1) / G8_BM) * ((p.N + BN - 1) / BN));
-  hipLaunchKernelGGL((g8p_kernel<NT, TAPI>), dim3(grid), dim3(512), shm, stream, p, m_fast);
+  hipLaunchKernelGGL((g8p_kernel<NT, TAPI, NPH>), dim3(grid), dim3(512), shm, stream, p, m_fast);
   return 0;
+}
+static int g8p_phases = -1;     // NR_G8P_PHASES: 4 (default) or 2 phases per k-tile where the instantiation exists (NT <= 4); nr_g8p_set_phases overrides
+template <int NT, bool TAPI>
+int launch_g8p(const NrGemmParams& p, int m_fast, hipStream_t stream) {
+  if (g8p_phases < 0) g8p_phases = getenv("NR_G8P_PHASES") ? atoi(getenv("NR_G8P_PHASES")) : 4;
+  if constexpr (NT <= 4) { if (g8p_phases == 2) return launch_g8p_n<NT, TAPI, 2>(p, m_fast, stream); }
+  return launch_g8p_n<NT, TAPI, 4>(p, m_fast, stream);
 }
 
 }  // namespace
@@ -367,6 +383,7 @@ int launch_g8p(const NrGemmParams& p, int m_fast, hipStream_t stream) {
 // 0 = not for this kernel; else NT (columns per tile / 64).  Pure function of the launch parameters (and of NR_G8P / NR_G8P_MIN_TILES).
 static int g8p_mode = -1;       // NR_G8P: 0 off (A/B), 1 heuristic (default), 2 whenever the shape is supported; nr_g8p_set_mode overrides (tests, A/B tools)
 extern "C" void nr_g8p_set_mode(int mode) { g8p_mode = mode; }
+extern "C" void nr_g8p_set_phases(int phases) { g8p_phases = phases == 2 ? 2 : 4; }
 extern "C" int nr_g8p_plan(const NrGemmParams* pp) {
   const NrGemmParams& p = *pp;
   if (g8p_mode < 0) g8p_mode = getenv("NR_G8P") ? atoi(getenv("NR_G8P")) : 1;

@@ -59,6 +59,11 @@ def g8p_mode(mode):
     _lib.load().nr_g8p_set_mode(int(mode))
 
 
+def g8p_phases(n):
+    """4 (default) or 2 phases per k-tile of the ping-pong kernel (A/B)."""
+    _lib.load().nr_g8p_set_phases(int(n))
+
+
 def ln_gemm(a, w, gamma, beta, bias=None, res=None, eps=1e-5, act=0):
     """out = Linear(LayerNorm(a)) with the LayerNorm folded into the GEMM (engine: ln_linear).  The folding of gamma / beta
     into (w_scaled, ln_c, bias_folded) is done here on the host exactly as engine.hip's w_ln_linear does."""

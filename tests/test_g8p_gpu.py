@@ -37,7 +37,10 @@ def _both(fn):
         new = fn().clone()
         new2 = fn()
         assert torch.equal(new, new2), "ping-pong kernel: two runs differ"
+        ops.g8p_phases(2)                  # the two-phase schedule (where instantiated) is the same arithmetic in the same order
+        assert torch.equal(new, fn()), "ping-pong kernel: 2 phases per k-tile differ from 4"
     finally:
+        ops.g8p_phases(4)
         ops.g8p_mode(1)
     return old, new
 
@@ -133,10 +136,13 @@ def test_many_repetitions_are_bit_reproducible(cuda):
     try:
         ops.g8p_mode(2)
         r1, r2 = ops.gemm(a, w).clone(), ops.conv3x3(x, wc, tap_inner=True).clone()
-        for i in range(100):
-            if i % 3 == 0:
-                big.mul_(1.0001)
-            assert torch.equal(ops.gemm(a, w), r1), f"gemm repetition {i}"
-            assert torch.equal(ops.conv3x3(x, wc, tap_inner=True), r2), f"conv repetition {i}"
+        for phases in (4, 2):
+            ops.g8p_phases(phases)
+            for i in range(100):
+                if i % 3 == 0:
+                    big.mul_(1.0001)
+                assert torch.equal(ops.gemm(a, w), r1), f"gemm repetition {i} ({phases} phases)"
+                assert torch.equal(ops.conv3x3(x, wc, tap_inner=True), r2), f"conv repetition {i} ({phases} phases)"
     finally:
+        ops.g8p_phases(4)
         ops.g8p_mode(1)

@@ -27,18 +27,23 @@ def time_fn(fn, n=10):
 
 
 def ab(name, fn, flop):
-    t = {0: [], 2: []}
-    for mode in (0, 2):
+    arms = ((0, 4), (2, 4), (2, 2))          # (mode, phases per k-tile)
+    t = {a: [] for a in arms}
+    for mode, ph in arms:
         ops.g8p_mode(mode)
+        ops.g8p_phases(ph)
         fn()
     torch.cuda.synchronize()
     for _ in range(7):
-        for mode in (0, 2):
+        for mode, ph in arms:
             ops.g8p_mode(mode)
-            t[mode].append(time_fn(fn))
+            ops.g8p_phases(ph)
+            t[(mode, ph)].append(time_fn(fn))
     ops.g8p_mode(1)
-    a, b = statistics.median(t[0]), statistics.median(t[2])
-    print(f"{name:58s} tiled {a:8.1f} us {flop / a / 1e6:7.1f} TF | ping-pong {b:8.1f} us {flop / b / 1e6:7.1f} TF | x{a / b:5.2f}", flush=True)
+    ops.g8p_phases(4)
+    a, b, c = (statistics.median(t[k]) for k in arms)
+    print(f"{name:52s} tiled {a:7.1f} us {flop / a / 1e6:6.0f} TF | ping-pong 4ph {b:7.1f} us {flop / b / 1e6:6.0f} TF x{a / b:4.2f} | 2ph {c:7.1f} us {flop / c / 1e6:6.0f} TF x{a / c:4.2f}",
+          flush=True)
 
 
 def main():
