@@ -314,7 +314,7 @@ const char* nr_net_op_desc(const nr_net* h, int32_t i);
 /* which GEMM kernel serves the big launches (gemm8p.hip, the 256-row ping-pong kernel): 0 never, 1 the shipped heuristic (default; env
  * NR_G8P), 2 whenever the shape is supported.  Process-wide; plan choices are read at nr_net_plan / launch time.  A/B tools and tests. */
 void nr_g8p_set_mode(int32_t mode);
-/* phases per k-tile of that kernel: 4 (default) or 2 (half the barriers; tiles of <= 256 columns only).  A/B tools and tests (env NR_G8P_PHASES). */
+/* phases per k-tile of that kernel: 2 (default; tiles of <= 256 columns only) or 4.  A/B tools and tests (env NR_G8P_PHASES). */
 void nr_g8p_set_phases(int32_t phases);
 
 /* Leaf-module handles (kinds NR_KIND_LEAF_TRANSFORMER3D / NR_KIND_LEAF_TEMPORAL): Transformer3DModel.forward (attention.py:95-142) or

@@ -11,7 +11,9 @@
 //     barrier: while one group issues its MFMAs (a "phase" = 2 row tiles x NT x 2 k-steps = 4 NT MFMAs, setprio 1), its SIMD partners read
 //     fragments from LDS and issue LDS-DMA, then they swap.  The matrix pipe of a SIMD always has one wave feeding it
 //     (MI355X_MICROARCH.md "Two waves per SIMD" item 9; cdna_hip_programming.md 5.5 T3+T4+T5).
-//   * k-tile t is computed in 4 phases.  Weight fragments (NT x 2) are read ONCE per k-tile in phase 0 and stay in registers, activation
+//   * k-tile t is computed in NPH = 2 (default for tiles of <= 256 columns) or 4 phases; the description below is the 4-phase form, the
+//     2-phase form merges phases {0,1} and {2,3} (half the barriers; the weight region is then re-staged one interval after its last read,
+//     so the weight-fragment reads are retired by an lgkmcnt(0) BEFORE the phase's first barrier).  Weight fragments (NT x 2) are read ONCE per k-tile in phase 0 and stay in registers, activation
 //     fragments (2 x 2) per phase.  LDS-DMA (asm global_load_lds_dwordx4, 1 KiB pieces, XOR swizzle on the SOURCE address) is spread over
 //     the phases, two or three pieces per wave and phase: phases 0-1 stage the activation half-tile of k-tile t+1 (each group stages and
 //     reads ITS OWN 128 rows), phases 2-3 the weight tile of k-tile t+2 -- the weight region of the current buffer is free by then,
@@ -370,10 +372,11 @@ int launch_g8p_n(const NrGemmParams& p, int m_fast, hipStream_t stream) {
   hipLaunchKernelGGL((g8p_kernel<NT, TAPI, NPH>), dim3(grid), dim3(512), shm, stream, p, m_fast);
   return 0;
 }
-static int g8p_phases = -1;     // NR_G8P_PHASES: 4 (default) or 2 phases per k-tile where the instantiation exists (NT <= 4); nr_g8p_set_phases overrides
+static int g8p_phases = -1;     // NR_G8P_PHASES: 2 (default where the instantiation exists, NT <= 4: never slower in tools/g8p_ab.py, GEGLU 1.08-1.16x
+                                // instead of 1.00-1.08x) or 4 phases per k-tile; nr_g8p_set_phases overrides
 template <int NT, bool TAPI>
 int launch_g8p(const NrGemmParams& p, int m_fast, hipStream_t stream) {
-  if (g8p_phases < 0) g8p_phases = getenv("NR_G8P_PHASES") ? atoi(getenv("NR_G8P_PHASES")) : 4;
+  if (g8p_phases < 0) g8p_phases = getenv("NR_G8P_PHASES") ? atoi(getenv("NR_G8P_PHASES")) : 2;
   if constexpr (NT <= 4) { if (g8p_phases == 2) return launch_g8p_n<NT, TAPI, 2>(p, m_fast, stream); }
   return launch_g8p_n<NT, TAPI, 4>(p, m_fast, stream);
 }
@@ -428,8 +431,13 @@ extern "C" int nr_g8p_plan(const NrGemmParams* pp) {
     if (score > best_score) { best_score = score; best = nt; }
   }
   if (mode != 2 && best_score < 0.70) return 0;
-  static const int geglu_ok = getenv("NR_G8P_GEGLU") ? atoi(getenv("NR_G8P_GEGLU")) : 0;
-  if (mode != 2 && p.geglu && !geglu_ok) return 0;
+  // GEGLU projections (gate evaluated in the epilogue, all eight waves side by side): 1.07-1.16x on the two-phase schedule from 512 tiles
+  // with K >= 1024 or M >= 32768; the B = 1 U-Net's M = 8192 case loses (0.96x)
+  static const int geglu_ok = getenv("NR_G8P_GEGLU") ? atoi(getenv("NR_G8P_GEGLU")) : 1;
+  if (mode != 2 && p.geglu) {
+    const long long tiles = best ? ntm * ((p.N + 64 * best - 1) / (64 * best)) : 0;
+    if (!geglu_ok || tiles < 512 || !(nk >= 16 || Mp >= 32768)) return 0;
+  }
   return best;
 }
 

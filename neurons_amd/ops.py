@@ -60,7 +60,7 @@ def g8p_mode(mode):
 
 
 def g8p_phases(n):
-    """4 (default) or 2 phases per k-tile of the ping-pong kernel (A/B)."""
+    """2 (default where instantiated) or 4 phases per k-tile of the ping-pong kernel (A/B)."""
     _lib.load().nr_g8p_set_phases(int(n))
 
 

@@ -37,10 +37,10 @@ def _both(fn):
         new = fn().clone()
         new2 = fn()
         assert torch.equal(new, new2), "ping-pong kernel: two runs differ"
-        ops.g8p_phases(2)                  # the two-phase schedule (where instantiated) is the same arithmetic in the same order
-        assert torch.equal(new, fn()), "ping-pong kernel: 2 phases per k-tile differ from 4"
+        ops.g8p_phases(4)                  # the four-phase schedule is the same arithmetic in the same order as the (default) two-phase one
+        assert torch.equal(new, fn()), "ping-pong kernel: 4 phases per k-tile differ from 2"
     finally:
-        ops.g8p_phases(4)
+        ops.g8p_phases(2)
         ops.g8p_mode(1)
     return old, new
 
@@ -144,5 +144,5 @@ def test_many_repetitions_are_bit_reproducible(cuda):
                 assert torch.equal(ops.gemm(a, w), r1), f"gemm repetition {i} ({phases} phases)"
                 assert torch.equal(ops.conv3x3(x, wc, tap_inner=True), r2), f"conv repetition {i} ({phases} phases)"
     finally:
-        ops.g8p_phases(4)
+        ops.g8p_phases(2)
         ops.g8p_mode(1)

@@ -40,7 +40,7 @@ def ab(name, fn, flop):
             ops.g8p_phases(ph)
             t[(mode, ph)].append(time_fn(fn))
     ops.g8p_mode(1)
-    ops.g8p_phases(4)
+    ops.g8p_phases(2)
     a, b, c = (statistics.median(t[k]) for k in arms)
     print(f"{name:52s} tiled {a:7.1f} us {flop / a / 1e6:6.0f} TF | ping-pong 4ph {b:7.1f} us {flop / b / 1e6:6.0f} TF x{a / b:4.2f} | 2ph {c:7.1f} us {flop / c / 1e6:6.0f} TF x{a / c:4.2f}",
           flush=True)
