@@ -36,7 +36,7 @@ PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
 
-CURRENT_ROUND = "r03"      # a committed traffic file of an earlier round is reported as historical
+CURRENT_ROUND = "r04"      # a committed traffic file of an earlier round is reported as historical
 
 
 def parse():
@@ -536,7 +536,7 @@ def main():
                          "launches_per_ddim_step": round(ig_n, 1), "ms_per_ddim_step": round(ig_ms, 3),
                          # kernels enqueued per DDIM step, both networks (split-K reduces, multi-pass norms and the time-embedding MLP counted
                          # per kernel; + set_timesteps and the CFG/DDIM update; SparseCtrl's share is 1/grp of an evaluation)
-                         "whole_step_launches": round(sum(pu[k]["launches"] + pc[k]["launches"] for k in pu) + 2 + 1.0 / grp, 1),
+                         "whole_step_launches_sparsectrl_counted_at_1_over_group": round(sum(pu[k]["launches"] + pc[k]["launches"] for k in pu) + 2 + 1.0 / grp, 1),
                          "sparsectrl_steps_per_evaluation": grp,
                          "algorithmic_tflop_per_ddim_step": round(ig_fl / 1e12, 3),
                          "per_class_ms_per_ddim_step": breakdown,

@@ -256,6 +256,15 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p) {
     qf[ks] = dim0 < p.d ? *(const bf16x8*)(p.q + qbase + (long long)qrow_c * p.q_seq + dim0) : zero8;
   }
 
+  // d = 40 / 48 (DK = 2, DT = 3): the second k-step of K Q^T covers dims 32..47 only, so it runs on v_mfma_f32_16x16x16_bf16 (K = 16: half the
+  // matrix-pipe cycles of the 32-deep form, whose upper 16 dims would multiply zeros): lane group g supplies dims 32 + 4g .. 32 + 4g + 3
+  constexpr bool K48 = !FP8 && DK == 2 && DT == 3;
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  s16x4 qf4 = {0, 0, 0, 0};
+  if constexpr (K48) {
+    const int dim0 = 32 + 4 * g;
+    if (dim0 < p.d) qf4 = *(const s16x4*)(p.q + qbase + (long long)qrow_c * p.q_seq + dim0);
+  }
   long qf8[DK];
   if constexpr (FP8) {
 #pragma unroll
@@ -341,6 +350,13 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p) {
       s[t] = zacc;
 #pragma unroll
       for (int ks = 0; ks < DK; ++ks) {
+        if constexpr (K48) {
+          if (ks == 1) {       // dims 32 + 4g ..: 8 bytes of chunk 4 + (g >> 1) of the swizzled K row (pad dims >= d are zero in the image)
+            const s16x4 kf4 = *(const s16x4*)(sk + (16 * t + c) * KSK + ((((4 + (g >> 1)) ^ (c & 7)) << 3) + ((g & 1) << 2)));
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kf4, qf4, s[t], 0, 0, 0);
+            continue;
+          }
+        }
         const bf16x8 kf = KSWZ ? *(const bf16x8*)(sk + (16 * t + c) * KSK + (((ks * 4 + g) ^ (c & 7)) << 3))
                                : *(const bf16x8*)(sk + (16 * t + c) * KSK + ks * 32 + g * 8);
         if constexpr (FP8) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(to_fp8x8(kf), qf8[ks], s[t], 0, 0, 0);
