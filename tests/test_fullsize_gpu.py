@@ -192,6 +192,35 @@ def test_c3_96x96_forward_vs_oracle(c3, cuda):
     assert rel <= FWD_REL_L2_SGM96 and psnr > 40, (rel, psnr)
 
 
+def test_c3_four_keyframes_per_euler_loop_vs_single_calls_and_oracle(c3, cuda):
+    """Several keyframes per call (utils.unclip_recon's num_samples, utils.py:302-303,316-321; bench.py --workload keyframe --batch B): B = 4
+    keyframes = CFG batch 8 in ONE Euler loop at unclip6 width, 64x64 latent, 10 steps, against four B = 1 loops on the same handle (the
+    weight-streaming M = 512 GEMMs become M = 2048: another launch plan, so two bf16 roundings of the same arithmetic: >= 40 dB, rel-L2 <= 5e-2,
+    the bar of the batched video test) and keyframe 0 / 3 against the fp32 oracle (loop bar)."""
+    from neurons_amd.sgm import EulerEDMSampler
+    S, g = c3["S"], c3["g"]
+    B, steps = 4, 10
+    z = torch.randn(B, 4, 64, 64, generator=g, device=cuda)
+    c = {"crossattn": torch.randn(B, 256, 1664, generator=g, device=cuda), "vector": torch.randn(B, 1024, generator=g, device=cuda)}
+    uc = {"crossattn": torch.randn(B, 256, 1664, generator=g, device=cuda), "vector": c["vector"].clone()}
+    sampler = EulerEDMSampler(num_steps=steps, scale=5.0)
+    both = sampler(c3["net"], z, cond=c, uc=uc).clone()
+    assert torch.isfinite(both).all() and tuple(both.shape) == (B, 4, 64, 64)
+    worst_db, worst_rel = 1e9, 0.0
+    for i in range(B):
+        ci = {k: v[i:i + 1] for k, v in c.items()}
+        ui = {k: v[i:i + 1] for k, v in uc.items()}
+        one = sampler(c3["net"], z[i:i + 1], cond=ci, uc=ui)
+        rel, psnr = metrics(f"C3 B=4: keyframe {i} of the batched Euler loop vs the same keyframe alone ({steps} steps)", both[i:i + 1], one)
+        worst_db, worst_rel = min(worst_db, psnr), max(worst_rel, rel)
+        if i in (0, B - 1):
+            with torch.no_grad():
+                want = S.euler_edm_sample(c3["sd"], c3["cfg"], z[i:i + 1], ci, ui, steps, 5.0)
+            r2, p2 = metrics(f"C3 B=4: keyframe {i} of the batched Euler loop vs the fp32 oracle", both[i:i + 1], want)
+            assert p2 >= LOOP_PSNR_DB and r2 <= LOOP_REL_L2, (i, p2, r2)
+    assert worst_db >= 40.0 and worst_rel <= 5e-2, (worst_db, worst_rel)
+
+
 def test_a18_unclip_recon_harness_matches_reference_fixture(cuda):
     """utils.unclip_recon (utils.py:302-350) end to end in HIP: unclip_sample (noised_z, offset noise, uc tokens, Euler/CFG)
     -> decode_keyframe (first-stage decode, clamp(x*.8+.2)); expected pixels from the reference's own function."""
