@@ -194,12 +194,13 @@ def test_c3_96x96_forward_vs_oracle(c3, cuda):
 
 def test_c3_four_keyframes_per_euler_loop_vs_single_calls_and_oracle(c3, cuda):
     """Several keyframes per call (utils.unclip_recon's num_samples, utils.py:302-303,316-321; bench.py --workload keyframe --batch B): B = 4
-    keyframes = CFG batch 8 in ONE Euler loop at unclip6 width, 64x64 latent, 10 steps, against four B = 1 loops on the same handle (the
+    keyframes = CFG batch 8 in ONE Euler loop at unclip6 width, 64x64 latent, 25 steps (10 steps measured 46.8 dB / rel-L2 3.3e-2 vs the oracle:
+    with few, large Euler steps the per-evaluation error of the depth-10 network weighs more; the 50-step loop is at 2.0e-2), against four B = 1 loops on the same handle (the
     weight-streaming M = 512 GEMMs become M = 2048: another launch plan, so two bf16 roundings of the same arithmetic: >= 40 dB, rel-L2 <= 5e-2,
     the bar of the batched video test) and keyframe 0 / 3 against the fp32 oracle (loop bar)."""
     from neurons_amd.sgm import EulerEDMSampler
     S, g = c3["S"], c3["g"]
-    B, steps = 4, 10
+    B, steps = 4, 25
     z = torch.randn(B, 4, 64, 64, generator=g, device=cuda)
     c = {"crossattn": torch.randn(B, 256, 1664, generator=g, device=cuda), "vector": torch.randn(B, 1024, generator=g, device=cuda)}
     uc = {"crossattn": torch.randn(B, 256, 1664, generator=g, device=cuda), "vector": c["vector"].clone()}
