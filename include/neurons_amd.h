@@ -316,6 +316,9 @@ const char* nr_net_op_desc(const nr_net* h, int32_t i);
 void nr_g8p_set_mode(int32_t mode);
 /* phases per k-tile of that kernel: 2 (default; tiles of <= 256 columns only) or 4.  A/B tools and tests (env NR_G8P_PHASES). */
 void nr_g8p_set_phases(int32_t phases);
+/* waves per 128-row workgroup of the fused FeedForward kernel (ffpanel.hip): 8 (default: 16-row waves, two per SIMD) or 4 (32-row waves,
+ * one per SIMD; the round-3 form).  Results are bit-identical between the two.  A/B tools and tests (env NR_FF_WAVES). */
+void nr_ff_set_waves(int32_t waves);
 
 /* Leaf-module handles (kinds NR_KIND_LEAF_TRANSFORMER3D / NR_KIND_LEAF_TEMPORAL): Transformer3DModel.forward (attention.py:95-142) or
  * VanillaTemporalModule.forward (motion_module.py:79-86 -> TemporalTransformer3DModel.forward :134-158) on the reference's own tensors,

@@ -103,6 +103,7 @@ SYMBOLS = {
     "nr_net_read_tap": (_I32, [_VP, _I32, _VP, _I64, C.POINTER(_I32), C.POINTER(_I32)]),
     "nr_g8p_set_mode": (None, [_I32]),
     "nr_g8p_set_phases": (None, [_I32]),
+    "nr_ff_set_waves": (None, [_I32]),
     "nr_net_num_ops": (_I32, [_VP]),
     "nr_net_op_desc": (C.c_char_p, [_VP, _I32]),
     "nr_leaf_forward": (_I32, [_VP, _VP, _VP, _VP, _I32, _VP]),

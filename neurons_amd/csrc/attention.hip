@@ -212,12 +212,25 @@ __device__ __forceinline__ float rows_sum(float v) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// acc += A B with the accumulator TIED (vDst = SrcC).  In the ONES instantiation hipcc 7.2 otherwise allocates the third accumulator as a
+// v[2:5] -> v[0:3] -> v[2:5] chain (destination partially overlapping the SrcC the previous MFMA wrote) with no wait states between the
+// dependent MFMAs, and the kernel returns wrong sums on gfx950 (tools/check_mfma_overlap.py scans the shipped ISA for that pattern).
+// Distances that make the missing hazard bookkeeping of an asm MFMA safe here: its operands come from v_cvt_pk / ds_read_tr + s_waitcnt, its
+// result is next touched by VALU one softmax later (the rescale) or after the loop's barrier.
+__device__ __forceinline__ void mfma_bf16_tied(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+  asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+
 // LDS images of a 64-key tile.  K (d <= 64): [64][64] bf16, 128-byte rows with the 16-byte chunk index XOR-swizzled by (key & 7): the
 // b128 fragment reads (lane = key 16t + c, chunk 4ks + g) are conflict-free, the layout gemm.hip uses for its operand tiles; larger
 // heads keep padded rows of 32 DK + 8 elements.  V: rows of KSV elements with KSV = 16 (mod 32), so the 8 rows a half-wave touches in
 // one ds_read_b64_tr_b16 start 8 banks apart (conflict-free transpose reads).  Pad columns are zero (written once).
-template <int DK, int DT, bool FP8 = false>
+// ONES (d = 40 in its 48-wide V image only): pad column d of the V image holds 1.0 for every key, so row d of O^T = V^T P^T IS the softmax
+// denominator: the sum of the probabilities exactly as the matrix pipe sees them (bf16 / e4m3, fp32 accumulation), rescaled with the
+// accumulator for free.  It replaces 17 dependent v_add_f32 per key tile in a loop whose bound is the vector issue port.
+template <int DK, int DT, bool FP8 = false, bool ONES = false>
 __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p) {
+  static_assert(!ONES || (DK == 2 && DT == 3), "the ones column lives in the pad of the 48-wide image of d = 40");
   constexpr bool KSWZ = DK <= 2;
   constexpr int KSK = KSWZ ? 64 : DK * 32 + 8;
   constexpr int KSV = (DT * 16) % 32 == 16 ? DT * 16 : DT * 16 + 16;
@@ -330,6 +343,9 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p) {
   // columns): the fragment reads below need no head-dim predicate (a predicated 16-byte LDS read costs an exec-mask branch each)
   for (int id = tid; id < 2 * TILE2 / 8; id += 256) *(bf16x8*)(lds + id * 8) = zero8;
   __syncthreads();
+  if constexpr (ONES) {                        // column d of both V images (the staging below never touches pad columns)
+    if (tid < 2 * KT2) lds[(tid / KT2) * TILE2 + TILEK + (tid % KT2) * KSV + p.d] = (bf16)1.0f;
+  }
   const int ntile = (p.Lk + KT2 - 1) / KT2;
   load_regs(0);
   write_lds(0);
@@ -396,7 +412,7 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], sl2, -m_new));   // masked keys: exp2(-huge) = 0
-        rs += e;
+        if constexpr (!ONES) rs += e;
         if constexpr (FP8) pe[t >> 1][(t & 1) * 4 + r] = e * 256.0f;
         else pf[t >> 1][(t & 1) * 4 + r] = (bf16)e;
       }
@@ -405,12 +421,12 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p) {
     // l_i stays a per-lane partial sum (this lane's 16 keys of every tile); the four rows are added once after the loop
     if (__builtin_amdgcn_ballot_w64(m_new != m_i) != 0ull) {
       const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
-      l_i *= alpha;
+      if constexpr (!ONES) l_i *= alpha;
 #pragma unroll
       for (int i = 0; i < DT; ++i) acc[i] *= alpha;
       m_i = m_new;
     }
-    l_i += rs;
+    if constexpr (!ONES) l_i += rs;
     // ---- O^T += V^T P^T ; k-slot j of step u -> key 32u + (j<4 ? 4g+j : 16+4g+j-4) ----
 #pragma unroll
     for (int i = 0; i < DT; ++i) {
@@ -423,6 +439,7 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
         if constexpr (FP8) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(to_fp8x8(vf), pf8[u], acc[i], 0, 0, 0);
+        else if constexpr (ONES) mfma_bf16_tied(acc[i], vf, pf[u]);
         else acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u], acc[i], 0, 0, 0);
       }
     }
@@ -430,9 +447,12 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p) {
     __syncthreads();
   }
 
-  const float l_all = rows_sum(l_i);          // all lanes active here
+  // all lanes active here.  ONES: dv = 40 = 16 * 2 + 4 * 2 + 0 is element 0 of acc[2] in lane group g = 2 of the query's column c
+  float l_all;
+  if constexpr (ONES) l_all = __shfl(acc[2][0], 32 + c, 64);
+  else l_all = rows_sum(l_i);
   if (qrow < p.Lq) {
-    const float inv = (FP8 ? 1.0f / 256.0f : 1.0f) / l_all;
+    const float inv = (FP8 && !ONES ? 1.0f / 256.0f : 1.0f) / l_all;      // ONES + FP8: the 256 of the scaled probabilities is in l_all too
     bf16* op = p.out + obase + (long long)qrow * p.o_seq;
 #pragma unroll
     for (int i = 0; i < DT; ++i) {
@@ -460,10 +480,23 @@ int launch_attn(const NrAttnParams& p, hipStream_t stream) {
     if (!(attr_mask >> (dev & 63) & 1ull)) {
       (void)hipFuncSetAttribute((const void*)attn_fwd_shared_kernel<DK, DT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
       (void)hipFuncSetAttribute((const void*)attn_fwd_shared_kernel<DK, DT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+      if constexpr (DK == 2 && DT == 3) {
+        (void)hipFuncSetAttribute((const void*)attn_fwd_shared_kernel<DK, DT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_shared_kernel<DK, DT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+      }
       attr_mask |= 1ull << (dev & 63);
     }
     const int qblocks = (p.Lq + 63) / 64;
     const unsigned blocks = (unsigned)((long long)p.nbatch * p.heads * qblocks);
+    if constexpr (DK == 2 && DT == 3) {
+      // d = 40: the denominator rides on the pad column of V (NR_ATTN_ROWSUM=adds keeps the VALU sums: A/B only)
+      static const bool ones = !(getenv("NR_ATTN_ROWSUM") && getenv("NR_ATTN_ROWSUM")[0] == 'a');
+      if (ones && p.d == 40) {
+        if (p.fp8) hipLaunchKernelGGL((attn_fwd_shared_kernel<DK, DT, true, true>), dim3(blocks), dim3(256), shm, stream, p);
+        else hipLaunchKernelGGL((attn_fwd_shared_kernel<DK, DT, false, true>), dim3(blocks), dim3(256), shm, stream, p);
+        return 0;
+      }
+    }
     if (p.fp8) hipLaunchKernelGGL((attn_fwd_shared_kernel<DK, DT, true>), dim3(blocks), dim3(256), shm, stream, p);
     else hipLaunchKernelGGL((attn_fwd_shared_kernel<DK, DT, false>), dim3(blocks), dim3(256), shm, stream, p);
     return 0;

@@ -39,14 +39,14 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 
 constexpr int FF_C = 320;
-constexpr int FF_ROWS = 128;                 // rows per workgroup (4 waves x 32)
+constexpr int FF_ROWS = 128;                 // rows per workgroup: 4 waves x 32 rows (MT = 2) or 8 waves x 16 rows (MT = 1)
 constexpr int FF_SUB = 64 * 64;              // elements of one [64][64] sub-tile
 constexpr int FF_STAGE = 5 * FF_SUB;         // elements of one stage (40 KiB)
 constexpr int FF_NS = 3;                     // ring depth
 constexpr int FF_TSTAGES = FF_C / 64;        // 5: t-part of the second GEMM
 constexpr int FF_PAIRS = (4 * FF_C) / 64;    // 20: pairs of W1 chunks (64 hidden units per pair)
 constexpr int FF_NSTAGES = FF_TSTAGES + 3 * FF_PAIRS;   // 65
-constexpr int FF_DMA = FF_STAGE * 2 / (4 * 1024);       // 10 LDS-DMA instructions per wave and stage
+constexpr int FF_PIECES = FF_STAGE * 2 / 1024;          // 40 LDS-DMA pieces (1 KiB) per stage: 10 per wave with 4 waves, 5 with 8
 
 struct NrFFParams {
   const bf16* t; int ldt;        // [M][C] residual stream inside the transformer (pre-LayerNorm)
@@ -66,8 +66,16 @@ struct NrFFParams {
 // exact-erf GELU gate times the value, two outputs at a time (Abramowitz-Stegun 7.1.25 as gelu_erf_fast of common.h)
 __device__ __forceinline__ float geglu1(float v, float g) { return v * gelu_erf_fast(g); }
 
-__global__ __launch_bounds__(256) void ff_fused_kernel(NrFFParams p) {
+// MT = 16-row tiles per wave.  MT = 2: four waves, one per SIMD (round 3).  MT = 1 (round 4): EIGHT waves of 16 rows, two per SIMD: the same
+// 128-row workgroup, weight stream and LDS ring, but the matrix pipe of a SIMD now has a second wave to take MFMAs from while the first is in
+// its GELU / packing VALU work (round 3 measured the one-wave form issue-bound: 83 k MFMA + 71 k VALU + 59 k wait cycles, nothing overlapping).
+// Every weight fragment read from LDS then feeds one MFMA instead of two (the LDS array becomes as busy as the matrix pipe), which is the price.
+template <int MT>
+__global__ __launch_bounds__(MT == 2 ? 256 : 512, MT == 2 ? 1 : 2) void ff_fused_kernel(NrFFParams p) {
   constexpr int C = FF_C, KS = C / 32, NT2 = C / 16;       // 10 k-steps of the panel, 20 16-column groups of the output
+  constexpr int NW = FF_ROWS / (16 * MT);                  // waves per workgroup
+  constexpr int FF_DMA = FF_PIECES / NW;                   // LDS-DMA instructions per wave and stage
+  constexpr int NTHR = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) bf16 smem[];   // FF_NS stages, then b1 (8C floats)
 
   const int tid = threadIdx.x;
@@ -101,13 +109,13 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(NrFFParams p) {
   // the net.0 bias (8C floats) lives in LDS behind the ring: a global load inside the stage loop would make hipcc wait for it with a
   // vmcnt that also drains the LDS-DMA issued before it
   float* sB1 = reinterpret_cast<float*>(smem + FF_NS * FF_STAGE);
-  for (int i = tid * 4; i < 8 * C; i += 256 * 4) *(f32x4*)(sB1 + i) = *(const f32x4*)(p.b1 + i);
+  for (int i = tid * 4; i < 8 * C; i += NTHR * 4) *(f32x4*)(sB1 + i) = *(const f32x4*)(p.b1 + i);
 
-  // ---- the row panel: lane holds row (16 mt + fr) of its wave's 32 rows, k = 32 ks + 8 fg .. +7 ----
-  const int mrow0 = blockIdx.x * FF_ROWS + wave * 32;
-  bf16x8 xb[2][KS];
+  // ---- the row panel: lane holds row (16 mt + fr) of its wave's 16 MT rows, k = 32 ks + 8 fg .. +7 ----
+  const int mrow0 = blockIdx.x * FF_ROWS + wave * (16 * MT);
+  bf16x8 xb[MT][KS];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     int m = mrow0 + 16 * mt + fr;
     m = m < p.M ? m : p.M - 1;
     const bf16* ap = p.t + (size_t)m * p.ldt + 8 * fg;
@@ -116,11 +124,11 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(NrFFParams p) {
   }
   __syncthreads();      // b1 is visible to every wave before the first chunk (the stage barriers are raw s_barrier)
 
-  f32x4 oacc[NT2][2];
+  f32x4 oacc[NT2][MT];
 #pragma unroll
   for (int nt = 0; nt < NT2; ++nt)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) oacc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt) oacc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- stage sequencing: ring slot and waits are runtime values, everything that indexes registers is unrolled ----
   int s = 0, ring = 0;
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(NrFFParams p) {
   };
   // piece i of stage s + 2 goes out behind MFMA group i of stage s: spreads the ~100-cycle issue cost of an LDS-DMA piece over the stage
   // instead of stalling its head
-  auto prefetch_piece = [&](int i) { if (!(p.dbg & 4)) glds16(pf_src + i * 1024, pf_dst + (unsigned)(i * 1024)); };
+  auto prefetch_piece = [&](int i) { if (i < FF_DMA && !(p.dbg & 4)) glds16(pf_src + i * 1024, pf_dst + (unsigned)(i * 1024)); };
   auto stage_end = [&]() { ++s; ring = ring + 1 == FF_NS ? 0 : ring + 1; };
 
   auto frag_n320 = [&](const bf16* sW, int nt, int ks2) {
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(NrFFParams p) {
   // one 4-nt group of a [320 n][64 k] stage: 4 fragment reads (issued one group ahead by the caller) -> 8 MFMAs
   // out += A(stage [320 n][64 k]) x B(b0 | b1 per mt): 10 groups of (4 reads, 8 MFMAs); EPI(grp) is VALU work the caller wants
   // interleaved with group grp's MFMAs (the previous chunk's GEGLU epilogue)
-  auto gemm_n320 = [&](const bf16* sW, const bf16x8 (&b0)[2], const bf16x8 (&b1)[2], auto&& epi) {
+  auto gemm_n320 = [&](const bf16* sW, const bf16x8 (&b0)[MT], const bf16x8 (&b1)[MT], auto&& epi) {
     bf16x8 fa[4], fb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) fa[i] = frag_n320(sW, i, 0);
@@ -172,12 +180,12 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(NrFFParams p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int nt = 4 * q + i;
-        oacc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[i], ks2 ? b1[0] : b0[0], oacc[nt][0], 0, 0, 0);
-        oacc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[i], ks2 ? b1[1] : b0[1], oacc[nt][1], 0, 0, 0);
-      }
-      // one MFMA, then the VALU / transcendental instructions that fit under it, eight times
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+        for (int mt = 0; mt < MT; ++mt) oacc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[i], ks2 ? b1[mt] : b0[mt], oacc[nt][mt], 0, 0, 0);
+      }
+      // one MFMA, then the VALU / transcendental instructions that fit under it, once per MFMA of the group
+#pragma unroll
+      for (int i = 0; i < 4 * MT; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x402, 4, 0);
       }
@@ -190,8 +198,9 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(NrFFParams p) {
 #pragma unroll
   for (int ts = 0; ts < FF_TSTAGES; ++ts) {
     const bf16* sW = stage_begin();
-    const bf16x8 b0[2] = {xb[0][2 * ts], xb[1][2 * ts]};
-    const bf16x8 b1[2] = {xb[0][2 * ts + 1], xb[1][2 * ts + 1]};
+    bf16x8 b0[MT], b1[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { b0[mt] = xb[mt][2 * ts]; b1[mt] = xb[mt][2 * ts + 1]; }
     gemm_n320(sW, b0, b1, no_epi);
     stage_end();
   }
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(NrFFParams p) {
   // kernel rounds; gamma / beta come from global memory once (the two stages in flight are simply waited for here) ----
   {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
       float sm = 0.f;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
@@ -233,11 +242,12 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(NrFFParams p) {
   }
 
   // W1 chunk: acc = b1 + xn . W1[chunk]^T.  EPI(ks) = VALU work interleaved with k-step ks (the previous chunk's GEGLU epilogue)
-  auto gemm_w1 = [&](const bf16* sW, int chunk, f32x4 (&acc)[4][2], auto&& epi) {
+  auto gemm_w1 = [&](const bf16* sW, int chunk, f32x4 (&acc)[4][MT], auto&& epi) {
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const f32x4 bv = *(const f32x4*)(sB1 + chunk * 64 + 16 * nt + 4 * fg);      // lane's 4 columns of tile nt: the bias is the C operand
-      acc[nt][0] = bv; acc[nt][1] = bv;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = bv;
     }
     auto read_w = [&](bf16x8 (&wf)[4], int ks) {
       const int t = ks >> 1, k2 = ks & 1;
@@ -261,19 +271,20 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(NrFFParams p) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[nt], xb[mt][ks], acc[nt][mt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[nt], xb[mt][ks], acc[nt][mt], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < 4 * MT; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x402, 4, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  // GEGLU epilogue of one chunk, cut into 8 slices of 2 outputs: slice i -> (mt = i >> 2, h = (i >> 1) & 1, e0 = 2 (i & 1)).
+  // GEGLU epilogue of one chunk, cut into 4 MT slices of 2 outputs: slice i -> (mt = i >> 2, h = (i >> 1) & 1, e0 = 2 (i & 1)).
   // Lane holds rows (16 mt + fr); value tile 2 h, gate tile 2 h + 1, columns 4 fg + e.
-  float gt[2][8];
-  auto epi_slice = [&](const f32x4 (&acc)[4][2], int i) {
+  constexpr int NSL = 4 * MT;
+  float gt[MT][8];
+  auto epi_slice = [&](const f32x4 (&acc)[4][MT], int i) {
     const int mt = i >> 2, h = (i >> 1) & 1, e0 = 2 * (i & 1);
     float r0 = geglu1(acc[2 * h][mt][e0], acc[2 * h + 1][mt][e0]);
     float r1 = geglu1(acc[2 * h][mt][e0 + 1], acc[2 * h + 1][mt][e0 + 1]);
@@ -288,8 +299,8 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(NrFFParams p) {
     for (int e = 0; e < 8; ++e) dst[e] = (bf16)gt[mt][e];
   };
 
-  bf16x8 gB[2][2];            // [k-step of the g-piece = W1 chunk parity][mt]
-  f32x4 accA[4][2], accB[4][2];
+  bf16x8 gB[2][MT];           // [k-step of the g-piece = W1 chunk parity][mt]
+  f32x4 accA[4][MT], accB[4][MT];
   for (int q = 0; q < FF_PAIRS; ++q) {
     int pair = pair0 + q;
     pair = pair >= FF_PAIRS ? pair - FF_PAIRS : pair;
@@ -302,9 +313,9 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(NrFFParams p) {
     // ---- chunk B: MFMAs with chunk A's GEGLU epilogue interleaved (slices 0..7 behind k-steps 0..7) ----
     {
       const bf16* sW = stage_begin();
-      gemm_w1(sW, 2 * pair + 1, accB, [&](int ks) { if (ks < 8) epi_slice(accA, ks); });
-      pack_g(gB[0][0], 0);
-      pack_g(gB[0][1], 1);
+      gemm_w1(sW, 2 * pair + 1, accB, [&](int ks) { if (ks < NSL) epi_slice(accA, ks); });
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) pack_g(gB[0][mt], mt);
       stage_end();
     }
     // ---- g-piece: out += g[:, 64 pair .. +63] . (Wpo Wff2)[:, same]^T.  k-step 0 (groups 0..4) needs chunk A only: chunk B's epilogue
@@ -326,17 +337,24 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(NrFFParams p) {
         }
         prefetch_piece(grp);
         __builtin_amdgcn_sched_barrier(0);
-        if (grp < 4) { epi_slice(accB, 2 * grp); epi_slice(accB, 2 * grp + 1); }
-        if (grp == 4) { pack_g(gB[1][0], 0); pack_g(gB[1][1], 1); }
+        // chunk B's slices ride on groups 0..3: two per group with 32-row waves, one per group with 16-row waves
+        if (grp < 4) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i) epi_slice(accB, MT * grp + i);
+        }
+        if (grp == 4) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) pack_g(gB[1][mt], mt);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int nt = 4 * qq + i;
-          oacc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[i], gB[ks2][0], oacc[nt][0], 0, 0, 0);
-          oacc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[i], gB[ks2][1], oacc[nt][1], 0, 0, 0);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) oacc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[i], gB[ks2][mt], oacc[nt][mt], 0, 0, 0);
         }
         if (grp < 4) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
+          for (int i = 0; i < 4 * MT; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x402, 8, 0);
           }
@@ -350,7 +368,7 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(NrFFParams p) {
   wait_vmcnt<0>();      // the tail's dummy pieces
   // ---- epilogue: out = x + bc + acc, lane holds rows (16 mt + fr), columns 16 nt + 4 fg .. +3 ----
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     const int m = mrow0 + 16 * mt + fr;
     if (m >= p.M) continue;
     const bf16* xr = p.x + (size_t)m * p.ldx + 4 * fg;
@@ -396,9 +414,11 @@ __global__ __launch_bounds__(256) void ff_stream_pack_kernel(const bf16* __restr
 }
 
 unsigned long long g_ff_attr = 0;
+int g_ff_waves = -1;       // NR_FF_WAVES: 8 (default: 16-row waves, two per SIMD) or 4 (the round-3 form); nr_ff_set_waves overrides (A/B, tests)
 
 }  // namespace
 
+extern "C" void nr_ff_set_waves(int waves) { g_ff_waves = waves == 4 ? 4 : 8; }
 extern "C" size_t nr_ff_stream_bytes(int C) { return C == FF_C ? (size_t)FF_NSTAGES * FF_STAGE * sizeof(bf16) : 0; }
 
 extern "C" int nr_ff_fused_eligible(int C, long long M) {
@@ -424,9 +444,13 @@ extern "C" int nr_launch_ff_fused(const bf16* t, int ldt, const bf16* x, int ldx
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!(g_ff_attr >> (dev & 63) & 1ull)) {
-    if (hipFuncSetAttribute((const void*)ff_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return 2;
+    if (hipFuncSetAttribute((const void*)ff_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return 2;
+    if (hipFuncSetAttribute((const void*)ff_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return 2;
     g_ff_attr |= 1ull << (dev & 63);
   }
-  hipLaunchKernelGGL(ff_fused_kernel, dim3((unsigned)((M + FF_ROWS - 1) / FF_ROWS)), dim3(256), shm, s, p);
+  if (g_ff_waves < 0) g_ff_waves = getenv("NR_FF_WAVES") ? atoi(getenv("NR_FF_WAVES")) : 8;
+  const unsigned grid = (unsigned)((M + FF_ROWS - 1) / FF_ROWS);
+  if (g_ff_waves == 4) hipLaunchKernelGGL(ff_fused_kernel<2>, dim3(grid), dim3(256), shm, s, p);
+  else hipLaunchKernelGGL(ff_fused_kernel<1>, dim3(grid), dim3(512), shm, s, p);
   return 0;
 }

@@ -64,6 +64,11 @@ def g8p_phases(n):
     _lib.load().nr_g8p_set_phases(int(n))
 
 
+def ff_waves(n):
+    """8 (default) or 4 waves per workgroup of the fused FeedForward kernel (A/B; bit-identical results)."""
+    _lib.load().nr_ff_set_waves(int(n))
+
+
 def ln_gemm(a, w, gamma, beta, bias=None, res=None, eps=1e-5, act=0):
     """out = Linear(LayerNorm(a)) with the LayerNorm folded into the GEMM (engine: ln_linear).  The folding of gamma / beta
     into (w_scaled, ln_c, bias_folded) is done here on the host exactly as engine.hip's w_ln_linear does."""

@@ -290,11 +290,8 @@ def test_sgm_sampler_recognises_only_the_canonical_denoiser_closure():
     assert rec(canonical) is None
 
 
-def test_shipped_library_contains_no_packed_fp32_valu_ops():
-    """The two-stream corruption of round 2 was bisected to the packed-fp32 code generation of norm.o (DESIGN 3c, profiles/r03_race_*) and
-    is NOT root-caused; the product's protection is the library-wide `-packed-fp32-ops` target feature (csrc/Makefile).  A toolchain or
-    flag change that re-introduces v_pk_{add,mul,fma}_f32 would give no compile-time signal, so disassemble every gfx950 code object of
-    the shipped .so and look (ADVICE r3).  Needs llvm-objcopy / llvm-objdump of the ROCm image, no GPU."""
+def _disassemble_shipped_library():
+    """ISA text of every gfx950 code object inside libneurons_amd.so (llvm-objcopy / llvm-objdump of the ROCm image; no GPU)."""
     import shutil
     import struct
     import subprocess
@@ -304,13 +301,13 @@ def test_shipped_library_contains_no_packed_fp32_valu_ops():
     objcopy, objdump = os.path.join(llvm, "llvm-objcopy"), os.path.join(llvm, "llvm-objdump")
     if not (os.path.exists(objcopy) and os.path.exists(objdump)):
         pytest.skip("ROCm llvm tools not present")
-    tmp = tempfile.mkdtemp(prefix="nr_pkchk_")
+    tmp = tempfile.mkdtemp(prefix="nr_isa_")
+    out = []
     try:
         fat = os.path.join(tmp, "fat.bin")
         subprocess.run([objcopy, "--dump-section", f".hip_fatbin={fat}", _lib.LIB_PATH, os.path.join(tmp, "copy.so")], check=True)
         d = open(fat, "rb").read()
-        magic, pos, objs = b"__CLANG_OFFLOAD_BUNDLE__", 0, 0
-        mfma = packed = 0
+        magic, pos = b"__CLANG_OFFLOAD_BUNDLE__", 0
         while True:
             i = d.find(magic, pos)
             if i < 0:
@@ -322,14 +319,58 @@ def test_shipped_library_contains_no_packed_fp32_valu_ops():
                 triple = d[o:o + tl].decode()
                 o += tl
                 if "gfx950" in triple and size:
-                    co = os.path.join(tmp, f"co{objs}.o")
+                    co = os.path.join(tmp, f"co{len(out)}.o")
                     open(co, "wb").write(d[i + off:i + off + size])
-                    objs += 1
-                    asm = subprocess.run([objdump, "-d", "--mcpu=gfx950", co], check=True, capture_output=True, text=True).stdout
-                    mfma += asm.count("v_mfma_")
-                    packed += sum(asm.count(op) for op in ("v_pk_add_f32", "v_pk_mul_f32", "v_pk_fma_f32"))
+                    out.append(subprocess.run([objdump, "-d", "--mcpu=gfx950", co], check=True, capture_output=True, text=True).stdout)
             pos = i + 24
-        assert objs >= 8 and mfma > 1000, (objs, mfma)            # the disassembly really is the library's kernels
-        assert packed == 0, f"{packed} packed fp32 VALU instructions in {_lib.LIB_PATH}: was the -packed-fp32-ops flag dropped?"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def test_shipped_library_contains_no_packed_fp32_valu_ops():
+    """The two-stream corruption of round 2 was bisected to the packed-fp32 code generation of norm.o (DESIGN 3c, profiles/r03_race_*) and
+    is NOT root-caused; the product's protection is the library-wide `-packed-fp32-ops` target feature (csrc/Makefile).  A toolchain or
+    flag change that re-introduces v_pk_{add,mul,fma}_f32 would give no compile-time signal, so disassemble every gfx950 code object of
+    the shipped .so and look (ADVICE r3).  Needs llvm-objcopy / llvm-objdump of the ROCm image, no GPU."""
+    from neurons_amd import _lib
+    asms = _disassemble_shipped_library()
+    mfma = sum(a.count("v_mfma_") for a in asms)
+    packed = sum(a.count(op) for a in asms for op in ("v_pk_add_f32", "v_pk_mul_f32", "v_pk_fma_f32"))
+    assert len(asms) >= 8 and mfma > 1000, (len(asms), mfma)            # the disassembly really is the library's kernels
+    assert packed == 0, f"{packed} packed fp32 VALU instructions in {_lib.LIB_PATH}: was the -packed-fp32-ops flag dropped?"
+
+
+def test_mfma_overlap_scanner_flags_the_miscompiled_chain_and_nothing_else():
+    """tools/check_mfma_overlap.py on the exact instruction pair hipcc 7.2 emitted for attention.hip's ONES instantiation (wrong sums on
+    MI355X) and on the harmless look-alike (partial overlap with a VALU-zeroed SrcC, ffpanel.hip)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from check_mfma_overlap import scan
+    bad = """
+	v_mfma_f32_16x16x32_bf16 v[0:3], v[86:89], v[18:21], v[2:5]
+	v_mfma_f32_16x16x32_bf16 v[10:13], v[82:85], v[22:25], v[10:13]
+	v_mfma_f32_16x16x32_bf16 v[2:5], v[90:93], v[22:25], v[0:3]     // 000000001234: D3B50002
+"""
+    hits = scan(bad)
+    assert len(hits) == 1 and hits[0][1].startswith("v_mfma_f32_16x16x32_bf16 v[2:5]"), hits
+    ok = """
+	v_mov_b32_e32 v46, 0
+	v_mov_b32_e32 v47, 0
+	v_mov_b32_e32 v48, 0
+	v_mov_b32_e32 v49, 0
+	v_mfma_f32_16x16x32_bf16 v[48:51], v[0:3], v[112:115], v[46:49]
+	v_mfma_f32_16x16x32_bf16 v[48:51], v[0:3], v[112:115], v[48:51]
+	v_mfma_f32_16x16x32_bf16 v[14:17], v[14:17], v[58:61], v[24:27]
+"""
+    assert scan(ok) == []
+
+
+def test_shipped_library_has_no_partially_overlapping_mfma_accumulator_chain():
+    """The miscompile of DESIGN 3e gives no compile-time signal either: scan the shipped ISA for MFMA -> MFMA chains whose destination
+    partially overlaps the SrcC the previous MFMA produced."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from check_mfma_overlap import scan
+    asms = _disassemble_shipped_library()
+    assert len(asms) >= 8
+    hits = [h for a in asms for h in scan(a)]
+    assert not hits, hits[:5]

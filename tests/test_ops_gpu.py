@@ -377,6 +377,13 @@ def test_fused_feedforward_proj_out_matches_torch(cuda, M):
     ref = x.float() + torch.nn.functional.linear(tf + ff, wpo, bpo)
     _cmp(f"fused FF + proj_out M={M}", out, ref)
     assert torch.equal(out, ops.ff_fused(t, x, gamma, beta, w1, b1, w2, b2, wpo, bpo))
+    # the 4-wave (32 rows per wave) and 8-wave (16 rows per wave, the default) forms run the same MFMA sequence per row: bit-identical
+    try:
+        ops.ff_waves(4)
+        out4 = ops.ff_fused(t, x, gamma, beta, w1, b1, w2, b2, wpo, bpo)
+    finally:
+        ops.ff_waves(8)
+    assert torch.equal(out, out4)
 
 
 @pytest.mark.parametrize("nbatch,hw", [(2, 1024), (1, 264), (3, 8)])

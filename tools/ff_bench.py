@@ -74,6 +74,12 @@ def bench(fn, iters=30):
 
 flops = 2.0 * M * C * 13 * C
 fused_pack()
-for name, fn in (("fused FF + proj_out (one launch)", fused), ("GEGLU + net.2 (two launches)", two_launch)):
-    us = bench(fn)
-    print(f"M={M}: {name:34s} {us:8.1f} us  {flops / us / 1e6:7.0f} TFLOP/s (13 C^2 per row)", flush=True)
+outs = {}
+for waves in (4, 8):
+    ops.ff_waves(waves)
+    us = bench(fused)
+    outs[waves] = out.clone()
+    print(f"M={M}: fused FF + proj_out, {waves} waves/WG       {us:8.1f} us  {flops / us / 1e6:7.0f} TFLOP/s (13 C^2 per row)", flush=True)
+print("4-wave and 8-wave results bit-identical:", torch.equal(outs[4], outs[8]), flush=True)
+us = bench(two_launch)
+print(f"M={M}: GEGLU + net.2 (two launches)          {us:8.1f} us  {flops / us / 1e6:7.0f} TFLOP/s (13 C^2 per row)", flush=True)
