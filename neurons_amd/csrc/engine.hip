@@ -1842,7 +1842,8 @@ struct nr_net {
     dry = true;
     char* old = arena_base; arena_base = nullptr;
     main_high = 0;
-    build();
+    try { build(); }
+    catch (...) { dry = false; arena_base = old; throw; }      // a shape the network rejects: keep (and later free) the arena of the previous plan
     main_high = Arena::align(arena.high + 256);
     const size_t need_bytes = main_high + parena.high + 256;
     dry = false;

@@ -15,6 +15,7 @@ hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); ++g_live_allocs; return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipFree(void* p) { if (p) { free(p); --g_live_allocs; } return hipSuccess; }
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
 hipError_t hipGetLastError(void) { return hipSuccess; }
