@@ -215,10 +215,14 @@ __device__ __forceinline__ float rows_sum(float v) {
 // acc += A B with the accumulator TIED (vDst = SrcC).  In the ONES instantiation hipcc 7.2 otherwise allocates the third accumulator as a
 // v[2:5] -> v[0:3] -> v[2:5] chain (destination partially overlapping the SrcC the previous MFMA wrote) with no wait states between the
 // dependent MFMAs, and the kernel returns wrong sums on gfx950 (tools/check_mfma_overlap.py scans the shipped ISA for that pattern).
-// Distances that make the missing hazard bookkeeping of an asm MFMA safe here: its operands come from v_cvt_pk / ds_read_tr + s_waitcnt, its
-// result is next touched by VALU one softmax later (the rescale) or after the loop's barrier.
+// The compiler keeps no hazard bookkeeping for an MFMA it cannot see, so the asm carries its own:
+//  * VALU write -> MFMA read of that register needs wait states (measured: a v_cvt_pk_bf16_f32 of the P operand directly in front of the
+//    MFMA, with only an already-satisfied s_waitcnt between them, gave NaN; one wait state cures it): the leading s_nop 1 gives two,
+//    the figure LLVM uses for its own MFMAs;
+//  * MFMA result -> VALU / LDS read: the accumulators are next touched by the rescale (after the next tile's barrier and its eight K Q^T
+//    MFMAs) or after the loop's final barrier -- far beyond the 18 wait states of an 8-pass MFMA.
 __device__ __forceinline__ void mfma_bf16_tied(f32x4& acc, const bf16x8& a, const bf16x8& b) {
-  asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  asm("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 
 // LDS images of a 64-key tile.  K (d <= 64): [64][64] bf16, 128-byte rows with the 16-byte chunk index XOR-swizzled by (key & 7): the
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p) {
     float mx = -1e30f;
     if (full) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) mx = fmaxf(fmaxf(mx, fmaxf(s[t][0], s[t][1])), fmaxf(s[t][2], s[t][3]));
+      for (int t = 0; t < 4; ++t) mx = fmaxf(fmaxf(fmaxf(fmaxf(mx, s[t][0]), s[t][1]), s[t][2]), s[t][3]);      // 8 x v_max3_f32
     } else {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -398,12 +402,25 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p) {
           mx = fmaxf(mx, v);
         }
     }
-    mx = rows_max(mx) * sl2;                   // sl2 > 0: the max of the scaled scores
     // Lazy running maximum: the reference maximum of a query only moves when the tile's maximum exceeds it by more than 2^8, so the
     // probabilities stay <= 256 (exact in the fp32 sums, in range for bf16 / scaled e4m3) and the accumulator rescale, which costs a
     // register round trip of the whole O tile, runs on the first tile and then almost never (wave-uniform skip).
     constexpr float LAZY = FP8 ? 0.0f : 8.0f;  // e4m3 probabilities keep the exact running maximum (P <= 1, scaled by 256 below)
-    const float m_new = mx > m_i + LAZY ? mx : m_i;
+    // The cross-lane maximum (two permlane swaps + selects: ~16 issue slots of a loop bound by its issue port) is only needed when the
+    // reference moves.  If NO lane's own 16 scores exceed its query's reference by the margin, no query's tile maximum does (it is the
+    // maximum over that query's four lanes), so m_new = m_i for every lane exactly as the full computation would find: skip it.
+    mx *= sl2;                                 // sl2 > 0: the max of this lane's scaled scores
+    float m_new = m_i;
+    if (__builtin_amdgcn_ballot_w64(mx > m_i + LAZY) != 0ull) {
+      mx = rows_max(mx);
+      m_new = mx > m_i + LAZY ? mx : m_i;
+      // l_i stays a per-lane partial sum (this lane's 16 keys of every tile); the four rows are added once after the loop
+      const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);      // 1 for the queries whose reference stays
+      if constexpr (!ONES) l_i *= alpha;
+#pragma unroll
+      for (int i = 0; i < DT; ++i) acc[i] *= alpha;
+      m_i = m_new;
+    }
     float rs = 0.f;
     bf16x8 pf[2];
     float pe[2][8];
@@ -418,14 +435,6 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p) {
       }
     long pf8[2];
     if constexpr (FP8) { pf8[0] = to_fp8x8(pe[0]); pf8[1] = to_fp8x8(pe[1]); }
-    // l_i stays a per-lane partial sum (this lane's 16 keys of every tile); the four rows are added once after the loop
-    if (__builtin_amdgcn_ballot_w64(m_new != m_i) != 0ull) {
-      const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
-      if constexpr (!ONES) l_i *= alpha;
-#pragma unroll
-      for (int i = 0; i < DT; ++i) acc[i] *= alpha;
-      m_i = m_new;
-    }
     if constexpr (!ONES) l_i += rs;
     // ---- O^T += V^T P^T ; k-slot j of step u -> key 32u + (j<4 ? 4g+j : 16+4g+j-4) ----
 #pragma unroll
