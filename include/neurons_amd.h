@@ -386,6 +386,11 @@ nr_status nr_op_ff_fused(nr_stream stream, const void* t_dev, const void* x_dev,
 nr_status nr_op_tattn_fused(nr_stream stream, void* t_dev, int32_t nbatch, int32_t hw, const void* wq_dev, const void* wk_dev,
                             const void* wv_dev, const void* wo_dev, const float* gamma_dev, const float* gb_dev, const float* bo_dev,
                             float ln_eps);
+/* The same for sequences of `frames` = 16 or 32 frames (32: BASELINE config 5, motion_module temporal_position_encoding_max_len = 32):
+ * t [nbatch * frames * hw][320], gb [frames][320], hw a multiple of 128 / frames. */
+nr_status nr_op_tattn_fused_frames(nr_stream stream, void* t_dev, int32_t nbatch, int32_t frames, int32_t hw, const void* wq_dev,
+                                   const void* wk_dev, const void* wv_dev, const void* wo_dev, const float* gamma_dev, const float* gb_dev,
+                                   const float* bo_dev, float ln_eps);
 
 #ifdef __cplusplus
 }

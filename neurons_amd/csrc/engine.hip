@@ -71,7 +71,7 @@ int nr_launch_fold_linear_pair(const float* w2, const float* w1, const float* b2
 size_t nr_tattn_stream_bytes(void);
 int nr_tattn_fused_eligible(int C, int heads, int frames, int hw, long long rows);
 int nr_launch_tattn_stream_pack(const bf16* wq, const bf16* wk, const bf16* wv, const bf16* wo, bf16* stream, hipStream_t s);
-int nr_launch_tattn_fused(bf16* t, int nbatch, int hw, const bf16* stream, const float* gamma, const float* gb, const float* bo, float ln_eps,
+int nr_launch_tattn_fused(bf16* t, int nbatch, int frames, int hw, const bf16* stream, const float* gamma, const float* gb, const float* bo, float ln_eps,
                           int norot, hipStream_t s);
 // ffpanel.hip: fused FeedForward(GEGLU) + proj_out of the C = 320 level
 size_t nr_ff_stream_bytes(int C);
@@ -1036,7 +1036,7 @@ struct nr_net {
     for (int k = 0; k < cfg.motion_num_attention_blocks; ++k) {
       const std::string ab = b + ".attention_blocks." + std::to_string(k);
       if (nr_tattn_fused_eligible(C, heads, F, x.H * x.W, det_rows(t.rows())) && t.ld == C) {
-        // C = 320, F = 16: the whole block (LayerNorm + PE, q|k|v, 16 x 16 attention per pixel and head, to_out + residual) in ONE launch
+        // C = 320, F = 16 or 32: the whole block (LayerNorm + PE, q|k|v, F x F attention per pixel and head, to_out + residual) in ONE launch
         // that updates t in place (tattn.hip); q|k|v and the attention output never reach HBM
         const std::string nrm = b + ".norms." + std::to_string(k);
         for (const char* wn : {".to_q.weight", ".to_k.weight", ".to_v.weight", ".to_out.0.weight"}) check_shape(ab + wn, need(ab + wn), {C, C});
@@ -1077,7 +1077,8 @@ struct nr_net {
         char d[160];
         snprintf(d, sizeof(d), "tattn_fused M=%d C=%d F=%d (LN+PE, q|k|v, attention, to_out + residual)", (int)t.rows(), C, F);
         const int norot = det_batch ? 1 : 0;
-        emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_tattn_fused(tp, nb2, hw, stream, gamma, gb, bo, 1e-5f, norot, s)); }, NR_PROF_IGEMM,
+        const int Fn = F;
+        emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_tattn_fused(tp, nb2, Fn, hw, stream, gamma, gb, bo, 1e-5f, norot, s)); }, NR_PROF_IGEMM,
              2.0 * M * C * 4.0 * C + 4.0 * (M / F) * heads * (double)F * F * (C / heads), 2.0 * (2.0 * M * C + 4.0 * C * (double)C), d);
         op_tap("tattn_fused", t);
         continue;
@@ -2847,19 +2848,26 @@ extern "C" nr_status nr_op_ff_fused(nr_stream stream, const void* t_dev, const v
   NR_CATCH
 }
 
-// ---- fused temporal-attention block (tattn.hip), op-level entry for tests.  t: bf16 [nbatch * 16 * hw][320], updated in place;
-// wq / wk / wv / wo: bf16 [320][320]; gamma fp32 [320]; gb fp32 [16][320] = LayerNorm bias + positional encoding; bo fp32 [320] ----
-extern "C" nr_status nr_op_tattn_fused(nr_stream stream, void* t_dev, int32_t nbatch, int32_t hw, const void* wq_dev, const void* wk_dev,
-                                       const void* wv_dev, const void* wo_dev, const float* gamma_dev, const float* gb_dev, const float* bo_dev,
-                                       float ln_eps) {
+// ---- fused temporal-attention block (tattn.hip), op-level entry for tests.  t: bf16 [nbatch * frames * hw][320], updated in place;
+// wq / wk / wv / wo: bf16 [320][320]; gamma fp32 [320]; gb fp32 [frames][320] = LayerNorm bias + positional encoding; bo fp32 [320];
+// frames = 16 or 32 ----
+extern "C" nr_status nr_op_tattn_fused_frames(nr_stream stream, void* t_dev, int32_t nbatch, int32_t frames, int32_t hw, const void* wq_dev,
+                                              const void* wk_dev, const void* wv_dev, const void* wo_dev, const float* gamma_dev,
+                                              const float* gb_dev, const float* bo_dev, float ln_eps) {
   NR_TRY
-  if (!nr_tattn_fused_eligible(320, 8, 16, hw, 1 << 30)) throw NrError(NR_ERR_UNSUPPORTED, "fused temporal attention: C = 320, 8 heads, 16 frames, hw % 8 == 0");
+  if (!nr_tattn_fused_eligible(320, 8, frames, hw, 1 << 30))
+    throw NrError(NR_ERR_UNSUPPORTED, "fused temporal attention: C = 320, 8 heads, 16 or 32 frames, hw % (128 / frames) == 0");
   static void* ws = nullptr;
   if (!ws) HIP_OK(hipMalloc(&ws, nr_tattn_stream_bytes()));
   // wq == NULL: reuse the stream packed by the previous call (timing loops)
   if (wq_dev) LAUNCH_OK(nr_launch_tattn_stream_pack((const bf16*)wq_dev, (const bf16*)wk_dev, (const bf16*)wv_dev, (const bf16*)wo_dev, (bf16*)ws,
                                                     (hipStream_t)stream));
-  LAUNCH_OK(nr_launch_tattn_fused((bf16*)t_dev, nbatch, hw, (const bf16*)ws, gamma_dev, gb_dev, bo_dev, ln_eps,
+  LAUNCH_OK(nr_launch_tattn_fused((bf16*)t_dev, nbatch, frames, hw, (const bf16*)ws, gamma_dev, gb_dev, bo_dev, ln_eps,
                                   getenv("NR_DETERMINISTIC_BATCH") && getenv("NR_DETERMINISTIC_BATCH")[0] == '1', (hipStream_t)stream));
   NR_CATCH
+}
+extern "C" nr_status nr_op_tattn_fused(nr_stream stream, void* t_dev, int32_t nbatch, int32_t hw, const void* wq_dev, const void* wk_dev,
+                                       const void* wv_dev, const void* wo_dev, const float* gamma_dev, const float* gb_dev, const float* bo_dev,
+                                       float ln_eps) {
+  return nr_op_tattn_fused_frames(stream, t_dev, nbatch, 16, hw, wq_dev, wk_dev, wv_dev, wo_dev, gamma_dev, gb_dev, bo_dev, ln_eps);
 }

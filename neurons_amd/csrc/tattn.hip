@@ -1,4 +1,5 @@
-// One kernel per temporal-attention block of the 32x32 level (C = 320, 8 heads of d = 40, F = 16 frames):
+// One kernel per temporal-attention block of the C = 320 level (8 heads of d = 40; F = 16 frames, or F = 32 for BASELINE config 5: see the
+// template parameter of tattn_fused_kernel; the description below is the F = 16 form):
 //
 //     t  <-  t + to_out( softmax( q k^T / sqrt(d) ) v ) ,   [q | k | v] = ( LayerNorm(t) + pe[frame] ) . [Wq | Wk | Wv]^T
 //
@@ -40,8 +41,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-constexpr int TA_C = 320, TA_HEADS = 8, TA_D = 40, TA_F = 16;
-constexpr int TA_ROWS = 128;                    // rows per workgroup = 8 pixels x 16 frames
+constexpr int TA_C = 320, TA_HEADS = 8, TA_D = 40;
+constexpr int TA_ROWS = 128;                    // rows per workgroup = 8 pixels x 16 frames or 4 pixels x 32 frames
 constexpr int TA_QSUB = 48 * 64;                // elements of one [48][64] sub-tile of a q / k / v stage
 constexpr int TA_QKV_BYTES = 32 * 1024;         // stage stride of a q / k / v stage (30 KiB image + 2 KiB pad: 8 DMA per wave)
 constexpr int TA_OSUB = 64 * 64;
@@ -70,8 +71,13 @@ __device__ __forceinline__ s16x4 pack4(const f32x4& v) {
   return __builtin_bit_cast(s16x4, b);
 }
 
+// F = 16 (round 3): a wave owns 2 pixels, row tile mt = pixel.  F = 32 (round 4, BASELINE config 5): a wave owns ONE pixel, row tile mt = frames
+// 16 mt .. 16 mt + 15; the projections and the out GEMM do not care what a row tile means, only the attention core and the addressing do.
+template <int F>
 __global__ __launch_bounds__(256) void tattn_fused_kernel(NrTAttnParams p) {
+  static_assert(F == 16 || F == 32, "one or two MFMA row tiles of frames per pixel");
   constexpr int C = TA_C, KS = C / 32, NT2 = C / 16;
+  constexpr int PIX_WG = TA_ROWS / F, PIX_WAVE = 32 / F;       // pixels per workgroup / per wave (8 / 2 or 4 / 1)
   extern __shared__ __attribute__((aligned(16))) bf16 smem[];   // TA_NS slots of 40 KiB
 
   const int tid = threadIdx.x;
@@ -105,14 +111,15 @@ __global__ __launch_bounds__(256) void tattn_fused_kernel(NrTAttnParams p) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) prefetch_piece(i);
 
-  // ---- the row panel: tile mt = pixel, lane row fr = frame; row index in t = (b F + frame) hw + pixel ----
-  const int groups_per_img = p.hw >> 3;
+  // ---- the row panel: row index in t = (b F + frame) hw + pixel; F = 16: tile mt = pixel pix0 + mt, lane row fr = frame;
+  // F = 32: tile mt = frames 16 mt + fr of the wave's one pixel ----
+  const int groups_per_img = p.hw / PIX_WG;
   const int b = blockIdx.x / groups_per_img;
-  const int pix0 = (blockIdx.x - b * groups_per_img) * 8 + wave * 2;
-  const size_t row_stride = (size_t)p.hw * C;                       // between frames
+  const int pix0 = (blockIdx.x - b * groups_per_img) * PIX_WG + wave * PIX_WAVE;
   bf16* trow[2];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) trow[mt] = p.t + ((size_t)(b * TA_F + fr) * p.hw + pix0 + mt) * C;
+  for (int mt = 0; mt < 2; ++mt)
+    trow[mt] = F == 16 ? p.t + ((size_t)(b * F + fr) * p.hw + pix0 + mt) * C : p.t + ((size_t)(b * F + 16 * mt + fr) * p.hw + pix0) * C;
   bf16x8 xb[2][KS];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
@@ -145,9 +152,10 @@ __global__ __launch_bounds__(256) void tattn_fused_kernel(NrTAttnParams p) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const f32x4 g0 = *(const f32x4*)(gar + 32 * ks), g1 = *(const f32x4*)(gar + 32 * ks + 4);
-      const f32x4 b0 = *(const f32x4*)(gbr + 32 * ks), b1 = *(const f32x4*)(gbr + 32 * ks + 4);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
+        const float* gbm = gbr + (F == 32 ? (size_t)16 * mt * C : (size_t)0);       // positional encoding of frame 16 mt + fr
+        const f32x4 b0 = *(const f32x4*)(gbm + 32 * ks), b1 = *(const f32x4*)(gbm + 32 * ks + 4);
         bf16x8 v = xb[mt][ks];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -224,34 +232,56 @@ __global__ __launch_bounds__(256) void tattn_fused_kernel(NrTAttnParams p) {
   // exp -> shuffle -> rcp -> MFMA); each phase is pinned (opaque asm) so that the o stage of the previous head can put one group of 8
   // MFMAs between consecutive phases ----
   s16x4 qa[3][2], ka[3][2], va[3][2];
-  f32x4 at_s[2], at_o[3][2];          // at_s: scores, then their exponentials
+  constexpr int KT = F / 16;          // key tiles per query tile: 1 (F = 16: keys = the 16 frames of the tile's own pixel) or 2 (F = 32: both frame tiles)
+  f32x4 at_s[KT][2], at_o[3][2];      // at_s[kt][mt]: scores of key tile kt for the queries of tile mt, then their exponentials
   float at_m[2], at_l[2];
   bf16x8 ob_prev0[2], ob_prev1[2];   // O^T of the head whose o stage runs next, as the two B fragments of that stage
   auto attn_phase = [&](int ph) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       if (ph == 0) {               // S^T[key 4 fg + r][query fr] += K[key][c] Q[query][c] over the 16 channels of tile nt
-        f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int nt = 0; nt < 3; ++nt) s4 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ka[nt][mt], qa[nt][mt], s4, 0, 0, 0);
-        at_s[mt] = s4;
+        for (int kt = 0; kt < KT; ++kt) {
+          const int km = F == 16 ? mt : kt;                  // row tile that holds the keys
+          f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int nt = 0; nt < 3; ++nt) s4 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ka[nt][km], qa[nt][mt], s4, 0, 0, 0);
+          at_s[kt][mt] = s4;
+        }
       } else if (ph == 1) {
-        float mx = fmaxf(fmaxf(at_s[mt][0], at_s[mt][1]), fmaxf(at_s[mt][2], at_s[mt][3]));
+        float mx = fmaxf(fmaxf(at_s[0][mt][0], at_s[0][mt][1]), fmaxf(at_s[0][mt][2], at_s[0][mt][3]));
+        if constexpr (KT == 2) mx = fmaxf(mx, fmaxf(fmaxf(at_s[1][mt][0], at_s[1][mt][1]), fmaxf(at_s[1][mt][2], at_s[1][mt][3])));
         at_m[mt] = fmaxf(mx, __shfl_xor(mx, 16, 64));
       } else if (ph == 2) {
         at_m[mt] = fmaxf(at_m[mt], __shfl_xor(at_m[mt], 32, 64));
       } else if (ph == 3) {
         float l = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { at_s[mt][r] = __builtin_amdgcn_exp2f((at_s[mt][r] - at_m[mt]) * p.scale_log2e); l += at_s[mt][r]; }
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { at_s[kt][mt][r] = __builtin_amdgcn_exp2f((at_s[kt][mt][r] - at_m[mt]) * p.scale_log2e); l += at_s[kt][mt][r]; }
         at_l[mt] = l + __shfl_xor(l, 16, 64);
       } else if (ph == 4) {
         at_l[mt] = at_l[mt] + __shfl_xor(at_l[mt], 32, 64);
       } else if (ph == 5) {        // O^T[channel 16 g + 4 fg + r][query fr] = V^T P^T
-        const s16x4 pb = pack4(at_s[mt]);
+        if constexpr (KT == 1) {
+          const s16x4 pb = pack4(at_s[0][mt]);
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
-          at_o[g][mt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va[g][mt], pb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          for (int g = 0; g < 3; ++g)
+            at_o[g][mt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va[g][mt], pb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        } else {
+          // 32 keys = ONE 32-deep MFMA: k-slot 8 fg + j <-> key (j < 4 ? 4 fg + j : 16 + 4 fg + j - 4), i.e. the lane's own registers of key
+          // tile 0 then key tile 1 -- for P (accumulator layout of S^T) and for V^T (the swapped projection leaves 4 frames of each tile per lane)
+          const s16x4 p0 = pack4(at_s[0][mt]), p1 = pack4(at_s[1][mt]);
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x8 pb8 = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+#pragma unroll
+          for (int g = 0; g < 3; ++g) {
+            const s16x8 va8 = {va[g][0][0], va[g][0][1], va[g][0][2], va[g][0][3], va[g][1][0], va[g][1][1], va[g][1][2], va[g][1][3]};
+            at_o[g][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, va8), __builtin_bit_cast(bf16x8, pb8),
+                                                                  f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          }
+        }
       } else {
         const float inv = __builtin_amdgcn_rcpf(at_l[mt]);
         bf16x8 b0, b1;
@@ -264,9 +294,12 @@ __global__ __launch_bounds__(256) void tattn_fused_kernel(NrTAttnParams p) {
       }
     }
     // pin the phase
-    if (ph == 0) asm volatile("" : "+v"(at_s[0]), "+v"(at_s[1]));
+    if (ph == 0 || ph == 3) {
+      asm volatile("" : "+v"(at_s[0][0]), "+v"(at_s[0][1]));
+      if constexpr (KT == 2) asm volatile("" : "+v"(at_s[1][0]), "+v"(at_s[1][1]));
+      if (ph == 3) asm volatile("" : "+v"(at_l[0]), "+v"(at_l[1]));
+    }
     else if (ph == 1 || ph == 2) asm volatile("" : "+v"(at_m[0]), "+v"(at_m[1]));
-    else if (ph == 3) asm volatile("" : "+v"(at_l[0]), "+v"(at_l[1]), "+v"(at_s[0]), "+v"(at_s[1]));
     else if (ph == 4) asm volatile("" : "+v"(at_l[0]), "+v"(at_l[1]));
     else if (ph == 5) asm volatile("" : "+v"(at_o[0][0]), "+v"(at_o[1][0]), "+v"(at_o[2][0]), "+v"(at_o[0][1]), "+v"(at_o[1][1]), "+v"(at_o[2][1]));
     else asm volatile("" : "+v"(ob_prev0[0]), "+v"(ob_prev0[1]), "+v"(ob_prev1[0]), "+v"(ob_prev1[1]));
@@ -393,7 +426,7 @@ extern "C" size_t nr_tattn_stream_bytes(void) { return (size_t)TA_HEADS * TA_HEA
 
 extern "C" int nr_tattn_fused_eligible(int C, int heads, int frames, int hw, long long rows) {
   static const bool off = getenv("NR_TATTN_FUSED") && getenv("NR_TATTN_FUSED")[0] == '0';   // A/B switch
-  return !off && C == TA_C && heads == TA_HEADS && frames == TA_F && hw % 8 == 0 && rows >= 4096;
+  return !off && C == TA_C && heads == TA_HEADS && (frames == 16 || frames == 32) && hw % (TA_ROWS / frames) == 0 && rows >= 4096;
 }
 
 extern "C" int nr_launch_tattn_stream_pack(const bf16* wq, const bf16* wk, const bf16* wv, const bf16* wo, bf16* stream, hipStream_t s) {
@@ -402,9 +435,9 @@ extern "C" int nr_launch_tattn_stream_pack(const bf16* wq, const bf16* wk, const
   return 0;
 }
 
-extern "C" int nr_launch_tattn_fused(bf16* t, int nbatch, int hw, const bf16* stream, const float* gamma, const float* gb, const float* bo,
+extern "C" int nr_launch_tattn_fused(bf16* t, int nbatch, int frames, int hw, const bf16* stream, const float* gamma, const float* gb, const float* bo,
                                      float ln_eps, int norot, hipStream_t s) {
-  if (nbatch <= 0 || hw <= 0 || hw % 8 != 0) return 1;
+  if (nbatch <= 0 || hw <= 0 || (frames != 16 && frames != 32) || hw % (TA_ROWS / frames) != 0) return 1;
   NrTAttnParams p;
   p.t = t; p.hw = hw; p.nbatch = nbatch; p.stream = stream; p.gamma = gamma; p.gb = gb; p.bo = bo; p.ln_eps = ln_eps; p.norot = norot;
   p.scale_log2e = 1.4426950408889634f / sqrtf((float)TA_D);
@@ -414,9 +447,12 @@ extern "C" int nr_launch_tattn_fused(bf16* t, int nbatch, int hw, const bf16* st
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!(g_ta_attr >> (dev & 63) & 1ull)) {
-    if (hipFuncSetAttribute((const void*)tattn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return 2;
+    if (hipFuncSetAttribute((const void*)tattn_fused_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return 2;
+    if (hipFuncSetAttribute((const void*)tattn_fused_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return 2;
     g_ta_attr |= 1ull << (dev & 63);
   }
-  hipLaunchKernelGGL(tattn_fused_kernel, dim3((unsigned)(nbatch * (hw / 8))), dim3(256), shm, s, p);
+  const unsigned grid = (unsigned)(nbatch * (hw / (TA_ROWS / frames)));
+  if (frames == 16) hipLaunchKernelGGL(tattn_fused_kernel<16>, dim3(grid), dim3(256), shm, s, p);
+  else hipLaunchKernelGGL(tattn_fused_kernel<32>, dim3(grid), dim3(256), shm, s, p);
   return 0;
 }

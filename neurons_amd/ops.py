@@ -245,16 +245,17 @@ def temporal_pe_table(frames, C, device):
     return pe
 
 
-def tattn_fused(t, nbatch, hw, gamma, beta, wq, wk, wv, wo, bo, eps=1e-5, reuse_stream=False):
-    """t <- t + to_out(temporal self-attention(LayerNorm(t) + pe)) over the 16 frames of every pixel, C = 320, 8 heads, ONE launch (tattn.hip).
-    t: [nbatch * 16 * hw, 320] bf16 in "(b f) (h w) c" row order, updated IN PLACE and returned; w*: [320, 320] fp32 or bf16."""
+def tattn_fused(t, nbatch, hw, gamma, beta, wq, wk, wv, wo, bo, eps=1e-5, reuse_stream=False, frames=16):
+    """t <- t + to_out(temporal self-attention(LayerNorm(t) + pe)) over the ``frames`` (16 or 32) frames of every pixel, C = 320, 8 heads, ONE
+    launch (tattn.hip).  t: [nbatch * frames * hw, 320] bf16 in "(b f) (h w) c" row order, updated IN PLACE and returned; w*: [320, 320] fp32 or bf16."""
     _chk_bf16(t)
-    C, F = 320, 16
+    C, F = 320, int(frames)
     assert t.shape == (nbatch * F * hw, C)
     gb = (beta.float()[None] + temporal_pe_table(F, C, t.device)).contiguous()
     ws = [w.to(torch.bfloat16).contiguous() for w in (wq, wk, wv, wo)]
-    _lib.check(_lib.load().nr_op_tattn_fused(_stream(), _ptr(t), nbatch, hw, None if reuse_stream else _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]),
-                                             _ptr(ws[3]), _ptr(gamma.float().contiguous()), _ptr(gb), _ptr(bo.float().contiguous()), float(eps)))
+    _lib.check(_lib.load().nr_op_tattn_fused_frames(_stream(), _ptr(t), nbatch, F, hw, None if reuse_stream else _ptr(ws[0]), _ptr(ws[1]),
+                                                    _ptr(ws[2]), _ptr(ws[3]), _ptr(gamma.float().contiguous()), _ptr(gb),
+                                                    _ptr(bo.float().contiguous()), float(eps)))
     return t
 
 

@@ -352,6 +352,15 @@ def gen_leaf_ops(out_dir):
     yb = tmb(randn("tm320big.x", (1, 320, 16, 16, 16), 62), None, None)
     out["tm320big.idx"], out["tm320big.val"] = _sub(yb, 16384)
     out["tm320big.shape"] = np.array(yb.shape)
+    # the 32-frame clips of BASELINE config 5 (temporal_position_encoding_max_len = 32): 32 frames x 12x12 = 4608 rows reach the two-row-tile form
+    # of the fused temporal-attention kernel (tattn.hip, F = 32)
+    tm32 = fill(ref_mm.VanillaTemporalModule(in_channels=320, num_attention_heads=8, num_transformer_block=1,
+                                             attention_block_types=("Temporal_Self", "Temporal_Self"),
+                                             temporal_position_encoding=True, temporal_position_encoding_max_len=32,
+                                             zero_initialize=False), "tm320f32", 66)
+    yb = tm32(randn("tm320f32.x", (1, 320, 32, 12, 12), 67), None, None)
+    out["tm320f32.idx"], out["tm320f32.val"] = _sub(yb, 16384)
+    out["tm320f32.shape"] = np.array(yb.shape)
     t3b = fill(ref_attention.Transformer3DModel(8, 40, in_channels=320, num_layers=1, cross_attention_dim=768, norm_num_groups=32,
                                                 unet_use_cross_frame_attention=False, unet_use_temporal_attention=False), "t3d320big", 63)
     yb = t3b(randn("t3d320big.x", (1, 320, 2, 48, 48), 64), encoder_hidden_states=randn("t3d320big.ctx", (1, 77, 768), 65)).sample

@@ -386,15 +386,15 @@ def test_fused_feedforward_proj_out_matches_torch(cuda, M):
     assert torch.equal(out, out4)
 
 
-@pytest.mark.parametrize("nbatch,hw", [(2, 1024), (1, 264), (3, 8)])
-def test_fused_temporal_attention_block_matches_torch(cuda, nbatch, hw):
+@pytest.mark.parametrize("nbatch,hw,F", [(2, 1024, 16), (1, 264, 16), (3, 8, 16), (2, 1024, 32), (1, 260, 32), (3, 4, 32)])
+def test_fused_temporal_attention_block_matches_torch(cuda, nbatch, hw, F):
     """tattn.hip: norm -> (+ positional encoding) -> to_q|k|v -> softmax(q k^T / sqrt(40)) v over the 16 frames of each pixel -> to_out (+bias)
     -> + residual, C = 320, 8 heads, one launch, in place; against the fp32 torch composition of the reference
     (motion_module.py:210-218 block, :270-329 VersatileAttention incl. the "(b f) d c -> (b d) f c" regroup, :225-243 PositionalEncoding;
     motion_module_new.py:201-287 attention arithmetic).  Tolerance as the other MFMA ops (bf16 operands, fp32 accumulation)."""
     from neurons_amd import ops
-    C, F, H = 320, 16, 8
-    g = torch.Generator(device="cuda").manual_seed(nbatch * 1000 + hw)
+    C, H = 320, 8                                  # F = 32: BASELINE config 5's clips (two MFMA row tiles of frames per pixel)
+    g = torch.Generator(device="cuda").manual_seed(nbatch * 1000 + hw + F)
     t = (torch.randn(nbatch * F * hw, C, generator=g, device="cuda") * 1.1 + 0.1).to(torch.bfloat16)
     gamma = 1.0 + 0.2 * torch.randn(C, generator=g, device="cuda")
     beta = 0.1 * torch.randn(C, generator=g, device="cuda")
@@ -410,7 +410,7 @@ def test_fused_temporal_attention_block_matches_torch(cuda, nbatch, hw):
     o = torch.nn.functional.linear(a.transpose(1, 2).reshape(nbatch * hw, F, C), bw(wo), bo)
     ref = x + o.view(nbatch, hw, F, C).permute(0, 2, 1, 3)
     t1 = t.clone()
-    out = ops.tattn_fused(t1, nbatch, hw, gamma, beta, wq, wk, wv, wo, bo)
-    _cmp(f"fused temporal attention block nbatch={nbatch} hw={hw}", out.view(nbatch, F, hw, C), ref)
+    out = ops.tattn_fused(t1, nbatch, hw, gamma, beta, wq, wk, wv, wo, bo, frames=F)
+    _cmp(f"fused temporal attention block nbatch={nbatch} hw={hw} F={F}", out.view(nbatch, F, hw, C), ref)
     t2 = t.clone()
-    assert torch.equal(out, ops.tattn_fused(t2, nbatch, hw, gamma, beta, wq, wk, wv, wo, bo))
+    assert torch.equal(out, ops.tattn_fused(t2, nbatch, hw, gamma, beta, wq, wk, wv, wo, bo, frames=F))

@@ -151,6 +151,11 @@ def test_composite_modules_match_reference():
     y = O.temporal_transformer3d(sd, "m", randn("tm320big.x", (1, 320, 16, 16, 16), 62), 8, 32, 2, 24)
     assert tuple(y.shape) == tuple(g["tm320big.shape"])
     _close("tm320big", y.reshape(-1)[torch.from_numpy(g["tm320big.idx"])], g["tm320big.val"])
+    # 32-frame clips (BASELINE config 5): the two-row-tile form of the fused temporal-attention kernel
+    sd = {f"m.{k}": v for k, v in _fill({k[len("m."):]: v for k, v in _motion_keys("m", 320, 2).items()}, "tm320f32", 66).items()}
+    y = O.temporal_transformer3d(sd, "m", randn("tm320f32.x", (1, 320, 32, 12, 12), 67), 8, 32, 2, 32)
+    assert tuple(y.shape) == tuple(g["tm320f32.shape"])
+    _close("tm320f32", y.reshape(-1)[torch.from_numpy(g["tm320f32.idx"])], g["tm320f32.val"])
     shp = {k[len("t."):]: v for k, v in _transformer_keys("t", 320, 768).items()}
     sd = {f"t.{k}": v for k, v in _fill(shp, "t3d320big", 63).items()}
     y = O.transformer3d(sd, "t", randn("t3d320big.x", (1, 320, 2, 48, 48), 64), randn("t3d320big.ctx", (1, 77, 768), 65), 8, 32)
