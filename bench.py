@@ -8,9 +8,9 @@ Inputs (latents, noise, text context, keyframe latent) are synthetic and residen
 region; weights are seeded random tensors of the reference architecture (1 277 M + 497 M parameters).
 
     python bench.py --gpus N --steps K --warmup W
-For N > 1 launch it under torch.distributed.run (one rank per GPU; the script refuses WORLD_SIZE != --gpus); clips shard
-across ranks with no data-path collective (weak scaling); rank 0 converts the weights once and broadcasts the bf16 arenas
-device-to-device over RCCL before timing.
+N > 1: either under torch.distributed.run (one rank per GPU), or bare (`python bench.py --gpus N`): the script then starts its own N
+rank processes before touching a GPU (self_launch) and forwards rank 0's line.  Clips shard across ranks with no data-path
+collective (weak scaling); rank 0 converts the weights once and broadcasts the bf16 arenas device-to-device over RCCL before timing.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     dominant kernel class = the MFMA implicit-GEMM (conv/Linear): algorithmic FLOPs / summed launch
@@ -36,7 +36,7 @@ PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
 
-CURRENT_ROUND = "r04"      # a committed traffic file of an earlier round is reported as historical
+CURRENT_ROUND = "r05"      # a committed traffic file of an earlier round is reported as historical
 
 
 def parse():
@@ -64,7 +64,110 @@ def parse():
                          "enhance = one GPU's share of BASELINE config 4: --batch keyframes in one Euler loop, then --batch clips in one call, decoded")
     ap.add_argument("--keyframe-steps", type=int, default=50)
     ap.add_argument("--keyframe-latent", type=int, default=64, help="64 = BASELINE config 3 (512 px); 96 = reference-faithful (768 px, 38 steps)")
+    ap.add_argument("--self-launch", action="store_true",
+                    help="start the rank processes from this process even for --gpus 1 (tests/test_dist_gpu.py: the N > 1 launcher with a world of one)")
+    ap.add_argument("--launch-dry-run", action="store_true",
+                    help="rank processes only rendezvous (gloo, CPU), shard a clip list, reduce a timing scalar and exit: the launcher and the "
+                         "rank logic without a GPU (tests/test_bench_launch.py)")
+    ap.add_argument("--launch-timeout", type=float, default=3600.0, help="self-launch: seconds before the rank processes are stopped")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start N FRESH rank processes of this same script (one per GPU, the layout
+    `accelerate launch` gives the reference: /root/reference/train_neurons.sh:92-96, scripts/neuroclips_video.py:39-40,323) and wait.
+    This parent never initialises HIP (torch.cuda.device_count() only counts) and never exec's: the ranks are children, rank 0's stdout
+    (the ONE JSON line) is forwarded, every other stream goes to stderr, the exit code is non-zero if any rank failed."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+    n = args.gpus
+    if not args.launch_dry_run:
+        have = torch.cuda.device_count()
+        if have < n:
+            raise SystemExit(f"--gpus {n} but this node shows {have} GPU(s)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    argv = [a for a in sys.argv[1:] if a != "--self-launch"]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", NR_BENCH_RANK_PROCESS="1")
+        if n == 1:
+            env["NR_DIST_FORCE"] = "1"        # a world of one still takes the RCCL path (init, broadcasts, all-reduce, barriers)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, cwd=os.getcwd(),
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
+
+    def _stop(signum, frame):                # the launcher is told to stop (driver timeout): take exactly our own ranks along
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        raise SystemExit(128 + signum)
+    signal.signal(signal.SIGTERM, _stop)
+    signal.signal(signal.SIGINT, _stop)
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)
+    reader.start()
+    deadline = time.time() + args.launch_timeout
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            failed = f"rank processes still running after {args.launch_timeout:.0f} s"
+            break
+        time.sleep(0.2)
+    if failed:
+        for p in procs:                      # exactly the PIDs started above
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    reader.join(timeout=10)
+    lines = [ln for ln in out0 if ln.startswith("{")]
+    for ln in out0:
+        if not ln.startswith("{"):
+            sys.stderr.write(ln)
+    if failed:
+        sys.stderr.write(f"bench.py self-launch: {failed}\n")
+        raise SystemExit(1)
+    if len(lines) != 1:
+        sys.stderr.write(f"bench.py self-launch: rank 0 printed {len(lines)} JSON lines, expected one\n")
+        raise SystemExit(1)
+    sys.stdout.write(lines[0])
+    sys.stdout.flush()
+
+
+def launch_dry_run(args):
+    """One rank of `--launch-dry-run`: the rendezvous, the clip sharding and the timing reduction of the real run on gloo / CPU tensors."""
+    import torch.distributed as dist
+    from neurons_amd.distributed import clip_indices_for_rank, max_over_ranks
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if os.environ.get("NR_LAUNCH_DRY_RUN_FAIL_RANK") == str(rank):      # test hook: a rank that dies before the rendezvous
+        raise SystemExit(3)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = torch.ones(1)
+    dist.all_reduce(seen)
+    mine = clip_indices_for_rank(world * args.steps, rank, world)
+    slowest = max_over_ranks(1.0 + rank)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (rank, int(os.environ["LOCAL_RANK"]), mine))
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "launcher dry run (no GPU work)", "value": 0.0, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ranks_seen": int(seen.item()), "slowest_rank_time": slowest,
+                          "ranks": [{"rank": r, "local_rank": lr, "clips": c} for r, lr, c in gathered]}))
 
 
 def vae_main(args):
@@ -369,15 +472,20 @@ def main():
         return vae_main(args)
     if args.workload == "enhance":
         return enhance_main(args)
+    # No launcher around us (`python bench.py --gpus N`, the driver's SCALE command): this process becomes the launcher of N rank processes.
+    # Under torch.distributed.run (RANK / WORLD_SIZE in the environment) it IS a rank.
+    if "RANK" not in os.environ and (args.gpus > 1 or args.self_launch or args.launch_dry_run):
+        return self_launch(args)
+    if args.launch_dry_run:
+        return launch_dry_run(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 with "
-                         f"python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world and --gpus must agree")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
+    dist, rccl_ranks_seen = None, None
     # NR_DIST_FORCE=1 under torchrun with ONE rank: the same NCCL (= RCCL) init / broadcast / all-reduce / barrier calls as N > 1
     # (tests/test_dist_gpu.py runs this on the single-GPU box)
     use_dist = world > 1 or (os.environ.get("NR_DIST_FORCE") == "1" and "RANK" in os.environ)
@@ -385,6 +493,9 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         dist.init_process_group("nccl", device_id=dev)
+        seen = torch.ones(1, device=dev)
+        dist.all_reduce(seen)                 # every rank's GPU answers over RCCL before anything is timed
+        rccl_ranks_seen = int(seen.item())
 
     from neurons_amd import _lib, DDIMScheduler, NativeSparseCtrl, NativeUNet3D, NeuroclipsPipeline
     from neurons_amd.sparsectrl import controlnet_config_from_unet
@@ -516,6 +627,7 @@ def main():
             "value": round(value, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if not args.attn_fp8 else "bf16 (attention operands e4m3)", "data": "synthetic",
+            "rccl_ranks_seen": rccl_ranks_seen,
             "config": {"workload": f"BASELINE config {5 if (Bc, F, L) == (4, 32, 64) else 4 if Bc > 1 else 2}: {Bc} clip(s) per call, ({Bc},4,{F},{L},{L}) latent, {args.ddim_steps} DDIM steps, CFG 8.5 "
                                    f"(batch {2 * Bc}), SparseCtrl + temporal U-Net per step, random-init weights",
                        "clips_per_gpu": args.steps * Bc, "frame_steps_per_s": round(value * args.ddim_steps, 2),

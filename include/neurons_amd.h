@@ -232,6 +232,11 @@ nr_status nr_prior_p_sample_step(nr_stream stream, const float* pred_dev, const 
 nr_status nr_cfg_ddim_step(nr_stream stream, const float* eps_dev, const float* x_dev, float* x_out_dev, int64_t n,
                            float guidance_scale, int32_t do_cfg, double alpha_prod_t, double alpha_prod_t_prev);
 
+/* replaces the CFG combine alone (pipeline_neuroclips.py:478-480) for a caller that keeps its own scheduler object
+ * (scripts/neuroclips_video.py:219) and calls its .step (pipeline_neuroclips.py:483) on the combined noise:
+ *   eps_dev fp32 [2B][...] (uncond half first) -> eps_out_dev fp32 [B][...] = e_u + g (e_t - e_u); n = elements of the output */
+nr_status nr_cfg_combine(nr_stream stream, const float* eps_dev, float* eps_out_dev, int64_t n, float guidance_scale);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 #define NR_PROF_IGEMM 0     /* MFMA implicit-GEMM conv / Linear kernel            */
 #define NR_PROF_GROUPNORM 1

@@ -90,6 +90,7 @@ SYMBOLS = {
     "nr_edm_cfg_euler_step": (_I32, [_VP, _VP, _VP, _VP, _I64, C.c_float, C.c_float, C.c_float, C.c_float]),
     "nr_prior_p_sample_step": (_I32, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, C.c_float, _I32, _I32, C.c_double, C.c_double, C.c_double]),
     "nr_cfg_ddim_step": (_I32, [_VP, _VP, _VP, _VP, _I64, C.c_float, _I32, C.c_double, C.c_double]),
+    "nr_cfg_combine": (_I32, [_VP, _VP, _VP, _I64, C.c_float]),
     "nr_net_export_manifest": (_I64, [_VP, _VP, _I64, C.POINTER(_I64)]),
     "nr_net_export_weights": (_I32, [_VP, _VP, _VP, _I64]),
     "nr_net_import_weights": (_I32, [_VP, _VP, C.c_char_p, _I64, _VP, _I64]),

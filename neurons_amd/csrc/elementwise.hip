@@ -264,6 +264,15 @@ __global__ void cfg_ddim_step_kernel(const float* __restrict__ eps, const float*
   x_out[i] = sqrt_ap * x0 + sqrt_1map * e;
 }
 
+// classifier-free guidance alone (pipeline_neuroclips.py:478-480): out = eps_uncond + g * (eps_text - eps_uncond).  For callers that keep a
+// scheduler of their own (the combined eps then goes to its .step); the pipeline's own scheduler uses the fused kernel above.
+__global__ void cfg_combine_kernel(const float* __restrict__ eps, float* __restrict__ out, long long total, float guidance) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const float eu = eps[i], et = eps[i + total];
+  out[i] = eu + guidance * (et - eu);
+}
+
 // One ancestral DDPM step of the diffusion prior (see nr_prior_p_sample_step in include/neurons_amd.h): network output -> x_start
 // (mode 0: the output IS x_start; 1: v-prediction; 2: noise prediction, clamped to [-1, 1] when `clamp`), classifier-free guidance
 // between the conditional and the null evaluation when pred_null != nullptr, posterior mean + sigma * noise.
@@ -541,6 +550,11 @@ extern "C" int nr_launch_cfg_ddim_step(const float* eps, const float* x, float* 
                                        hipStream_t stream) {
   hipLaunchKernelGGL(cfg_ddim_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, eps, x, x_out,
                      total, total, guidance, do_cfg, sqrt_at, sqrt_1mat, sqrt_ap, sqrt_1map);
+  return 0;
+}
+
+extern "C" int nr_launch_cfg_combine(const float* eps, float* out, long long total, float guidance, hipStream_t stream) {
+  hipLaunchKernelGGL(cfg_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, eps, out, total, guidance);
   return 0;
 }
 

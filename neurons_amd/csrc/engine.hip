@@ -53,6 +53,7 @@ int nr_launch_linear_small(const float* x, int M, int K, const bf16* W, const fl
                            float* y, const float* addend, hipStream_t stream);
 int nr_launch_edm_cfg_euler(const float* net, const float* x, float* x_out, long long total, float scale, float sigma_q,
                             float sigma, float sigma_next, hipStream_t stream);
+int nr_launch_cfg_combine(const float* eps, float* out, long long total, float guidance, hipStream_t stream);
 int nr_launch_cfg_ddim_step(const float* eps, const float* x, float* x_out, long long total, float guidance, int do_cfg,
                             float sqrt_at, float sqrt_1mat, float sqrt_ap, float sqrt_1map, hipStream_t stream);
 int nr_launch_add_bf16(const bf16* a, const bf16* b, bf16* out, long long n, hipStream_t stream);
@@ -2640,6 +2641,13 @@ extern "C" nr_status nr_cfg_ddim_step(nr_stream stream, const float* eps_dev, co
   LAUNCH_OK(nr_launch_cfg_ddim_step(eps_dev, x_dev, x_out_dev, n, guidance_scale, do_cfg, (float)std::sqrt(a_t),
                                     (float)std::sqrt(1.0 - a_t), (float)std::sqrt(a_prev), (float)std::sqrt(1.0 - a_prev),
                                     (hipStream_t)stream));
+  NR_CATCH
+}
+
+extern "C" nr_status nr_cfg_combine(nr_stream stream, const float* eps_dev, float* eps_out_dev, int64_t n, float guidance_scale) {
+  NR_TRY
+  if (!eps_dev || !eps_out_dev || n <= 0) throw NrError(NR_ERR_ARG, "bad argument");
+  LAUNCH_OK(nr_launch_cfg_combine(eps_dev, eps_out_dev, n, guidance_scale, (hipStream_t)stream));
   NR_CATCH
 }
 

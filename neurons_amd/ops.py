@@ -218,6 +218,16 @@ def cfg_ddim_step(eps, x, guidance_scale, alpha_prod_t, alpha_prod_t_prev, do_cf
     return out
 
 
+def cfg_combine(eps, guidance_scale):
+    """eps fp32 [2B, ...] (uncond half first) -> [B, ...] = e_u + g (e_t - e_u)  (pipeline_neuroclips.py:478-480), HIP nr_cfg_combine"""
+    _chk_f32(eps)
+    if eps.shape[0] % 2:
+        raise ValueError("cfg_combine: the batch must hold the unconditional and the text half")
+    out = torch.empty((eps.shape[0] // 2,) + tuple(eps.shape[1:]), dtype=torch.float32, device=eps.device)
+    _lib.check(_lib.load().nr_cfg_combine(_stream(), _ptr(eps), _ptr(out), out.numel(), float(guidance_scale)))
+    return out
+
+
 def ff_fused(t, x, gamma, beta, w1, b1, w2, b2, wpo, bpo, eps=1e-5, reuse_stream=False):
     """out = x + proj_out(t + FF(t)),  FF(t) = net.2(GEGLU(net.0(LayerNorm(t))))  — the tail of a (temporal) transformer at C = 320 in ONE
     launch (ffpanel.hip).  The weight conversion is done here on the host exactly as engine.hip does it: value/gate interleave of net.0

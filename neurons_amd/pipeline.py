@@ -201,6 +201,17 @@ class NeuroclipsPipeline:
         video = (video / 2 + 0.5).clamp(0, 1)
         return video.cpu().float().numpy()
 
+    def prepare_extra_step_kwargs(self, generator, eta):
+        """Same contract as pipeline_neuroclips.py:257-272: `eta` / `generator` reach scheduler.step only when its signature names them."""
+        import inspect
+        names = set(inspect.signature(self.scheduler.step).parameters.keys())
+        extra = {}
+        if "eta" in names:
+            extra["eta"] = eta
+        if "generator" in names:
+            extra["generator"] = generator
+        return extra
+
     def check_inputs(self, prompt, height, width, callback_steps):
         if not isinstance(prompt, str) and not isinstance(prompt, list):
             raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
@@ -242,7 +253,7 @@ class NeuroclipsPipeline:
         height = height or self.unet.config.sample_size * self.vae_scale_factor
         width = width or self.unet.config.sample_size * self.vae_scale_factor
         self.check_inputs(prompt, height, width, callback_steps)
-        if eta != 0.0:
+        if eta != 0.0 and hasattr(self.scheduler, "alpha_pair"):
             raise NotImplementedError("eta != 0 is not on the NEURONS path")
 
         batch_size = 1
@@ -267,7 +278,12 @@ class NeuroclipsPipeline:
 
         self.scheduler.set_timesteps(num_inference_steps, device=device)
         timesteps = self.scheduler.timesteps
-        timesteps_host = self.scheduler.timesteps_host
+        # This package's DDIMScheduler exposes host-side tables (timesteps_host / alpha_pair): CFG + the DDIM update then run as ONE HIP kernel.
+        # Any other scheduler object (the diffusers surface the reference caller constructs, scripts/neuroclips_video.py:219) is driven exactly
+        # as the reference drives it -- scale_model_input / step(...).prev_sample (pipeline_neuroclips.py:436,483) -- with the CFG combine in HIP.
+        own_scheduler = hasattr(self.scheduler, "alpha_pair") and hasattr(self.scheduler, "timesteps_host")
+        timesteps_host = self.scheduler.timesteps_host if own_scheduler else [int(v) for v in torch.as_tensor(timesteps).tolist()]
+        extra_step_kwargs = {} if own_scheduler else self.prepare_extra_step_kwargs(generator, eta)
 
         num_channels_latents = self.unet.in_channels
         latents = self.prepare_latents(batch_size * num_videos_per_prompt, num_channels_latents, video_length, height, width,
@@ -302,6 +318,10 @@ class NeuroclipsPipeline:
             assert controlnet_images.shape[2] >= len(controlnet_image_index)
             controlnet_cond[:, :, controlnet_image_index] = controlnet_images[:, :, :len(controlnet_image_index)]
             controlnet_conditioning_mask[:, :, controlnet_image_index] = 1
+            if hasattr(self.controlnet, "set_condition_frames"):
+                # the frames that carry a condition are known here: no tensor scan, no dependence on autograd version counters
+                # (torch.inference_mode tensors have none)
+                self.controlnet.set_condition_frames([int(i) % video_length for i in controlnet_image_index])
 
         lib = _lib.load()
         n_lat = latents.numel()
@@ -325,10 +345,13 @@ class NeuroclipsPipeline:
             groups, plan = controlnet_group_plan(list(timesteps_host), G)
             ctx_group = text_embeddings.repeat(G, 1, 1)
             launch_group(0)
-        with self.progress_bar(total=num_inference_steps) as progress_bar:
+        import contextlib
+        with contextlib.ExitStack() as cleanup, self.progress_bar(total=num_inference_steps) as progress_bar:
+            if use_ctrl and hasattr(self.controlnet, "set_condition_frames"):
+                cleanup.callback(self.controlnet.set_condition_frames, None)      # later direct forwards derive the list from their tensors again
             for i, t in enumerate(timesteps_host):
                 latent_model_input = torch.cat([latents] * 2) if do_classifier_free_guidance else latents
-                latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)
+                latent_model_input = self.scheduler.scale_model_input(latent_model_input, t if own_scheduler else timesteps[i])
                 down_res = mid_res = None
                 if G > 1:
                     launch, g, p_ = plan[i]
@@ -354,13 +377,23 @@ class NeuroclipsPipeline:
                     noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=text_embeddings,
                                            down_block_additional_residuals=down_res,
                                            mid_block_additional_residual=mid_res).sample
-                # CFG combine + DDIM step fused in one HIP kernel (reference: :478-483)
-                a_t, a_prev = self.scheduler.alpha_pair(t)
-                new_latents = torch.empty_like(latents)
-                _lib.check(lib.nr_cfg_ddim_step(torch.cuda.current_stream().cuda_stream, noise_pred.data_ptr(),
-                                                latents.data_ptr(), new_latents.data_ptr(), n_lat, float(guidance_scale),
-                                                1 if do_classifier_free_guidance else 0, a_t, a_prev))
-                latents = new_latents
+                if own_scheduler:
+                    # CFG combine + DDIM step fused in one HIP kernel (reference: :478-483)
+                    a_t, a_prev = self.scheduler.alpha_pair(t)
+                    new_latents = torch.empty_like(latents)
+                    _lib.check(lib.nr_cfg_ddim_step(torch.cuda.current_stream().cuda_stream, noise_pred.data_ptr(),
+                                                    latents.data_ptr(), new_latents.data_ptr(), n_lat, float(guidance_scale),
+                                                    1 if do_classifier_free_guidance else 0, a_t, a_prev))
+                    latents = new_latents
+                else:
+                    noise_pred = noise_pred.float().contiguous()
+                    if do_classifier_free_guidance:
+                        combined = torch.empty_like(latents)
+                        _lib.check(lib.nr_cfg_combine(torch.cuda.current_stream().cuda_stream, noise_pred.data_ptr(), combined.data_ptr(),
+                                                      n_lat, float(guidance_scale)))
+                        noise_pred = combined
+                    latents = self.scheduler.step(noise_pred, timesteps[i], latents, **extra_step_kwargs).prev_sample
+                    latents = latents.to(torch.float32).contiguous()
                 progress_bar.update()
                 if callback is not None and i % callback_steps == 0:
                     callback(i, t, latents)

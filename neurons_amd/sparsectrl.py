@@ -58,21 +58,37 @@ class NativeSparseCtrl(_NativeNet):
         return cls(controlnet_config_from_unet(unet.config, controlnet_additional_kwargs))
 
     # ---- identical-frame evaluation (C ABI nr_sparsectrl_set_condition_frames) ---------------------------------------------------------
+    def set_condition_frames(self, frames):
+        """Explicit frame list for the identical-frame evaluation: the caller states which frames carry a condition (the pipeline knows its
+        ``controlnet_image_index``), so no tensor is scanned.  ``None`` returns to deriving the list from the tensors."""
+        self._cframes_explicit = None if frames is None else tuple(sorted({int(i) for i in frames}))
+
     def _sync_condition_frames(self, controlnet_cond, conditioning_mask):
-        """Frames whose condition or mask is not all zero, read from the tensors themselves (one small reduction + host read per NEW
-        condition tensor: identity + in-place version are cached, so a clip's 50 steps / 10 groups pay it once).  Every other frame is
-        exactly zero, which is what makes the engine's shortcut exact; with the noisy sample NOT zeroed frames differ anyway: off."""
+        """Frames whose condition or mask is not all zero.  Every other frame is exactly zero, which is what makes the engine's shortcut exact;
+        with the noisy sample NOT zeroed frames differ anyway: off.  Source of the list, in order: NR_CTRL_DEDUP=0 (off, checked on every
+        call) -> ``set_condition_frames`` (explicit, the pipeline's path) -> a scan of the tensors (one small reduction + host read), cached
+        on (data_ptr, in-place version, shape).  The cache cannot see writes that do not bump the version counter (``cond.data[...] = x``, a
+        native kernel writing through ``data_ptr()`` into a reused buffer): such callers pass the list explicitly or call
+        ``invalidate_condition_frames()``.  Inference-mode tensors carry no version counter: they are scanned on every call."""
         if os.environ.get("NR_CTRL_DEDUP", "1") == "0" or not self.config.set_noisy_sample_input_to_zero:
             frames = None
+        elif getattr(self, "_cframes_explicit", None) is not None:
+            f = controlnet_cond.shape[2]
+            frames = tuple(sorted({i % f for i in self._cframes_explicit}))
         else:
-            key = (controlnet_cond.data_ptr(), controlnet_cond._version, conditioning_mask.data_ptr(), conditioning_mask._version,
-                   tuple(controlnet_cond.shape))
-            if getattr(self, "_cframes_key", None) == key:
-                return
-            nz = (controlnet_cond != 0).flatten(3).any(-1).any(1).any(0) | (conditioning_mask != 0).flatten(3).any(-1).any(1).any(0)
-            frames = tuple(int(i) for i in torch.nonzero(nz).flatten().tolist())
-            self._cframes_key = key
-            self._cframes_ref = (controlnet_cond, conditioning_mask)
+            try:
+                key = (controlnet_cond.data_ptr(), controlnet_cond._version, conditioning_mask.data_ptr(), conditioning_mask._version,
+                       tuple(controlnet_cond.shape))
+            except RuntimeError:            # "Inference tensors do not track version counter"
+                key = None
+            if key is not None and getattr(self, "_cframes_key", None) == key:
+                frames = self._cframes_scanned
+            else:
+                nz = (controlnet_cond != 0).flatten(3).any(-1).any(1).any(0) | (conditioning_mask != 0).flatten(3).any(-1).any(1).any(0)
+                frames = tuple(int(i) for i in torch.nonzero(nz).flatten().tolist())
+                self._cframes_key = key
+                self._cframes_scanned = frames
+                self._cframes_ref = (controlnet_cond, conditioning_mask) if key is not None else None    # keeps data_ptr from being reused
         if getattr(self, "_cframes", "unset") != frames:
             if frames is None:
                 _lib.check(_lib.load().nr_sparsectrl_set_condition_frames(self._handle(), None, -1))
@@ -81,6 +97,11 @@ class NativeSparseCtrl(_NativeNet):
                 _lib.check(_lib.load().nr_sparsectrl_set_condition_frames(self._handle(), arr, len(frames)))
             self._cframes = frames
             self._plan_key = None           # the launch plan depends on the frame list
+
+    def invalidate_condition_frames(self):
+        """Forget the cached scan (after an out-of-band write into a condition tensor that is passed again)."""
+        self._cframes_key = None
+        self._cframes_ref = None
 
     def _on_plan(self):
         b, f, h, w, L = self._plan_key

@@ -29,3 +29,18 @@ def test_bench_single_rank_through_rccl():
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["output_finite"]
     assert d["scaling"] == "weak"
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_world_of_one_through_rccl():
+    """`python bench.py --gpus N` without a launcher (the driver's SCALE command form): bench.self_launch starts the rank processes itself
+    before any GPU call.  One GPU here, so --self-launch forces the launcher at N = 1; the rank takes the RCCL path (NR_DIST_FORCE)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--self-launch", "--steps", "1", "--warmup", "1", "--ddim-steps", "4",
+           "--no-cpu-baseline", "--no-psnr", "--no-end-to-end", "--launch-timeout", "800"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["rccl_ranks_seen"] == 1 and d["value"] > 0 and d["config"]["output_finite"]

@@ -92,3 +92,84 @@ def test_c1_loop_to_pixels_with_native_vae(cuda):
         ref = V.decode_latents(vsd, torch.from_numpy(g["final"]), len(vcfg.ch_mult), vcfg.num_res_blocks)
     rel, psnr = metrics("C1 loop + native VAE pixels vs oracle decode of reference latents", video, ref)
     assert psnr >= 35.0
+
+
+class _ForeignDDIM:
+    """A scheduler that exposes ONLY the diffusers surface the reference pipeline touches (pipeline_neuroclips.py:317,378-379,423,436,483):
+    no timesteps_host, no alpha_pair.  Plain torch arithmetic of DDIM eta = 0 (test code, not product)."""
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self):
+        betas = torch.linspace(0.00085, 0.012, 1000, dtype=torch.float32)
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.steps_seen = []
+
+    def set_timesteps(self, n, device=None):
+        self.n = n
+        self.timesteps = (torch.arange(0, n) * (1000 // n)).flip(0).to(torch.int64).add(1).to(device)
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def add_noise(self, x, noise, t):
+        a = self.alphas_cumprod.to(x.device)[t.to(x.device)].flatten().view(-1, 1, 1, 1, 1)
+        return a.sqrt() * x + (1 - a).sqrt() * noise
+
+    def step(self, model_output, timestep, sample, eta=0.0, generator=None):
+        assert torch.is_tensor(timestep) and eta == 0.0
+        t = int(timestep)
+        self.steps_seen.append(t)
+        a_t = float(self.alphas_cumprod[t])
+        a_p = float(self.alphas_cumprod[t - 1000 // self.n]) if t - 1000 // self.n >= 0 else 1.0
+        x0 = (sample - (1 - a_t) ** 0.5 * model_output) / a_t ** 0.5
+        import types
+        return types.SimpleNamespace(prev_sample=a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * model_output)
+
+
+def test_foreign_scheduler_object_is_driven_through_its_step(cuda):
+    """north_star keeps `scheduler.step` as a preserved surface: a caller that hands in its own scheduler object (scripts/neuroclips_video.py:219)
+    gets the reference's call sequence -- scale_model_input, HIP CFG combine (nr_cfg_combine), scheduler.step(...).prev_sample -- and the same
+    latents as the fused nr_cfg_ddim_step path: <= 1e-5 after the first update (pure arithmetic), and far inside the loop tolerance at the end
+    (the two updates differ in fp32 rounding only; the bf16 networks see 1-ulp different inputs from step 2 on)."""
+    from neurons_amd import DDIMScheduler, NeuroclipsPipeline
+    g = np.load(os.path.join(GOLD, "c1_loop.npz"))
+    outs, firsts = [], []
+    for sched in (DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False), _ForeignDDIM()):
+        unet, ctrl = _tiny()
+        pipe = NeuroclipsPipeline(vae=None, text_encoder=None, tokenizer=None, unet=unet, scheduler=sched, controlnet=ctrl).to("cuda")
+        first = []
+        out = pipe("", video_length=8, height=64, width=64, num_inference_steps=int(g["steps"]), guidance_scale=float(g["guidance"]),
+                   latents=torch.from_numpy(g["latents"]).cuda(), noise=torch.from_numpy(g["noise"]),
+                   text_embeddings=torch.from_numpy(g["ctx"]).cuda(), controlnet_images=torch.from_numpy(g["cimg"]).cuda(),
+                   controlnet_image_index=[0], low_strength=0.3, output_type="latent",
+                   callback=lambda i, t, lat: first.append(lat.clone()) if i == 0 else None, callback_steps=1).videos
+        outs.append(out.clone())
+        firsts.append(first[0])
+    assert outs[1].dtype == outs[0].dtype and sched.steps_seen == [int(t) for t in g["timesteps"]]
+    d1 = (firsts[0] - firsts[1]).abs().max().item()
+    print(f"foreign scheduler: max |diff| after the first update {d1:.2e}")
+    assert d1 <= 1e-5
+    _, psnr_ref = metrics("foreign scheduler: final latents vs reference", outs[1], g["final"])
+    _, psnr_own = metrics("foreign scheduler vs fused update", outs[1], outs[0])
+    assert psnr_ref >= 40.0 and psnr_own >= 60.0
+
+
+def test_sparsectrl_forward_under_inference_mode(cuda):
+    """inference-mode tensors have no version counter; the condition-frame cache must not read one unguarded."""
+    unet, ctrl = _tiny()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    with torch.inference_mode():
+        x = torch.randn(2, 4, 8, 8, 8, generator=g, device="cuda")
+        ctx = torch.randn(2, 77, 64, generator=g, device="cuda")
+        cond = torch.zeros(1, 4, 8, 8, 8, device="cuda")
+        mask = torch.zeros(1, 1, 8, 8, 8, device="cuda")
+        cond[:, :, 0] = torch.randn(1, 4, 8, 8, generator=g, device="cuda")
+        mask[:, :, 0] = 1
+        down, mid = ctrl(x, 500, encoder_hidden_states=ctx, controlnet_cond=cond, conditioning_mask=mask, return_dict=False)
+        assert ctrl._cframes == (0,)
+        cond[:, :, 3] = 1.0                 # in place, no version counter to notice it: scanned again on every call
+        mask[:, :, 3] = 1
+        ctrl(x, 500, encoder_hidden_states=ctx, controlnet_cond=cond, conditioning_mask=mask, return_dict=False)
+        assert ctrl._cframes == (0, 3)
+    assert torch.isfinite(mid.float()).all()
