@@ -289,6 +289,10 @@ nr_status nr_sparsectrl_set_condition_frames(nr_net* h, const int32_t* frames, i
  * clip's CFG pair instead of the rows of the whole call.  A clip then gets the same result alone, in a batch of 8 (BASELINE config 4) or in
  * any SparseCtrl group size; the price is the speed of the shapes that would have taken another plan.  Changing it invalidates the plan. */
 nr_status nr_net_set_deterministic_batch(nr_net* h, int32_t enable);
+/* How many samples of the batch belong to ONE clip: 2 (default: the classifier-free-guidance pair, pipeline_neuroclips.py:435) or 1 (guidance
+ * off, do_classifier_free_guidance false: the batch holds one sample per clip).  Only read in deterministic-batch mode, where "the rows of
+ * one clip" is what every plan choice is made for; the pipeline sets it per call.  Changing it in that mode invalidates the plan. */
+nr_status nr_net_set_clip_samples(nr_net* h, int32_t samples);
 
 /* ---- converted-weight exchange between handles (multi-GPU start-up) -----------------
  * The reference shards clips over processes and every process loads the checkpoints itself (scripts/neuroclips_video.py:

@@ -458,6 +458,10 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p) {
 
   // all lanes active here.  ONES: dv = 40 = 16 * 2 + 4 * 2 + 0 is element 0 of acc[2] in lane group g = 2 of the query's column c
   float l_all;
+  // ONES: the last P.V MFMAs are inline asm (mfma_bf16_tied), so hipcc does not know acc[] is an in-flight MFMA result and inserts no wait
+  // states in front of its first reader (the ds_bpermute of the shuffle below).  An 8-pass XDL write needs ~11 issue slots on gfx950; the
+  // compiled stream happened to leave ~13 (two branches, a wait, a barrier, four VALU ops): state the distance instead of relying on it.
+  if constexpr (ONES) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
   if constexpr (ONES) l_all = __shfl(acc[2][0], 32 + c, 64);
   else l_all = rows_sum(l_i);
   if (qrow < p.Lq) {

@@ -258,9 +258,10 @@ struct nr_net {
   // folded vs separate, split-K depth, row-panel / fused-kernel eligibility, GroupNorm variant and chunking, the weight-stream rotation of
   // the fused kernels) is made for the rows of ONE clip's CFG pair, so a clip's result does not depend on how many clips share the call
   bool det_batch = false;
-  long long det_rows(long long rows) const {       // rows of this op that belong to one clip's CFG pair (rows itself when not in that mode)
-    if (!det_batch || B2 <= 2) return rows;
-    return rows / B2 * 2;
+  int clip_samples = 2;          // nr_net_set_clip_samples: samples of ONE clip in the batch (2 = CFG pair, 1 = no guidance)
+  long long det_rows(long long rows) const {       // rows of this op that belong to one clip (rows itself when not in that mode)
+    if (!det_batch || B2 <= clip_samples) return rows;
+    return rows / B2 * clip_samples;
   }
   // SparseCtrl only (nr_sparsectrl_set_condition_frames): the frames whose condition / mask is not all zero.  With the noisy sample zeroed
   // (sparse_controlnet.py:468-469) every OTHER frame enters the network as the same constant image (conv_in(0) + cond_embedding(0) =
@@ -2258,6 +2259,14 @@ extern "C" nr_status nr_net_set_deterministic_batch(nr_net* h, int32_t enable) {
   NR_TRY
   if (!h) throw NrError(NR_ERR_ARG, "null handle");
   if (h->det_batch != (enable != 0)) { h->det_batch = enable != 0; h->planned = false; }
+  NR_CATCH
+}
+
+extern "C" nr_status nr_net_set_clip_samples(nr_net* h, int32_t samples) {
+  NR_TRY
+  if (!h) throw NrError(NR_ERR_ARG, "null handle");
+  if (samples != 1 && samples != 2) throw NrError(NR_ERR_ARG, "clip samples must be 1 (no guidance) or 2 (CFG pair)");
+  if (h->clip_samples != samples) { h->clip_samples = samples; if (h->det_batch) h->planned = false; }
   NR_CATCH
 }
 

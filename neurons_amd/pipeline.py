@@ -325,6 +325,9 @@ class NeuroclipsPipeline:
 
         lib = _lib.load()
         n_lat = latents.numel()
+        for net in (self.unet, getattr(self, "controlnet", None)):
+            if hasattr(net, "set_clip_samples"):       # deterministic-batch mode plans per clip: a clip is 2 samples with guidance, 1 without
+                net.set_clip_samples(2 if do_classifier_free_guidance else 1)
         fused = use_ctrl and hasattr(self.unet, "forward_with_controlnet") and \
             getattr(self.controlnet, "set_noisy_sample_input_to_zero", False) and self.overlap_controlnet
         # grouped schedule: G steps per SparseCtrl evaluation (controlnet_group_size)

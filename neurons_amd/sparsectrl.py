@@ -13,7 +13,7 @@ from typing import List, Optional
 import torch
 
 from . import _lib
-from .unet3d import _on_device, UNet3DConfig, _NativeNet
+from .unet3d import _on_device, UNet3DConfig, _NativeNet, tensor_version
 
 
 @dataclass
@@ -76,11 +76,9 @@ class NativeSparseCtrl(_NativeNet):
             f = controlnet_cond.shape[2]
             frames = tuple(sorted({i % f for i in self._cframes_explicit}))
         else:
-            try:
-                key = (controlnet_cond.data_ptr(), controlnet_cond._version, conditioning_mask.data_ptr(), conditioning_mask._version,
-                       tuple(controlnet_cond.shape))
-            except RuntimeError:            # "Inference tensors do not track version counter"
-                key = None
+            vc, vm = tensor_version(controlnet_cond), tensor_version(conditioning_mask)
+            key = (controlnet_cond.data_ptr(), vc, conditioning_mask.data_ptr(), vm, tuple(controlnet_cond.shape)) \
+                if isinstance(vc, int) and isinstance(vm, int) else None          # no counter ("Inference tensors do not track version counter")
             if key is not None and getattr(self, "_cframes_key", None) == key:
                 frames = self._cframes_scanned
             else:
@@ -210,7 +208,7 @@ class NativeSparseCtrl(_NativeNet):
             self._io_cond = torch.empty(cb, self.config.conditioning_channels, f, h, w, dtype=torch.float32, device=ctx.device)
             self._io_mask = torch.empty(cb, 1, f, h, w, dtype=torch.float32, device=ctx.device)
             self._cond_key = None
-        ckey = (controlnet_cond.data_ptr(), controlnet_cond._version, conditioning_mask.data_ptr(), conditioning_mask._version,
+        ckey = (controlnet_cond.data_ptr(), tensor_version(controlnet_cond), conditioning_mask.data_ptr(), tensor_version(conditioning_mask),
                 tuple(controlnet_cond.shape), self._plan_key)
         if getattr(self, "_cond_key", None) != ckey:      # staged once per clip: an evaluation in flight may be reading it
             self._io_cond.copy_(controlnet_cond)

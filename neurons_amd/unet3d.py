@@ -286,6 +286,15 @@ def _on_device(fn):
     return inner
 
 
+def tensor_version(t):
+    """In-place version counter of ``t`` for identity-based caches, or a fresh unique object when the tensor has none (tensors created
+    under torch.inference_mode raise on ``._version``): such tensors never hit a cache, they are re-staged / re-scanned on every call."""
+    try:
+        return t._version
+    except RuntimeError:
+        return object()
+
+
 class _NativeNet:
     """Shared handle management for the two networks."""
     _kind = _lib.NR_KIND_UNET3D
@@ -358,6 +367,15 @@ class _NativeNet:
         self._plan_key = None
         return self
 
+    def set_clip_samples(self, samples):
+        """Samples of one clip in the batch: 2 = CFG pair (default), 1 = guidance off (``nr_net_set_clip_samples``; read in
+        deterministic-batch mode only)."""
+        if getattr(self, "_clip_samples", 2) != int(samples):
+            _lib.check(_lib.load().nr_net_set_clip_samples(self._handle(), int(samples)))
+            self._clip_samples = int(samples)
+            self._plan_key = None
+        return self
+
     def state_dict_keys(self):
         return list(self._schema.keys())
 
@@ -425,7 +443,7 @@ class _NativeNet:
     def _set_context(self, ctx):
         """Copy the context into the fixed staging buffer only when it changed (tensor identity + in-place version
         counter); the engine then recomputes the cached K|V projections (nr_net_invalidate_context)."""
-        key = (ctx.data_ptr(), ctx._version, tuple(ctx.shape), ctx.dtype)
+        key = (ctx.data_ptr(), tensor_version(ctx), tuple(ctx.shape), ctx.dtype)
         if getattr(self, "_ctx_key", None) != key or getattr(self, "_ctx_plan", None) != self._plan_key:
             self._io_ctx.copy_(ctx)
             _lib.check(_lib.load().nr_net_invalidate_context(self._handle()))
@@ -632,7 +650,7 @@ class NativeUNet3D(_NativeNet):
             controlnet._io_cond = torch.empty(cb, controlnet.config.conditioning_channels, f, h, w, dtype=torch.float32, device=sample.device)
             controlnet._io_mask = torch.empty(cb, 1, f, h, w, dtype=torch.float32, device=sample.device)
         # copy the (step-invariant) condition only when it changed: a prefetched SparseCtrl evaluation may be reading it
-        ckey = (controlnet_cond.data_ptr(), controlnet_cond._version, conditioning_mask.data_ptr(), conditioning_mask._version,
+        ckey = (controlnet_cond.data_ptr(), tensor_version(controlnet_cond), conditioning_mask.data_ptr(), tensor_version(conditioning_mask),
                 tuple(controlnet_cond.shape), controlnet._plan_key)
         if getattr(controlnet, "_cond_key", None) != ckey:
             _lib.check(_lib.load().nr_net_invalidate_context(controlnet._handle()))     # drops any prefetched evaluation

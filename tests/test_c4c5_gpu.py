@@ -220,3 +220,76 @@ def test_deterministic_batch_mode_makes_a_clip_independent_of_its_neighbours(cud
     finally:
         unet.set_deterministic_batch(False)
         ctrl.set_deterministic_batch(False)
+
+
+def test_deterministic_batch_mode_without_guidance(cuda, nets):
+    """with guidance off the batch holds ONE sample per clip (pipeline_neuroclips.py:435 does not double the latents), so 'the rows
+    of one clip' is half of what the CFG case plans for.  nr_net_set_clip_samples (set by the pipeline per call) tells the engine; a clip of a
+    batch of 4 must then equal the same clip alone bit for bit, as in the CFG test above.  Full width, (4,4,16,32,32), 4 DDIM steps."""
+    from neurons_amd import DDIMScheduler, NeuroclipsPipeline
+    n = nets
+    unet, ctrl = n["unet"], n["ctrl"]
+    unet.set_attention_fp8(False)
+    ctrl.set_attention_fp8(False)
+    unet.set_deterministic_batch(True)
+    ctrl.set_deterministic_batch(True)
+    try:
+        sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
+        pipe = NeuroclipsPipeline(vae=None, text_encoder=None, tokenizer=None, unet=unet, scheduler=sched, controlnet=ctrl).to(cuda)
+        B, F, L, steps = 4, 16, 32, 4
+        g = torch.Generator(device=cuda).manual_seed(1002)
+        lat = torch.randn(B, 4, F, L, L, generator=g, device=cuda)
+        noise = torch.randn(B, 4, F, L, L, generator=g, device=cuda)
+        ctx = torch.randn(B, 77, n["ucfg"].cross_attention_dim, generator=g, device=cuda)
+        cimg = torch.randn(B, 4, 1, L, L, generator=g, device=cuda) * 0.18215
+        kw = dict(video_length=F, height=L * 8, width=L * 8, num_inference_steps=steps, guidance_scale=1.0, controlnet_image_index=[0],
+                  low_strength=0.3, output_type="latent")
+        both = pipe([""] * B, latents=lat, noise=noise, text_embeddings=ctx, controlnet_images=cimg, **kw).videos.clone()
+        assert torch.isfinite(both).all()
+        nequal = 0
+        for i in (0, B - 1):
+            one = pipe("", latents=lat[i:i + 1], noise=noise[i:i + 1], text_embeddings=ctx[i:i + 1], controlnet_images=cimg[i:i + 1], **kw).videos
+            nequal += int(torch.equal(both[i:i + 1], one))
+            _, psnr = metrics(f"deterministic-batch mode, guidance off: clip {i} of a batch of {B} vs the same clip alone", both[i:i + 1], one)
+            assert psnr >= 60.0, psnr
+        assert nequal == 2, "one sample per clip: the per-clip plan must not depend on the batch"
+    finally:
+        unet.set_deterministic_batch(False)
+        ctrl.set_deterministic_batch(False)
+        unet.set_clip_samples(2)
+        ctrl.set_clip_samples(2)
+
+
+def test_c4_full_50_step_loop_two_clips(cuda, nets):
+    """BASELINE config 4's loop at its FULL length on the GPU gate (the 8-clip test above stops at 12 steps): two clips in
+    one call, (2,4,16,32,32), 50 DDIM steps, CFG 8.5, SparseCtrl on (grouped), against the same clips run alone and clip 1 against the fp32
+    oracle's 50-step loop.  Same stated tolerances as every loop-level test."""
+    from neurons_amd import DDIMScheduler, NeuroclipsPipeline
+    n = nets
+    O = n["O"]
+    n["unet"].set_attention_fp8(False)
+    n["ctrl"].set_attention_fp8(False)
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
+    pipe = NeuroclipsPipeline(vae=None, text_encoder=None, tokenizer=None, unet=n["unet"], scheduler=sched, controlnet=n["ctrl"]).to(cuda)
+    B, F, L, steps = 2, 16, 32, 50
+    g = torch.Generator(device=cuda).manual_seed(1050)
+    lat = torch.randn(B, 4, F, L, L, generator=g, device=cuda)
+    noise = torch.randn(B, 4, F, L, L, generator=g, device=cuda)
+    ctx_u = torch.randn(B, 77, n["ucfg"].cross_attention_dim, generator=g, device=cuda)
+    ctx_t = torch.randn(B, 77, n["ucfg"].cross_attention_dim, generator=g, device=cuda)
+    cimg = torch.randn(B, 4, 1, L, L, generator=g, device=cuda) * 0.18215
+    kw = dict(video_length=F, height=L * 8, width=L * 8, num_inference_steps=steps, guidance_scale=8.5, controlnet_image_index=[0],
+              low_strength=0.3, output_type="latent")
+    both = pipe([""] * B, latents=lat, noise=noise, text_embeddings=torch.cat([ctx_u, ctx_t]), controlnet_images=cimg, **kw).videos.clone()
+    assert torch.isfinite(both).all()
+    for i in range(B):
+        one = pipe("", latents=lat[i:i + 1], noise=noise[i:i + 1], text_embeddings=torch.cat([ctx_u[i:i + 1], ctx_t[i:i + 1]]),
+                   controlnet_images=cimg[i:i + 1], **kw).videos
+        rel, psnr = metrics(f"C4 50 steps: clip {i} of a batch of {B} vs the same clip alone", both[i:i + 1], one)
+        assert psnr >= BATCH_VS_SINGLE_DB and rel <= BATCH_VS_SINGLE_REL, (i, psnr, rel)
+    i = 1
+    with torch.no_grad():
+        want, _ = O.neuroclips_denoise(n["usd"], n["ou"], n["csd"], n["oc"], lat[i:i + 1], noise[i:i + 1],
+                                       torch.cat([ctx_u[i:i + 1], ctx_t[i:i + 1]]), cimg[i:i + 1], (0,), steps, 8.5)
+    rel, psnr = metrics(f"C4 50 steps: clip {i} of the batched call vs the fp32 oracle", both[i:i + 1], want)
+    assert psnr >= LOOP_PSNR_DB and rel <= LOOP_REL_L2, (psnr, rel)
