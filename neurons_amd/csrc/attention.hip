@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(NrAttnParams p) {
         bf16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[i][e] * inv);
-        *(bf16x4*)(op + dv0) = o;
+        nr_store8(op + dv0, o);
       }
     }
   }
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void attn_fwd_shared_kernel(NrAttnParams p) {
         bf16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[i][e] * inv);
-        *(bf16x4*)(op + dv0) = o;
+        nr_store8(op + dv0, o);
       }
     }
   }

@@ -59,6 +59,52 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ----------------------------------------------------------------------------------------------
+// Output stores.  The eight XCD L2s are not coherent with each other, so the release at the end of every kernel writes the L2's dirty lines
+// back before the next kernel of the stream may start: with plain stores that write-back sits on the critical path between two launches
+// (MI355X_MICROARCH.md price list, row "boundary": + B / 6 TB/s for B dirty bytes, 1.7 us behind a 10 MB activation).  NR_STORE_WT builds
+// store activations write-through (`sc1`: agent scope, the bytes leave the L2 while the kernel still computes; same instruction rate as a
+// plain 16-byte store), so the end-of-kernel release finds nothing to write.  The consumer kernel reads them from the Infinity Cache, where
+// 7 of its 8 XCDs had to look anyway.  Data registers: the hardware needs them for two wait states only (s_nop 1), as in rowpanel.hip.
+#ifndef NR_STORE_WT
+#define NR_STORE_WT 0
+#endif
+__device__ __forceinline__ void nr_store16(bf16* ptr, const bf16x8& v) {
+#if NR_STORE_WT
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(ptr), "v"(v) : "memory");
+#else
+  *(bf16x8*)ptr = v;
+#endif
+}
+__device__ __forceinline__ void nr_store16f(float* ptr, const f32x4& v) {      // split-K slabs: written by one kernel, read by the reduce
+#if NR_STORE_WT
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(ptr), "v"(v) : "memory");
+#else
+  *(f32x4*)ptr = v;
+#endif
+}
+__device__ __forceinline__ void nr_store8(bf16* ptr, const bf16x4& v) {
+#if NR_STORE_WT
+  asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" : : "v"(ptr), "v"(v) : "memory");
+#else
+  *(bf16x4*)ptr = v;
+#endif
+}
+
+// Kernel arguments pinned in SGPRs at entry.  Left alone, hipcc loads the argument block lazily: one s_load + s_waitcnt lgkmcnt(0) in front of
+// every first use (the tiled igemm had 16 such round trips, scalar-cache misses among them, between its entry and its first LDS-DMA: 3,500 of the
+// ~20,000 cycles of a short-K workgroup, profiles/r05_igemm_timeline.txt).  An empty asm that takes the value as an "s" operand makes it opaque
+// (no rematerialisation from the argument segment), so every pinned field is fetched by the loads the compiler batches at the top of the kernel.
+#ifndef NR_PIN_ARGS
+#define NR_PIN_ARGS 1     // 0: the lazy loads again (A/B arm: make variant NAME=nopin VFLAGS=-DNR_PIN_ARGS=0)
+#endif
+template <class T> __device__ __forceinline__ T nr_pin(T v) {
+#if NR_PIN_ARGS
+  asm volatile("" : "+s"(v));
+#endif
+  return v;
+}
+
+// ----------------------------------------------------------------------------------------------
 // Launch-parameter structs shared between the kernels (*.hip) and the engine (engine.hip).
 // ----------------------------------------------------------------------------------------------
 
@@ -102,6 +148,17 @@ struct NrGemmParams {
                        // The 9 re-reads of an activation row segment then fall into 9 consecutive k-tiles (L2 hits) instead of being
                        // spread over the whole K loop (tap-major order: the working set of the tiles in flight exceeds the 4 MiB L2)
 };
+
+__device__ __forceinline__ NrGemmParams nr_pin_params(NrGemmParams p) {
+  p.a0 = nr_pin(p.a0); p.a1 = nr_pin(p.a1); p.c0 = nr_pin(p.c0); p.c1 = nr_pin(p.c1); p.lda0 = nr_pin(p.lda0); p.lda1 = nr_pin(p.lda1);
+  p.H = nr_pin(p.H); p.W = nr_pin(p.W); p.OH = nr_pin(p.OH); p.OW = nr_pin(p.OW); p.ksize = nr_pin(p.ksize); p.stride = nr_pin(p.stride);
+  p.ups = nr_pin(p.ups); p.w = nr_pin(p.w); p.M = nr_pin(p.M); p.N = nr_pin(p.N); p.K = nr_pin(p.K); p.bias = nr_pin(p.bias);
+  p.rowvec = nr_pin(p.rowvec); p.rowvec_div = nr_pin(p.rowvec_div); p.rowvec_mod = nr_pin(p.rowvec_mod); p.rowvec_ld = nr_pin(p.rowvec_ld);
+  p.res = nr_pin(p.res); p.ldr = nr_pin(p.ldr); p.out = nr_pin(p.out); p.ldo = nr_pin(p.ldo); p.out_scale = nr_pin(p.out_scale);
+  p.geglu = nr_pin(p.geglu); p.ln_c = nr_pin(p.ln_c); p.ln_eps = nr_pin(p.ln_eps); p.act = nr_pin(p.act); p.pad_tl0 = nr_pin(p.pad_tl0);
+  p.out_f32 = nr_pin(p.out_f32); p.tap_inner = nr_pin(p.tap_inner);
+  return p;
+}
 
 // Row-panel GEMM (rowpanel.hip): out = epilogue(a . w^T), K = 320, the 256-row panel held in registers
 struct NrRowPanelParams {

@@ -317,7 +317,7 @@ __global__ void add_bf16_kernel(const bf16* __restrict__ a, const bf16* __restri
   bf16x8 o;
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)va[e] + (float)vb[e]);
-  ((bf16x8*)out)[i] = o;
+  nr_store16((bf16*)out + 8 * i, o);
 }
 
 __global__ __launch_bounds__(256) void add_bf16_multi_kernel(NrAddMulti p) {
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void add_bf16_multi_kernel(NrAddMulti p) {
   bf16x8 o;
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)va[e] + (float)vb[e]);
-  ((bf16x8*)p.dst[t])[j] = o;
+  nr_store16(p.dst[t] + 8 * j, o);
 }
 
 // fp32 [rows][C] -> bf16 [rows][C]

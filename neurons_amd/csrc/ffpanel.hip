@@ -380,7 +380,7 @@ __global__ __launch_bounds__(MT == 2 ? 256 : 512, MT == 2 ? 1 : 2) void ff_fused
       bf16x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (bf16)(oacc[nt][mt][e] + b[e] + (float)xv[e]);
-      *(bf16x4*)(orow + 16 * nt) = o;
+      nr_store8(orow + 16 * nt, o);
     }
   }
 }

@@ -87,7 +87,9 @@ __device__ unsigned long long nr_stamp_buf[512][NR_STAMP_SLOTS];
 #endif
 
 template <int BM, int BN, int NS, int WGM, int WGN, bool LNF = false, bool ADMA = false>
-__global__ __launch_bounds__(64 * WGM * WGN, (LNF && WGM * WGN == 8) ? 4 : 1) void igemm_bf16_kernel(NrGemmParams p, int splitk, float* partial, int m_fast) {
+__global__ __launch_bounds__(64 * WGM * WGN, (LNF && WGM * WGN == 8) ? 4 : 1) void igemm_bf16_kernel(NrGemmParams p_arg, int splitk, float* partial, int m_fast) {
+  const NrGemmParams p = nr_pin_params(p_arg);
+  splitk = nr_pin(splitk); partial = nr_pin(partial); m_fast = nr_pin(m_fast);
   constexpr int BK = 64;
   constexpr int NW = WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (LNF && WGM * WGN == 8) ? 4 : 1) vo
       for (int i = 0; i < NT; ++i) {
         const int n = n0 + wn * WN + i * 16 + 4 * fg;
         if (n >= p.N) continue;
-        *(f32x4*)(slab + (size_t)m * p.N + n) = acc[i][j];
+        nr_store16f(slab + (size_t)m * p.N + n, acc[i][j]);
       }
     }
     return;
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (LNF && WGM * WGN == 8) ? 4 : 1) vo
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { o[e] = (bf16)va[e]; o[4 + e] = (bf16)vb[e]; }
-      *(bf16x8*)(p.out + (size_t)m * p.ldo + n) = o;
+      nr_store16(p.out + (size_t)m * p.ldo + n, o);
     }
 #ifdef NR_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (LNF && WGM * WGN == 8) ? 4 : 1) vo
         bf16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-        *(bf16x4*)(p.out + (size_t)m * p.ldo + n) = o;
+        nr_store8(p.out + (size_t)m * p.ldo + n, o);
       }
     } else {
       if constexpr (NT % 2 == 0) {
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (LNF && WGM * WGN == 8) ? 4 : 1) vo
           bf16x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (bf16)(v[e] * gelu_erf_fast(g[e]));
-          *(bf16x4*)(p.out + (size_t)m * p.ldo + oc) = o;
+          nr_store8(p.out + (size_t)m * p.ldo + oc, o);
         }
       }
     }
@@ -568,7 +570,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (LNF && WGM * WGN == 8) ? 4 : 1) vo
 }
 
 // out[m][n] = epilogue( sum_s partial[s][m][n] ), 4 consecutive n per thread
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(NrGemmParams p, int splitk, const float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(NrGemmParams p_arg, int splitk, const float* __restrict__ partial) {
+  const NrGemmParams p = nr_pin_params(p_arg);
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   const int n4 = p.N >> 2;
   if (idx >= (long long)p.M * n4) return;
@@ -593,7 +596,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(NrGemmParams p, int 
   bf16x4 o;
 #pragma unroll
   for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-  *(bf16x4*)(p.out + (size_t)m * p.ldo + n) = o;
+  nr_store8(p.out + (size_t)m * p.ldo + n, o);
 }
 
 struct Plan { int bm, bn, splitk, stages, waves; };

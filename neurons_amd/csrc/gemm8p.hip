@@ -57,7 +57,9 @@ __device__ __forceinline__ size_t rowvec_row(const NrGemmParams& p, int m) {
 constexpr int G8_BM = 256, G8_BK = 64;
 
 template <int NT, bool TAPI, int NPH = 4>
-__global__ __launch_bounds__(512, 2) void g8p_kernel(NrGemmParams p, int m_fast) {
+__global__ __launch_bounds__(512, 2) void g8p_kernel(NrGemmParams p_arg, int m_fast) {
+  const NrGemmParams p = nr_pin_params(p_arg);      // one batch of scalar loads at entry instead of a round trip per first use (common.h)
+  m_fast = nr_pin(m_fast);
   constexpr int BN = 64 * NT, WN = 16 * NT;
   constexpr int A_BYTES = G8_BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   static_assert(NPH == 4 || (NPH == 2 && NT <= 4), "phases per k-tile");
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(512, 2) void g8p_kernel(NrGemmParams p, int m_fast)
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { o[e] = (bf16)va[e]; o[4 + e] = (bf16)vb[e]; }
-      *(bf16x8*)(p.out + (size_t)m * p.ldo + n) = o;
+      nr_store16(p.out + (size_t)m * p.ldo + n, o);
     }
   }
 }

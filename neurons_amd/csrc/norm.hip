@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(NrGnParams p) {
             if (p.silu) f = silu_f(f);
             o[e] = (bf16)f;
           }
-          *(bf16x8*)(dst + (img_row + px + u * PL) * p.ldo) = o;
+          nr_store16(dst + (img_row + px + u * PL) * p.ldo, o);
         }
       }
       for (; px < pend; px += PL) {
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(NrGnParams p) {
           if (p.silu) f = silu_f(f);
           o[e] = (bf16)f;
         }
-        *(bf16x8*)(dst + (img_row + px) * p.ldo) = o;
+        nr_store16(dst + (img_row + px) * p.ldo, o);
       }
     }
     return;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(NrGnParams p) {
       if (p.silu) f = silu_f(f);
       o[e] = (bf16)f;
     }
-    *(bf16x8*)(p.out + row * p.ldo + c) = o;
+    nr_store16(p.out + row * p.ldo + c, o);
   }
 }
 
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(T) void gn_slab_kernel(NrGnParams p, int GS) {
         if (p.silu) f = silu_f(f);
         o[e] = (bf16)f;
       }
-      *(bf16x8*)(dst + (size_t)px * p.ldo) = o;
+      nr_store16(dst + (size_t)px * p.ldo, o);
     }
   }
 }
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (bf16)f[e];
-      *(bf16x8*)(out + (size_t)row * ldo + cc * 8) = o;
+      nr_store16(out + (size_t)row * ldo + cc * 8, o);
     }
   }
 }

@@ -44,7 +44,11 @@ __device__ __forceinline__ void glds16(const void* src, unsigned lds_wave_base) 
 // every chunk behind the previous chunk's HBM writes.  The hardware only needs the registers for two wait states (s_nop 1).
 // rsrc: the four descriptor words in SGPRs; off: byte offset per lane (range-checked: out-of-range lanes are dropped).
 __device__ __forceinline__ void buffer_store16(const u32x4& v, const u32x4& rsrc, unsigned off) {
+#if NR_STORE_WT
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc1\n\ts_nop 1" : : "v"(v), "v"(off), "s"(rsrc) : "memory");
+#else
   asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(v), "v"(off), "s"(rsrc) : "memory");
+#endif
 }
 
 // s_waitcnt vmcnt(n) for a wave-uniform runtime n in [0, 15]

@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void tattn_fused_kernel(NrTAttnParams p) {
       bf16x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (bf16)(oacc[nt][mt][e] + bb[e] + (float)xv[e]);
-      *(bf16x4*)(tr + 16 * nt) = o;
+      nr_store8(tr + 16 * nt, o);
     }
   }
 }

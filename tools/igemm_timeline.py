@@ -77,6 +77,12 @@ def run(M, N, K, res, pool_mb, smallm, force=None):
           " ".join(f"{k}={med[k]:.0f}" for k in keys), flush=True)
 
 
+if os.environ.get("TIMELINE_SHAPES"):      # "M,N,K,res;M,N,K,res;..." : the tiled igemm only, hot and HBM-cold weights
+    for pool in (0, 600):
+        for spec in os.environ["TIMELINE_SHAPES"].split(";"):
+            M_, N_, K_, r_ = (int(v) for v in spec.split(","))
+            run(M_, N_, K_, bool(r_), pool, False, os.environ.get("TIMELINE_FORCE") or None)
+    sys.exit(0)
 for pool in (0, 600):
     for smallm in (False,) if (os.environ.get("TIMELINE_IGEMM_ONLY") or not HAS_SMALLM) else (False, True):
         run(512, 1280, 1280, True, pool, smallm)
