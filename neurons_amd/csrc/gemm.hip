@@ -86,9 +86,13 @@ __device__ unsigned long long nr_stamp_buf[512][NR_STAMP_SLOTS];
 #define NR_STAMP_AT(slot) do { } while (0)
 #endif
 
-template <int BM, int BN, int NS, int WGM, int WGN, bool LNF = false, bool ADMA = false>
+// LIN: the launch is a plain Linear (1x1, one source): the im2col / tap / two-source paths are compiled out.  Same arithmetic; what it buys is
+// code size: a launch starts with a cold instruction cache (tools/icache_probe.py: +0.4-1.4 us per launch when instantiations alternate, as
+// they do in the engine's graphs), and two thirds of the launches of a denoising step are Linears.  LayerNorm-folded launches are always Linears.
+template <int BM, int BN, int NS, int WGM, int WGN, bool LNF = false, bool ADMA = false, bool LIN = LNF>
 __global__ __launch_bounds__(64 * WGM * WGN, (LNF && WGM * WGN == 8) ? 4 : 1) void igemm_bf16_kernel(NrGemmParams p_arg, int splitk, float* partial, int m_fast) {
-  const NrGemmParams p = nr_pin_params(p_arg);
+  NrGemmParams p = nr_pin_params(p_arg);
+  if constexpr (LIN) { p.ksize = 1; p.stride = 1; p.ups = 0; p.a1 = nullptr; p.c1 = 0; p.tap_inner = 0; p.pad_tl0 = 0; }
   splitk = nr_pin(splitk); partial = nr_pin(partial); m_fast = nr_pin(m_fast);
   constexpr int BK = 64;
   constexpr int NW = WGM * WGN;
@@ -709,6 +713,22 @@ int launch_cfg(const NrGemmParams& p, unsigned grid, int splitk, float* partial,
   }
   static const int adma_min = getenv("NR_IGEMM_ADMA_MINK") ? atoi(getenv("NR_IGEMM_ADMA_MINK")) : 24;   // k-tiles per slice; A/B switch
   const int nk_slice = (p.K / 64) / (splitk > 0 ? splitk : 1);
+  // plain Linears (1x1, one source) on the instantiation without the conv paths (rings up to 4 deep: the ones Linears are planned with)
+  static const bool lin_on = !(getenv("NR_IGEMM_LIN") && getenv("NR_IGEMM_LIN")[0] == '0');            // A/B switch
+  if constexpr (NS <= 4) {
+    if (lin_on && p.ksize == 1 && !p.a1 && p.c1 == 0) {
+      static unsigned long long attr_lin = 0;
+      if (attr_needed(attr_lin)) {
+        (void)hipFuncSetAttribute((const void*)igemm_bf16_kernel<BM, BN, NS, WGM, WGN, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        (void)hipFuncSetAttribute((const void*)igemm_bf16_kernel<BM, BN, NS, WGM, WGN, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      }
+      if (nk_slice >= adma_min)
+        hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, NS, WGM, WGN, false, true, true>), dim3(grid), dim3(64 * WGM * WGN), shm, stream, p, splitk, partial, m_fast);
+      else
+        hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, NS, WGM, WGN, false, false, true>), dim3(grid), dim3(64 * WGM * WGN), shm, stream, p, splitk, partial, m_fast);
+      return 0;
+    }
+  }
   if (nk_slice >= adma_min)
     hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, NS, WGM, WGN, false, true>), dim3(grid), dim3(64 * WGM * WGN), shm, stream, p, splitk,
                        partial, m_fast);
