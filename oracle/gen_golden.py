@@ -374,6 +374,48 @@ def gen_leaf_ops(out_dir):
     print("leaf_ops:", {k: v.shape for k, v in out.items()})
 
 
+@torch.no_grad()
+def gen_leaf_wide(out_dir):
+    """Round 5: the two composite modules of the 16x16 and 8x8 levels -- C = 640 (8 heads of d = 80) and C = 1280 (d = 160) -- at
+    exactly the shapes BASELINE config 2 runs them: CFG batch 2 x 16 frames x 16x16 (8192 rows) and x 8x8 (2048 rows).  Reference classes
+    (attention.py:95-142,256-300; motion_module.py:134-158,210-222), weights / inputs from the Philox recipe of gen_leaf_ops, outputs stored as
+    a deterministic subsample (tests/golden/leaf_wide.npz)."""
+    from neurons_amd.synth import randn
+    _, _, ref_attention, ref_mm, _ = reference_classes()
+    out = {}
+
+    def fill(mod, tag, seed):
+        sd = {}
+        for k, v in mod.state_dict().items():
+            if k.endswith("pos_encoder.pe"):
+                continue
+            z = randn(f"{tag}.{k}", tuple(v.shape), seed)
+            if v.dim() == 1:
+                z = (1.0 + 0.1 * z) if k.endswith("weight") else 0.05 * z
+            else:
+                z = z / (int(np.prod(v.shape[1:])) ** 0.5)
+            sd[k] = z
+        mod.load_state_dict(sd, strict=False)
+        return mod.eval()
+
+    for C, hw, seed in ((640, 16, 71), (1280, 8, 75)):
+        tm = fill(ref_mm.VanillaTemporalModule(in_channels=C, num_attention_heads=8, num_transformer_block=1,
+                                               attention_block_types=("Temporal_Self", "Temporal_Self"),
+                                               temporal_position_encoding=True, temporal_position_encoding_max_len=24,
+                                               zero_initialize=False), f"tm{C}", seed)
+        y = tm(randn(f"tm{C}.x", (2, C, 16, hw, hw), seed + 1), None, None)
+        out[f"tm{C}.idx"], out[f"tm{C}.val"] = _sub(y, 16384)
+        out[f"tm{C}.shape"] = np.array(y.shape)
+        t3 = fill(ref_attention.Transformer3DModel(8, C // 8, in_channels=C, num_layers=1, cross_attention_dim=768, norm_num_groups=32,
+                                                   unet_use_cross_frame_attention=False, unet_use_temporal_attention=False), f"t3d{C}", seed + 2)
+        y = t3(randn(f"t3d{C}.x", (2, C, 16, hw, hw), seed + 3), encoder_hidden_states=randn(f"t3d{C}.ctx", (2, 77, 768), seed + 4)).sample
+        out[f"t3d{C}.idx"], out[f"t3d{C}.val"] = _sub(y, 16384)
+        out[f"t3d{C}.shape"] = np.array(y.shape)
+        print(f"leaf_wide: C = {C} done", flush=True)
+    np.savez_compressed(os.path.join(out_dir, "leaf_wide.npz"), **out)
+    print("leaf_wide:", {k: v.shape for k, v in out.items()})
+
+
 # --------------------------------------------------------------------------------------------------
 # sgm unCLIP path: import the reference's own UNetModel / sampler (SURVEY.md §8c: bypass sgm/__init__.py, which
 # pulls Lightning/open_clip, by pre-registering namespace packages; omegaconf is only used in annotations)
@@ -907,6 +949,7 @@ if __name__ == "__main__":
     unet, ctrl, *_ = gen_networks(out_dir)
     gen_loop(out_dir, unet, ctrl)
     gen_leaf_ops(out_dir)
+    gen_leaf_wide(out_dir)
     gen_sgm(out_dir)
     gen_vae(out_dir)
     gen_clip(out_dir)

@@ -164,6 +164,23 @@ def test_composite_modules_match_reference():
 
 
 @torch.no_grad()
+def test_oracle_wide_leaf_modules_match_reference_golden():
+    """C = 640 (d = 80) and C = 1280 (d = 160) composite modules at the shapes BASELINE config 2 runs them (8192 / 2048 rows):
+    tests/golden/leaf_wide.npz from the reference classes (oracle/gen_golden.py: gen_leaf_wide); the GPU twin is tests/test_leaf_gpu.py."""
+    from neurons_amd.unet3d import _motion_keys, _transformer_keys
+    g = np.load(os.path.join(GOLD, "leaf_wide.npz"))
+    for C, hw, seed in ((640, 16, 71), (1280, 8, 75)):
+        sd = {f"m.{k}": v for k, v in _fill({k[len("m."):]: v for k, v in _motion_keys("m", C, 2).items()}, f"tm{C}", seed).items()}
+        y = O.temporal_transformer3d(sd, "m", randn(f"tm{C}.x", (2, C, 16, hw, hw), seed + 1), 8, 32, 2, 24)
+        assert tuple(y.shape) == tuple(g[f"tm{C}.shape"])
+        _close(f"tm{C}", y.reshape(-1)[torch.from_numpy(g[f"tm{C}.idx"])], g[f"tm{C}.val"])
+        sd = {f"t.{k}": v for k, v in _fill({k[len("t."):]: v for k, v in _transformer_keys("t", C, 768).items()}, f"t3d{C}", seed + 2).items()}
+        y = O.transformer3d(sd, "t", randn(f"t3d{C}.x", (2, C, 16, hw, hw), seed + 3), randn(f"t3d{C}.ctx", (2, 77, 768), seed + 4), 8, 32)
+        assert tuple(y.shape) == tuple(g[f"t3d{C}.shape"])
+        _close(f"t3d{C}", y.reshape(-1)[torch.from_numpy(g[f"t3d{C}.idx"])], g[f"t3d{C}.val"])
+
+
+@torch.no_grad()
 def test_sliced_attention_of_the_oracle_is_value_identical(tiny, monkeypatch):
     """The oracle evaluates softmax(q k^T) v a slice of (batch * heads) at a time when the fp32 score tensor would exceed its budget
     (BASELINE config 5: 34 GB).  Forcing one problem per slice must reproduce the reference golden exactly as the unsliced path does."""
