@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true", help="skip the reference-fixture PSNR run (profiling passes: keeps tiny-network launches out)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-controlnet", action="store_true",
+                    help="DIAGNOSTIC (not BASELINE config 2): the loop without SparseCtrl, to read what the second stream costs the U-Net's chain; "
+                         "the line says so in config.workload")
     ap.add_argument("--no-op-profile", action="store_true",
                     help="skip the per-launch HIP-event pass (rocprofv3 runs: keeps the launch counts of the trace at exactly the timed steps); "
                          "the roofline object is then omitted")
@@ -515,7 +518,7 @@ def main():
     if args.attn_fp8:
         unet.set_attention_fp8(True)
         ctrl.set_attention_fp8(True)
-    headline = args.batch == 1 and args.frames == 16 and args.latent == 32 and not args.attn_fp8
+    headline = args.batch == 1 and args.frames == 16 and args.latent == 32 and not args.attn_fp8 and not args.no_controlnet
 
     # ---- weights: rank 0 generates + converts once; the converted bf16 arenas travel device to device over RCCL/xGMI ----
     t0 = time.time()
@@ -572,7 +575,7 @@ def main():
             _mark(-1, None, None)
             extra = dict(callback=_mark, callback_steps=1)
         return pipe([""] * Bc if Bc > 1 else "", video_length=F, height=L * 8, width=L * 8, num_inference_steps=args.ddim_steps, guidance_scale=8.5,
-                    latents=c["latents"], noise=c["noise"], text_embeddings=c["ctx"], controlnet_images=c["cimg"],
+                    latents=c["latents"], noise=c["noise"], text_embeddings=c["ctx"], controlnet_images=None if args.no_controlnet else c["cimg"],
                     controlnet_image_index=[0], low_strength=0.3, output_type="latent", **extra).videos
 
     for i in range(args.warmup):
@@ -613,7 +616,8 @@ def main():
                 dist.barrier()
                 dist.destroy_process_group()
             return
-        pu, pc = unet.profile_last(), ctrl.profile_last()
+        pu = unet.profile_last()
+        pc = ctrl.profile_last() if not args.no_controlnet else {k: {f: 0.0 for f in v} for k, v in pu.items()}
         pc = {k: {f: v[f] / grp for f in v} for k, v in pc.items()}
         ig_ms = pu["igemm"]["ms"] + pc["igemm"]["ms"]
         ig_fl = pu["igemm"]["flops"] + pc["igemm"]["flops"]
@@ -629,7 +633,8 @@ def main():
             "vs_baseline": None, "dtype": "bf16" if not args.attn_fp8 else "bf16 (attention operands e4m3)", "data": "synthetic",
             "rccl_ranks_seen": rccl_ranks_seen,
             "config": {"workload": f"BASELINE config {5 if (Bc, F, L) == (4, 32, 64) else 4 if Bc > 1 else 2}: {Bc} clip(s) per call, ({Bc},4,{F},{L},{L}) latent, {args.ddim_steps} DDIM steps, CFG 8.5 "
-                                   f"(batch {2 * Bc}), SparseCtrl + temporal U-Net per step, random-init weights",
+                                   f"(batch {2 * Bc}), SparseCtrl + temporal U-Net per step, random-init weights" +
+                                   (" -- DIAGNOSTIC RUN WITHOUT SparseCtrl (--no-controlnet): not the configured workload" if args.no_controlnet else ""),
                        "clips_per_gpu": args.steps * Bc, "frame_steps_per_s": round(value * args.ddim_steps, 2),
                        "ms_per_ddim_step": round(1e3 * elapsed / args.steps / args.ddim_steps, 3),
                        "hip_graph": not args.no_graph, "output_finite": finite, "setup_s": round(setup_s, 1),
