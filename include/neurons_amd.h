@@ -395,6 +395,16 @@ nr_status nr_op_ff_fused(nr_stream stream, const void* t_dev, const void* x_dev,
 nr_status nr_op_tattn_fused(nr_stream stream, void* t_dev, int32_t nbatch, int32_t hw, const void* wq_dev, const void* wk_dev,
                             const void* wv_dev, const void* wo_dev, const float* gamma_dev, const float* gb_dev, const float* bo_dev,
                             float ln_eps);
+/* One CROSS-attention block of the C = 320 level in one launch (xattn.hip, round 5; engine: spatial_transformer):
+ *   t <- t + to_out(softmax(q K^T / sqrt(d)) V),  q = LayerNorm(t) Wq^T,  K | V = the context projections of the row's clip
+ * (attention.py:281-290 norm2 -> attn2 -> + hidden_states, context repeated per frame :100; motion_module_new.py:201-287).
+ * t: bf16 [nimg * hw][320] ("(b f) (h w) c"), updated in place, hw a multiple of 128; image i uses context i / img_per_ctx;
+ * wq, wo: bf16 [320][320] (to_q.weight, to_out[0].weight); kv: bf16 [nctx * Lk][ldkv] with K in columns [0, 320) and V in [320, 640)
+ * (the fused to_k | to_v projection of the context), Lk <= 80; gamma / beta fp32 [320] (norm2); bo fp32 [320] (to_out[0].bias).
+ * wq == NULL re-uses the streams packed by the previous call. */
+nr_status nr_op_xattn_fused(nr_stream stream, void* t_dev, int32_t nimg, int32_t hw, int32_t img_per_ctx, const void* wq_dev,
+                            const void* wo_dev, const void* kv_dev, int32_t ldkv, int32_t Lk, int32_t nctx, const float* gamma_dev,
+                            const float* beta_dev, const float* bo_dev, float ln_eps);
 /* The same for sequences of `frames` = 16 or 32 frames (32: BASELINE config 5, motion_module temporal_position_encoding_max_len = 32):
  * t [nbatch * frames * hw][320], gb [frames][320], hw a multiple of 128 / frames. */
 nr_status nr_op_tattn_fused_frames(nr_stream stream, void* t_dev, int32_t nbatch, int32_t frames, int32_t hw, const void* wq_dev,

@@ -69,6 +69,13 @@ int nr_groupnorm_launches(const NrGnParams* p);
 int nr_launch_fold_linear_pair(const float* w2, const float* w1, const float* b2, const float* b1, int C, int J, bf16* wc, float* bc,
                                hipStream_t stream);
 // tattn.hip: one kernel per temporal-attention block of the C = 320 level
+size_t nr_xattn_wstream_bytes(void);
+size_t nr_xattn_kvstream_bytes(int nctx);
+int nr_xattn_fused_eligible(int C, int heads, int Lk, int hw, long long rows);
+int nr_launch_xattn_w_pack(const bf16* wq, const bf16* wo, bf16* stream, hipStream_t s);
+int nr_launch_xattn_kv_pack(const bf16* kv, int ldkv, int Lk, int nctx, bf16* stream, hipStream_t s);
+int nr_launch_xattn_fused(bf16* t, int nimg, int hw, int img_per_ctx, int Lk, const bf16* wstream, const bf16* kvstream, const float* gamma,
+                          const float* beta, const float* bo, float ln_eps, int norot, hipStream_t s);
 size_t nr_tattn_stream_bytes(void);
 int nr_tattn_fused_eligible(int C, int heads, int frames, int hw, long long rows);
 int nr_launch_tattn_stream_pack(const bf16* wq, const bf16* wk, const bf16* wv, const bf16* wo, bf16* stream, hipStream_t s);
@@ -1001,7 +1008,53 @@ struct nr_net {
         GemmOpt oo; oo.bias = w_f32(b + ".attn1.to_out.0.bias", C); oo.res = &t; oo.out = &t;
         linear(a, w_linear(b + ".attn1.to_out.0.weight", C, C), C, oo);
       }
-      {  // cross-attention on the context (attention.py:100: context repeated per frame)
+      if (cfg.kind != NR_KIND_SGM_UNET && !attn_fp8 && t.ld == C && nr_xattn_fused_eligible(C, heads, ctx_len, x.H * x.W, det_rows(t.rows()))) {
+        // C = 320, 8 heads, <= 80 context tokens, >= 4096 rows: the whole cross-attention block (LayerNorm, q projection, attention on the cached
+        // K | V of the clip, to_out + residual) in ONE launch that updates t in place (xattn.hip); q and the attention output never reach HBM
+        GemmOpt ok;
+        building_ctx = true;      // K|V of the context + their per-head LDS images: recomputed only when the context changes
+        Act kv = new_act_persistent(ctx_bf.nimg, ctx_bf.H, ctx_bf.W, 2 * C);
+        ok.out = &kv;
+        linear(ctx_bf, w_linear_cat({b + ".attn2.to_k.weight", b + ".attn2.to_v.weight"}, C, cfg.cross_attention_dim), 2 * C, ok);
+        const int nctx = ctx_bf.nimg;
+        Act kvs = new_act_persistent(nctx, 1, 1, (int)(nr_xattn_kvstream_bytes(1) / sizeof(bf16)));
+        {
+          const bf16* kvp = kv.ptr; bf16* kvsp = kvs.ptr; const int ldkv = kv.ld, Lk = ctx_len;
+          emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_xattn_kv_pack(kvp, ldkv, Lk, nctx, kvsp, s)); });
+        }
+        building_ctx = false;
+        ctx_persist.push_back(kv);
+        ctx_persist.push_back(kvs);
+        for (const char* wn : {".attn2.to_q.weight", ".attn2.to_out.0.weight"}) check_shape(b + wn, need(b + wn), {C, C});
+        const std::string sname = "xas:" + b + ".attn2.to_q.weight|" + b + ".attn2.to_out.0.weight";
+        const bf16* wstream = (const bf16*)cached(sname, [&]() {
+          void* d = nullptr;
+          const size_t nb = nr_xattn_wstream_bytes();
+          // the two Linear matrices are only the inputs of the packed stream: freed again once it exists (unless another plan made them)
+          const bool had_q = dev.count("lin:" + b + ".attn2.to_q.weight") != 0, had_o = dev.count("lin:" + b + ".attn2.to_out.0.weight") != 0;
+          const bf16* wq = w_linear(b + ".attn2.to_q.weight", C, C);
+          const bf16* wo = w_linear(b + ".attn2.to_out.0.weight", C, C);
+          HIP_OK(hipMalloc(&d, nb));
+          LAUNCH_OK(nr_launch_xattn_w_pack(wq, wo, (bf16*)d, nullptr));
+          HIP_OK(hipDeviceSynchronize());
+          dev[sname] = d; dev_bytes[sname] = nb; weight_bytes += nb;
+          if (!had_q) drop("lin:" + b + ".attn2.to_q.weight");
+          if (!had_o) drop("lin:" + b + ".attn2.to_out.0.weight");
+          return d;
+        });
+        const float* gamma = w_f32(b + ".norm2.weight", C);
+        const float* beta = w_f32(b + ".norm2.bias", C);
+        const float* bo = w_f32(b + ".attn2.to_out.0.bias", C);
+        bf16* tp = t.ptr; const bf16* kvsp = kvs.ptr;
+        const int nimg = t.nimg, hwx = x.H * x.W, ipc = F, Lk = ctx_len;
+        const double M = (double)t.rows();
+        char d[160];
+        snprintf(d, sizeof(d), "xattn_fused M=%d C=%d Lk=%d (LN, q, context attention, to_out + residual)", (int)t.rows(), C, Lk);
+        const int norot = det_batch ? 1 : 0;
+        emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_xattn_fused(tp, nimg, hwx, ipc, Lk, wstream, kvsp, gamma, beta, bo, 1e-5f, norot, s)); }, NR_PROF_IGEMM,
+             2.0 * M * C * 2.0 * C + 4.0 * M * (double)Lk * C, 2.0 * (2.0 * M * C + 2.0 * C * (double)C), d);
+        op_tap("xattn_fused", t);
+      } else {  // cross-attention on the context (attention.py:100: context repeated per frame)
         Act q = ln_linear(t, b + ".norm2", {b + ".attn2.to_q.weight"}, {}, C, false, 0, false);
         GemmOpt ok;
         building_ctx = true;      // K|V of the context: recomputed only when the context changes
@@ -2880,6 +2933,31 @@ extern "C" nr_status nr_op_tattn_fused_frames(nr_stream stream, void* t_dev, int
   if (wq_dev) LAUNCH_OK(nr_launch_tattn_stream_pack((const bf16*)wq_dev, (const bf16*)wk_dev, (const bf16*)wv_dev, (const bf16*)wo_dev, (bf16*)ws,
                                                     (hipStream_t)stream));
   LAUNCH_OK(nr_launch_tattn_fused((bf16*)t_dev, nbatch, frames, hw, (const bf16*)ws, gamma_dev, gb_dev, bo_dev, ln_eps,
+                                  getenv("NR_DETERMINISTIC_BATCH") && getenv("NR_DETERMINISTIC_BATCH")[0] == '1', (hipStream_t)stream));
+  NR_CATCH
+}
+extern "C" nr_status nr_op_xattn_fused(nr_stream stream, void* t_dev, int32_t nimg, int32_t hw, int32_t img_per_ctx, const void* wq_dev,
+                                       const void* wo_dev, const void* kv_dev, int32_t ldkv, int32_t Lk, int32_t nctx, const float* gamma_dev,
+                                       const float* beta_dev, const float* bo_dev, float ln_eps) {
+  NR_TRY
+  if (!t_dev || !kv_dev || !gamma_dev || !beta_dev || !bo_dev) throw NrError(NR_ERR_ARG, "null argument");
+  if (!nr_xattn_fused_eligible(320, 8, Lk, hw, 1 << 30) || nimg <= 0 || img_per_ctx <= 0 || nctx <= 0 || (nimg + img_per_ctx - 1) / img_per_ctx > nctx)
+    throw NrError(NR_ERR_UNSUPPORTED, "fused cross attention: C = 320, 8 heads, Lk <= 80, hw % 128 == 0, one context per img_per_ctx images");
+  static void* ws = nullptr;
+  static void* kvs = nullptr;
+  static size_t kvs_bytes = 0;
+  if (!ws) HIP_OK(hipMalloc(&ws, nr_xattn_wstream_bytes()));
+  if (kvs_bytes < nr_xattn_kvstream_bytes(nctx)) {
+    if (kvs) { HIP_OK(hipDeviceSynchronize()); HIP_OK(hipFree(kvs)); }
+    kvs_bytes = nr_xattn_kvstream_bytes(nctx);
+    HIP_OK(hipMalloc(&kvs, kvs_bytes));
+  }
+  // wq == NULL: reuse the streams packed by the previous call (timing loops)
+  if (wq_dev) {
+    LAUNCH_OK(nr_launch_xattn_w_pack((const bf16*)wq_dev, (const bf16*)wo_dev, (bf16*)ws, (hipStream_t)stream));
+    LAUNCH_OK(nr_launch_xattn_kv_pack((const bf16*)kv_dev, ldkv, Lk, nctx, (bf16*)kvs, (hipStream_t)stream));
+  }
+  LAUNCH_OK(nr_launch_xattn_fused((bf16*)t_dev, nimg, hw, img_per_ctx, Lk, (const bf16*)ws, (const bf16*)kvs, gamma_dev, beta_dev, bo_dev, ln_eps,
                                   getenv("NR_DETERMINISTIC_BATCH") && getenv("NR_DETERMINISTIC_BATCH")[0] == '1', (hipStream_t)stream));
   NR_CATCH
 }

@@ -64,6 +64,23 @@ struct NrTAttnParams {
   int dbg;                 // timing experiments only (NR_FUSED_DBG): 1 no DMA waits, 2 no stage barriers, 4 no DMA issue (results are wrong)
 };
 
+// out-tile accumulation with the accumulator PINNED in the AGPR half of the register file (round 5, as xattn.hip: "+a": vDst = SrcC = an AGPR quad).
+// Left to hipcc the 160 accumulator registers of the out tile lived in VGPRs between the heads and the MFMA groups were bracketed by v_accvgpr
+// copies (584 copies per head iteration for 272 MFMAs).  The asm MFMA is invisible to the compiler's hazard bookkeeping: its A operand comes from
+// LDS (s_waitcnt placed for the asm input), its B operand (ob_prev*) is written by the attention's last phase, which never sits directly in front
+// of one of these MFMAs (phase 6 runs behind the last group), and the accumulator is next touched one head later or by the epilogue behind an
+// explicit s_nop.  tattn.o is compiled with -amdgpu-mfma-vgpr-form so the short-lived projection / attention accumulators stay in VGPRs.
+#ifndef NR_ACC_AGPR
+#define NR_ACC_AGPR 1      // 0: the compiler-allocated form again (A/B arm: make variant NAME=noagpr VFLAGS=-DNR_ACC_AGPR=0)
+#endif
+__device__ __forceinline__ void mfma_acc_agpr(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+#if NR_ACC_AGPR
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+#else
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+#endif
+}
+
 __device__ __forceinline__ s16x4 pack4(const f32x4& v) {
   bf16x4 b;
 #pragma unroll
@@ -326,8 +343,8 @@ __global__ __launch_bounds__(256) void tattn_fused_kernel(NrTAttnParams p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int nt = 4 * q + i;
-        oacc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[i], ks2 ? ob_prev1[0] : ob_prev0[0], oacc[nt][0], 0, 0, 0);
-        oacc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[i], ks2 ? ob_prev1[1] : ob_prev0[1], oacc[nt][1], 0, 0, 0);
+        mfma_acc_agpr(oacc[nt][0], cur[i], ks2 ? ob_prev1[0] : ob_prev0[0]);
+        mfma_acc_agpr(oacc[nt][1], cur[i], ks2 ? ob_prev1[1] : ob_prev0[1]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -363,6 +380,7 @@ __global__ __launch_bounds__(256) void tattn_fused_kernel(NrTAttnParams p) {
   }
   wait_vmcnt<0>();      // the tail's dummy pieces
 
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // the last asm MFMAs' results -> the accumulator reads below (>= 18 wait states, stated not assumed)
   // ---- epilogue: t <- t + bo + acc (lane: frame fr of pixel mt, channels 16 nt + 4 fg .. +3), in place ----
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {

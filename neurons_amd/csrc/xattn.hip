@@ -1,0 +1,499 @@
+// One kernel per CROSS-attention block of the C = 320 level (8 heads of d = 40, text context of up to 80 tokens: 77 on this path), round 5:
+//
+//     t  <-  t + to_out( softmax( q K^T / sqrt(d) ) V ) ,   q = LayerNorm(t) . Wq^T ,   K | V = the cached context projections of the clip
+//
+// i.e. BasicTransformerBlock's `norm2 -> attn2(encoder_hidden_states) -> + hidden_states` (animatediff/models/attention.py:281-290) with the
+// CrossAttention arithmetic of motion_module_new.py:201-287 (to_q without bias, to_out[0] with bias) and the per-frame repeat of the context
+// (attention.py:100).  Until round 5 this was three launches at the 32x32 level -- the LayerNorm-folded q projection (row-panel kernel, 20 us at
+// M = 32768), the 77-key attention core (25 us) and the to_out GEMM + residual (22 us) -- with q and the attention output (21 MB each) round-tripping
+// through HBM.  Every step of it is ROW-LOCAL (a query row only meets the 77 context rows of its clip), so a workgroup owns 128 consecutive rows of
+// t and nothing but t leaves the chip.  The skeleton is tattn.hip's (VERDICT r4 next #2b: "keys = 77 is the same regime as F = 16 / 32"):
+//
+//   * 256-thread workgroup = 4 waves, one per SIMD; wave w owns rows 32 w .. 32 w + 31 of the workgroup's 128 = 2 MFMA row tiles.
+//   * prologue: the wave's 32 x 320 panel of t -> registers, two-pass LayerNorm in registers, rounded to bf16 in place (the rounding point of the
+//     un-fused LayerNorm kernel), kept as MFMA fragments (80 VGPRs).
+//   * per head h three stages stream through a ring of three LDS slots by linear LDS-DMA copies (the streams are stored in HBM as the LDS images):
+//        q_h   [48 n][320 k] (40 rows + 8 zero rows, XOR-swizzled [48][64] sub-tiles):  acc = Wq_h . xn^T  (lane: 4 channels of its row)
+//        kv_h  of the row's CLIP: K_h [80 keys][56] and V_h^T [48 ch][88] (padded row strides of 28 / 44 dwords: the 8-byte fragment reads of a
+//              16 x 2-lane group then touch all 64 banks once), packed once per context by xattn_kv_pack_kernel from the cached K | V projection
+//        o_h   [320 n][64 k-slots]: Wo[:, 40 h .. 40 h + 39] in the k order in which the attention output sits in registers (as tattn.hip)
+//   * attention of (row tile, head) in registers with v_mfma_f32_16x16x16_bf16: S^T = K Q^T (5 key tiles x 3 channel tiles), softmax over the 80
+//     slots = 5 x 4 registers x 4 lane groups (keys >= Lk masked), O^T = V^T P^T (3 x 5); every accumulator -> operand hand-over is lane-local.
+//   * out += Wo_h . O_h^T accumulates over the heads in 160 VGPRs; epilogue t + bo + acc, written in place (rows are private).
+// Algorithmic work per launch at M = 32768: 13.4 GFLOP of projections + 3.2 GFLOP of attention; HBM: t in + t out = 42 MB.
+#include "common.h"
+#include <cstdlib>
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ void glds16(const void* src, unsigned lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_wave_base) : "memory", "m0");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+constexpr int XA_C = 320, XA_HEADS = 8, XA_D = 40;
+constexpr int XA_ROWS = 128;                    // rows per workgroup
+constexpr int XA_KEYS = 80;                     // key slots (5 tiles of 16); Lk <= 80
+constexpr int XA_QSUB = 48 * 64;                // elements of one [48][64] sub-tile of the q stage
+constexpr int XA_Q_BYTES = 32 * 1024;           // q stage: 30 KiB image + 2 KiB pad (8 DMA pieces per wave)
+constexpr int XA_OSUB = 64 * 64;
+constexpr int XA_O_BYTES = 40 * 1024;           // o stage: five [64][64] sub-tiles (10 pieces per wave)
+constexpr int XA_W_HEAD_BYTES = XA_Q_BYTES + XA_O_BYTES;
+constexpr int XA_KLD = 56, XA_VLD = 88;         // row strides (elements) of the K / V^T images: 28 / 44 dwords = 4 x odd
+constexpr int XA_K_BYTES = 9 * 1024;            // 80 x 56 x 2 = 8960 B, padded
+constexpr int XA_KV_BYTES = 20 * 1024;          // K image at 0, V^T image (48 x 88 x 2 = 8448 B) at 9 KiB: 5 pieces per wave
+constexpr int XA_SLOT = XA_O_BYTES;             // ring slot
+constexpr int XA_NS = 3;
+
+#ifdef NR_STAMP
+// Diagnostic build only (make stamp, tools/xattn_timeline.py): shader-clock stamps of wave 0 of the first 256 workgroups; no output depends on them
+__device__ unsigned long long xa_stamp_buf[256][64];
+#define XA_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 256 && (slot) < 64) xa_stamp_buf[blockIdx.x][(slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define XA_STAMP(slot) do { } while (0)
+#endif
+
+struct NrXAttnParams {
+  bf16* t;                 // [nimg * hw][C], updated in place
+  int hw, nimg;            // rows per frame-image, frame-images
+  int img_per_ctx;         // frame-images that share one context (attention.py:100: the frames of a clip); context b = image / img_per_ctx
+  int Lk;                  // valid keys (77)
+  int norot;               // 1: every workgroup walks the heads from head 0 (NR_DETERMINISTIC_BATCH)
+  const bf16* wstream;     // 8 heads x (q | o) stages (xattn_w_pack_kernel)
+  const bf16* kvstream;    // [contexts][8 heads] x XA_KV_BYTES (xattn_kv_pack_kernel)
+  const float* gamma;      // [C] LayerNorm weight
+  const float* beta;       // [C] LayerNorm bias
+  const float* bo;         // [C] to_out bias
+  float ln_eps;
+  float scale_log2e;       // d^-0.5 * log2(e)
+};
+
+// max / sum over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) on the VALU (v_permlane16_swap / v_permlane32_swap, as attention.hip:
+// a ds_bpermute round trip through the LDS otherwise -- four of them per row tile sit on the latency chain of the attention stage)
+__device__ __forceinline__ float rows_max(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows_sum(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// out-tile accumulation with the accumulator PINNED in the AGPR half of the register file ("+a": vDst = SrcC = an AGPR quad).  Left to hipcc the
+// 160 accumulator registers of the out tile live in VGPRs between the heads and every group of 8 MFMAs is bracketed by 64 v_accvgpr_write / _read
+// copies (478 copies for 200 MFMAs in the first build of this kernel; the o stage ran at 37 instead of 16 cycles per MFMA, tools/xattn_timeline.py).
+// An asm MFMA is invisible to the compiler's hazard bookkeeping: its A operand comes from LDS (covered by the s_waitcnt the compiler places for
+// the asm input), its B operand was converted many instructions earlier, and the accumulator is next touched one head later or by the epilogue
+// behind an explicit s_nop (below).  No VALU-written operand ever sits directly in front of these MFMAs (the VALU -> MFMA-operand hazard
+// attention.hip's mfma_bf16_tied pays an s_nop for): the weight fragments come from ds_read, O^T was packed before the stage's barrier.
+#ifndef NR_ACC_AGPR
+#define NR_ACC_AGPR 1      // 0: the compiler-allocated form again (A/B arm: make variant NAME=noagpr VFLAGS=-DNR_ACC_AGPR=0)
+#endif
+__device__ __forceinline__ void mfma_acc_agpr(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+#if NR_ACC_AGPR
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+#else
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+#endif
+}
+
+__device__ __forceinline__ s16x4 pack4(const f32x4& v) {
+  bf16x4 b;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) b[e] = (bf16)v[e];
+  return __builtin_bit_cast(s16x4, b);
+}
+
+__global__ __launch_bounds__(256) void xattn_fused_kernel(NrXAttnParams p) {
+  constexpr int C = XA_C, KS = C / 32, NT2 = C / 16, KT = XA_KEYS / 16;
+  extern __shared__ __attribute__((aligned(16))) bf16 smem[];   // XA_NS slots of 40 KiB
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  XA_STAMP(0);
+
+  // rows of this workgroup: 128 consecutive rows of one frame-image (hw % 128 == 0), hence of one context
+  const int row0 = blockIdx.x * XA_ROWS;
+  const int img = row0 / p.hw;
+  const int cb = img / p.img_per_ctx;
+
+  // ---- streams.  Every workgroup walks the heads from its own starting head (as tattn.hip: the workgroups of an XCD then read different regions
+  // of the streams instead of all hammering the same lines in lockstep; results depend on blockIdx alone) ----
+  const int head0 = p.norot ? 0 : (int)((blockIdx.x >> 3) & (XA_HEADS - 1));
+  const char* wsrc = reinterpret_cast<const char*>(p.wstream) + (size_t)lane * 16;
+  const char* kvsrc = reinterpret_cast<const char*>(p.kvstream) + (size_t)cb * XA_HEADS * XA_KV_BYTES + (size_t)lane * 16;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lptr_t)smem);
+  // stage s of head position hidx: 0 = q (slot 0, 8 pieces per wave), 1 = kv (slot 1, 5 pieces), 2 = o (slot 2, 10 pieces): three stages per head
+  // and three slots, so every stage type owns a slot; a stage is prefetched two stages ahead = into the slot the PREVIOUS stage has just left
+  const char* pf_src = wsrc;
+  unsigned pf_dst = lds0;
+  auto set_prefetch = [&](int hidx, int part) {
+    const int head = (head0 + hidx) & (XA_HEADS - 1);
+    const int n = part == 0 ? 8 : (part == 1 ? 5 : 10);
+    if (part == 1) pf_src = kvsrc + (size_t)head * XA_KV_BYTES + (size_t)(wave * n) * 1024;
+    else pf_src = wsrc + (size_t)head * XA_W_HEAD_BYTES + (size_t)(part == 2 ? XA_Q_BYTES : 0) + (size_t)(wave * n) * 1024;
+    pf_dst = lds0 + (unsigned)(part * XA_SLOT) + (unsigned)(wave * n * 1024);
+  };
+  auto prefetch_piece = [&](int i) { glds16(pf_src + i * 1024, pf_dst + (unsigned)(i * 1024)); };
+  set_prefetch(0, 0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) prefetch_piece(i);
+  set_prefetch(0, 1);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) prefetch_piece(i);
+
+  // ---- the row panel: tile mt = rows row0 + 32 wave + 16 mt + fr ----
+  bf16* trow[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) trow[mt] = p.t + (size_t)(row0 + 32 * wave + 16 * mt + fr) * C;
+  bf16x8 xb[2][KS];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xb[mt][ks] = *(const bf16x8*)(trow[mt] + 32 * ks + 8 * fg);
+  // LayerNorm (two-pass in registers: mean, then centred second moment), rounded to bf16 in place
+  {
+    float mu[2], rstd[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      float s = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)xb[mt][ks][e];
+      s = rows_sum(s);
+      mu[mt] = s * (1.0f / C);
+      float q = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = (float)xb[mt][ks][e] - mu[mt]; q += d * d; }
+      q = rows_sum(q);
+      rstd[mt] = rsqrtf(q * (1.0f / C) + p.ln_eps);
+    }
+    const float* gbr = p.beta + 8 * fg;
+    const float* gar = p.gamma + 8 * fg;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const f32x4 g0 = *(const f32x4*)(gar + 32 * ks), g1 = *(const f32x4*)(gar + 32 * ks + 4);
+      const f32x4 b0 = *(const f32x4*)(gbr + 32 * ks), b1 = *(const f32x4*)(gbr + 32 * ks + 4);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        bf16x8 v = xb[mt][ks];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = (bf16)(((float)v[e] - mu[mt]) * rstd[mt] * g0[e] + b0[e]);
+          v[4 + e] = (bf16)(((float)v[4 + e] - mu[mt]) * rstd[mt] * g1[e] + b1[e]);
+        }
+        xb[mt][ks] = v;
+      }
+    }
+  }
+
+  f32x4 oacc[NT2][2];
+#pragma unroll
+  for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) oacc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // stage start: this wave's pieces of the stage have landed; the FOLLOWING stage's pieces (NEXT of them) may stay in flight
+  const bf16* s_q = smem;
+  const bf16* s_kv = smem + XA_SLOT / 2;
+  const bf16* s_o = smem + 2 * (XA_SLOT / 2);
+
+  // fragment of the q stage: 16 weight rows nt (0..2), k-step ks
+  auto frag_q = [&](int nt, int ks) {
+    const int row = nt * 16 + fr;
+    return *(const bf16x8*)(s_q + (ks >> 1) * XA_QSUB + row * 64 + ((((ks & 1) * 4 + fg) ^ (row & 7)) << 3));
+  };
+  auto frag_o = [&](int nt, int ks2) {
+    const int row = (nt & 3) * 16 + fr;
+    return *(const bf16x8*)(s_o + (nt >> 2) * XA_OSUB + row * 64 + (((ks2 * 4 + fg) ^ (row & 7)) << 3));
+  };
+
+  s16x4 qa[3][2];
+  bf16x8 ob0[2], ob1[2];             // O^T of the current head as the two B fragments of the o stage
+  XA_STAMP(1);
+  for (int it = 0; it < XA_HEADS; ++it) {
+    const bool last = it + 1 == XA_HEADS;
+    XA_STAMP(2 + 6 * it);
+    // ================= q stage (slot 0); behind it in flight: kv (5).  Prefetch during its 10 k-steps: o of this head (10 pieces) =================
+    wait_vmcnt<5>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    XA_STAMP(3 + 6 * it);
+    set_prefetch(it, 2);
+    {
+      f32x4 acc[3][2];
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      bf16x8 w0[3], w1[3], w2[3];
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt) { w0[nt] = frag_q(nt, 0); w1[nt] = frag_q(nt, 1); }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 (&wc)[3] = (ks % 3 == 0) ? w0 : (ks % 3 == 1 ? w1 : w2);
+        bf16x8 (&wn)[3] = (ks % 3 == 0) ? w2 : (ks % 3 == 1 ? w0 : w1);
+        if (ks + 2 < KS) {
+#pragma unroll
+          for (int nt = 0; nt < 3; ++nt) wn[nt] = frag_q(nt, ks + 2);
+        }
+        prefetch_piece(ks);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[nt], xb[mt][ks], acc[nt][mt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) qa[nt][mt] = pack4(acc[nt][mt]);     // lane: channels 16 nt + 4 fg .. + 3 of row fr
+    }
+    XA_STAMP(4 + 6 * it);
+    // ================= kv stage (slot 1); behind it: o (10).  Prefetch: q of the next head (8; last head: a harmless re-fetch of the first) =================
+    wait_vmcnt<10>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    XA_STAMP(5 + 6 * it);
+    set_prefetch(last ? 0 : it + 1, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) prefetch_piece(i);
+    {
+      const bf16* sK = s_kv;
+      const bf16* sV = s_kv + XA_K_BYTES / 2;
+      // ---- S^T[key 16 kt + 4 fg + r][query fr] = sum_c K[key][c] Q[query][c]: A = K tile (lane: key fr, channels 4 fg ..), B = qa ----
+      f32x4 sc[KT][2];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        s16x4 kf[3];
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) kf[nt] = *(const s16x4*)(sK + (16 * kt + fr) * XA_KLD + 16 * nt + 4 * fg);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int nt = 0; nt < 3; ++nt) s4 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kf[nt], qa[nt][mt], s4, 0, 0, 0);
+          sc[kt][mt] = s4;
+        }
+      }
+      // ---- softmax over the key slots of a query: 20 registers in the lane x 4 lane groups; slots >= Lk are masked ----
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        float mx = -1e30f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (16 * kt + 4 * fg + r >= p.Lk) sc[kt][mt][r] = -1e30f;       // key slots beyond the context (their K rows are zero, not -inf)
+            mx = fmaxf(mx, sc[kt][mt][r]);
+          }
+        mx = rows_max(mx);
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { sc[kt][mt][r] = __builtin_amdgcn_exp2f((sc[kt][mt][r] - mx) * p.scale_log2e); l += sc[kt][mt][r]; }
+        l = rows_sum(l);
+        // ---- O^T[channel 16 g + 4 fg + r][query fr] = sum_key V^T[channel][key] P[query][key]: A = V^T tile (lane: channel fr, keys 4 fg ..), B = P ----
+        f32x4 ao[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) ao[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          const s16x4 pb = pack4(sc[kt][mt]);
+#pragma unroll
+          for (int g = 0; g < 3; ++g) {
+            const s16x4 vf = *(const s16x4*)(sV + (16 * g + fr) * XA_VLD + 16 * kt + 4 * fg);
+            ao[g] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf, pb, ao[g], 0, 0, 0);
+          }
+        }
+        const float inv = __builtin_amdgcn_rcpf(l);
+        bf16x8 b0, b1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          b0[r] = (bf16)(ao[0][r] * inv); b0[4 + r] = (bf16)(ao[1][r] * inv);   // k-slots 8 fg + j: channels {4 fg + j}, {16 + 4 fg + j}
+          b1[r] = (bf16)(ao[2][r] * inv); b1[4 + r] = (bf16)0.0f;              // k-slots 32 + 8 fg + j: channels {32 + 4 fg + j} (fg < 2; the rest is padding)
+        }
+        ob0[mt] = b0; ob1[mt] = b1;
+      }
+    }
+    XA_STAMP(6 + 6 * it);
+    // ================= o stage (slot 2); behind it: q of the next head (8).  Prefetch: kv of the next head (5 pieces) =================
+    wait_vmcnt<8>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    XA_STAMP(7 + 6 * it);
+    set_prefetch(last ? 0 : it + 1, 1);
+    {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = frag_o(i, 0);
+#pragma unroll
+      for (int grp = 0; grp < 10; ++grp) {
+        const int ks2 = grp / 5, q = grp - 5 * ks2;
+        bf16x8 (&cur)[4] = (grp & 1) ? fb : fa;
+        bf16x8 (&nxt)[4] = (grp & 1) ? fa : fb;
+        if (grp + 1 < 10) {
+          const int g2 = grp + 1, k2 = g2 / 5, q2 = g2 - 5 * k2;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) nxt[i] = frag_o(4 * q2 + i, k2);
+        }
+        if (grp < 5) prefetch_piece(grp);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int nt = 4 * q + i;
+          mfma_acc_agpr(oacc[nt][0], cur[i], ks2 ? ob1[0] : ob0[0]);
+          mfma_acc_agpr(oacc[nt][1], cur[i], ks2 ? ob1[1] : ob0[1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  XA_STAMP(50);
+  wait_vmcnt<0>();      // the tail's dummy pieces
+
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // the last asm MFMAs' results -> the accumulator reads below (>= 18 wait states, stated not assumed)
+  // ---- epilogue: t <- t + bo + acc (lane: row fr of tile mt, channels 16 nt + 4 fg .. +3), in place ----
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    bf16* tr = trow[mt] + 4 * fg;
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) {
+      const bf16x4 xv = *(const bf16x4*)(tr + 16 * nt);
+      const f32x4 bb = *(const f32x4*)(p.bo + 16 * nt + 4 * fg);
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16)(oacc[nt][mt][e] + bb[e] + (float)xv[e]);
+      nr_store8(tr + 16 * nt, o);
+    }
+  }
+  XA_STAMP(51);
+}
+
+// Builds the weight stream (8 heads x [q stage | o stage]) from the two bf16 [C][C] matrices.  One thread per 16-byte chunk.
+__global__ __launch_bounds__(256) void xattn_w_pack_kernel(const bf16* __restrict__ wq, const bf16* __restrict__ wo, bf16* __restrict__ stream) {
+  constexpr int C = XA_C;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  constexpr int CH_HEAD = XA_W_HEAD_BYTES / 16;
+  if (idx >= XA_HEADS * CH_HEAD) return;
+  const int head = idx / CH_HEAD;
+  int c = idx - head * CH_HEAD;
+  bf16x8 v = bf16x8_zero();
+  if (c < XA_Q_BYTES / 16) {
+    if (c < 5 * 48 * 8) {                                      // [5 sub-tiles][48 rows][8 chunks]; the tail of the stage is padding
+      const int sub = c / (48 * 8), row = (c / 8) % 48, phys = c & 7;
+      const int lchunk = phys ^ (row & 7);
+      if (row < XA_D) v = *(const bf16x8*)(wq + (size_t)(head * XA_D + row) * C + 64 * sub + 8 * lchunk);
+    }
+  } else {
+    c -= XA_Q_BYTES / 16;
+    const int sub = c >> 9, row = (c >> 3) & 63, phys = c & 7;   // [5][64 n rows][8 chunks of 8 k-slots]
+    const int lchunk = phys ^ (row & 7);
+    const int n = 64 * sub + row;
+    const int ks2 = lchunk >> 2, fgq = lchunk & 3;
+    const bf16* src = wo + (size_t)n * C + head * XA_D;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int ch = -1;
+      if (ks2 == 0) ch = j < 4 ? 4 * fgq + j : 16 + 4 * fgq + (j - 4);
+      else if (j < 4 && fgq < 2) ch = 32 + 4 * fgq + j;
+      v[j] = ch >= 0 ? src[ch] : (bf16)0.0f;
+    }
+  }
+  *(bf16x8*)(stream + (size_t)idx * 8) = v;
+}
+
+// The context's K | V projection [nctx * Lk][2 C] (K columns [0, C), V columns [C, 2 C)) -> per (context, head) the LDS image of the kv stage:
+// K_h [80][56] at byte 0 (rows >= Lk and columns >= 40 zero), V_h^T [48][88] at byte 9216 (channels >= 40 and keys >= Lk zero).  One thread per element.
+__global__ __launch_bounds__(256) void xattn_kv_pack_kernel(const bf16* __restrict__ kv, int ldkv, int Lk, int nctx, bf16* __restrict__ stream) {
+  constexpr int EL = XA_KV_BYTES / 2;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)nctx * XA_HEADS * EL) return;
+  const int e = (int)(idx % EL);
+  const int ch_ = (int)(idx / EL);
+  const int head = ch_ % XA_HEADS, cb = ch_ / XA_HEADS;
+  bf16 v = (bf16)0.0f;
+  if (e < XA_K_BYTES / 2) {
+    const int key = e / XA_KLD, c = e - key * XA_KLD;
+    if (key < Lk && key < XA_KEYS && c < XA_D) v = kv[((size_t)cb * Lk + key) * ldkv + head * XA_D + c];
+  } else {
+    const int e2 = e - XA_K_BYTES / 2;
+    const int c = e2 / XA_VLD, key = e2 - c * XA_VLD;
+    if (c < XA_D && key < Lk && key < XA_KEYS) v = kv[((size_t)cb * Lk + key) * ldkv + XA_C + head * XA_D + c];
+  }
+  stream[idx] = v;
+}
+
+unsigned long long g_xa_attr = 0;
+
+}  // namespace
+
+#ifdef NR_STAMP
+extern "C" int nr_xattn_stamp_read(void* dst, size_t bytes, int clear) {
+  const size_t n = bytes < sizeof(xa_stamp_buf) ? bytes : sizeof(xa_stamp_buf);
+  int rc = 0;
+  if (dst) rc = (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(xa_stamp_buf), n, 0, hipMemcpyDeviceToHost);
+  if (clear) { void* d = nullptr; (void)hipGetSymbolAddress(&d, HIP_SYMBOL(xa_stamp_buf)); (void)hipMemset(d, 0, sizeof(xa_stamp_buf)); }
+  return rc;
+}
+#endif
+
+extern "C" size_t nr_xattn_wstream_bytes(void) { return (size_t)XA_HEADS * XA_W_HEAD_BYTES; }
+extern "C" size_t nr_xattn_kvstream_bytes(int nctx) { return (size_t)nctx * XA_HEADS * XA_KV_BYTES; }
+
+extern "C" int nr_xattn_fused_eligible(int C, int heads, int Lk, int hw, long long rows) {
+  static const bool off = getenv("NR_XATTN_FUSED") && getenv("NR_XATTN_FUSED")[0] == '0';   // A/B switch
+  return !off && C == XA_C && heads == XA_HEADS && Lk > 0 && Lk <= XA_KEYS && hw % XA_ROWS == 0 && rows >= 4096;
+}
+
+extern "C" int nr_launch_xattn_w_pack(const bf16* wq, const bf16* wo, bf16* stream, hipStream_t s) {
+  const int total = XA_HEADS * (XA_W_HEAD_BYTES / 16);
+  hipLaunchKernelGGL(xattn_w_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, wq, wo, stream);
+  return 0;
+}
+
+extern "C" int nr_launch_xattn_kv_pack(const bf16* kv, int ldkv, int Lk, int nctx, bf16* stream, hipStream_t s) {
+  if (Lk <= 0 || Lk > XA_KEYS || nctx <= 0) return 1;
+  const long long total = (long long)nctx * XA_HEADS * (XA_KV_BYTES / 2);
+  hipLaunchKernelGGL(xattn_kv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, kv, ldkv, Lk, nctx, stream);
+  return 0;
+}
+
+extern "C" int nr_launch_xattn_fused(bf16* t, int nimg, int hw, int img_per_ctx, int Lk, const bf16* wstream, const bf16* kvstream, const float* gamma,
+                                     const float* beta, const float* bo, float ln_eps, int norot, hipStream_t s) {
+  if (nimg <= 0 || hw <= 0 || hw % XA_ROWS != 0 || img_per_ctx <= 0 || Lk <= 0 || Lk > XA_KEYS) return 1;
+  NrXAttnParams p;
+  p.t = t; p.hw = hw; p.nimg = nimg; p.img_per_ctx = img_per_ctx; p.Lk = Lk; p.norot = norot; p.wstream = wstream; p.kvstream = kvstream;
+  p.gamma = gamma; p.beta = beta; p.bo = bo; p.ln_eps = ln_eps;
+  p.scale_log2e = 1.4426950408889634f / sqrtf((float)XA_D);
+  constexpr size_t shm = (size_t)XA_NS * XA_SLOT;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!(g_xa_attr >> (dev & 63) & 1ull)) {
+    if (hipFuncSetAttribute((const void*)xattn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return 2;
+    g_xa_attr |= 1ull << (dev & 63);
+  }
+  const unsigned grid = (unsigned)((long long)nimg * hw / XA_ROWS);
+  hipLaunchKernelGGL(xattn_fused_kernel, dim3(grid), dim3(256), shm, s, p);
+  return 0;
+}

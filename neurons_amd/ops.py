@@ -269,6 +269,21 @@ def tattn_fused(t, nbatch, hw, gamma, beta, wq, wk, wv, wo, bo, eps=1e-5, reuse_
     return t
 
 
+def xattn_fused(t, nimg, hw, img_per_ctx, gamma, beta, wq, wo, bo, kv, Lk, eps=1e-5, reuse_streams=False):
+    """t <- t + to_out(cross-attention(LayerNorm(t), context K | V)) at C = 320, 8 heads, in ONE launch (xattn.hip).  t: [nimg * hw, 320] bf16 in
+    "(b f) (h w) c" row order, updated IN PLACE and returned; image i attends to context i // img_per_ctx; kv: [nctx * Lk, 640] bf16 (K | V columns:
+    the fused to_k | to_v projection of the context); wq, wo: [320, 320]."""
+    _chk_bf16(t, kv)
+    C = 320
+    assert t.shape == (nimg * hw, C) and kv.shape[1] == 2 * C and kv.shape[0] % Lk == 0
+    nctx = kv.shape[0] // Lk
+    ws = [w.to(torch.bfloat16).contiguous() for w in (wq, wo)]
+    _lib.check(_lib.load().nr_op_xattn_fused(_stream(), _ptr(t), nimg, hw, img_per_ctx, None if reuse_streams else _ptr(ws[0]), _ptr(ws[1]), _ptr(kv),
+                                             kv.shape[1], Lk, nctx, _ptr(gamma.float().contiguous()), _ptr(beta.float().contiguous()),
+                                             _ptr(bo.float().contiguous()), float(eps)))
+    return t
+
+
 # ---------------------------------------------------------------------------------------------------
 # Leaf-module handles (test hooks): ONE reference module planned as a network of its own, so the reference classes' own
 # outputs (tests/golden/leaf_ops.npz) can be replayed at the row counts where the engine picks its fused kernels.

@@ -414,3 +414,37 @@ def test_fused_temporal_attention_block_matches_torch(cuda, nbatch, hw, F):
     _cmp(f"fused temporal attention block nbatch={nbatch} hw={hw} F={F}", out.view(nbatch, F, hw, C), ref)
     t2 = t.clone()
     assert torch.equal(out, ops.tattn_fused(t2, nbatch, hw, gamma, beta, wq, wk, wv, wo, bo, frames=F))
+
+
+@pytest.mark.parametrize("nimg,hw,ipc,Lk", [(4, 1024, 2, 77), (6, 256, 3, 77), (2, 128, 1, 80), (3, 384, 3, 33)])
+def test_fused_cross_attention_block_matches_torch(cuda, nimg, hw, ipc, Lk):
+    """xattn.hip (round 5): norm2 -> to_q -> softmax(q K^T / sqrt(40)) V on the cached context K | V of the row's clip -> to_out (+bias) -> + residual,
+    C = 320, 8 heads, ONE launch, in place; against the fp32 torch composition of the reference (attention.py:281-290, context repeated per frame
+    :100; motion_module_new.py:201-287).  Covers: several contexts (image i uses context i // ipc), hw = 128 (one workgroup per image), a full
+    80-key tile (no masked slot) and a short context (masked slots in three key tiles).  Tolerance as the other MFMA ops."""
+    from neurons_amd import ops
+    C, H = 320, 8
+    nctx = (nimg + ipc - 1) // ipc
+    g = torch.Generator(device="cuda").manual_seed(nimg * 1000 + hw + Lk)
+    t = (torch.randn(nimg * hw, C, generator=g, device="cuda") * 1.1 + 0.1).to(torch.bfloat16)
+    gamma = 1.0 + 0.2 * torch.randn(C, generator=g, device="cuda")
+    beta = 0.1 * torch.randn(C, generator=g, device="cuda")
+    wq, wo = (torch.randn(C, C, generator=g, device="cuda") * C ** -0.5 for _ in range(2))
+    wq = wq * 2.0                                  # sharper softmax: exercises the max subtraction
+    bo = 0.1 * torch.randn(C, generator=g, device="cuda")
+    kv = (torch.randn(nctx * Lk, 2 * C, generator=g, device="cuda") * 1.2).to(torch.bfloat16)
+    bw = lambda w: w.to(torch.bfloat16).float()
+    x = t.float().view(nimg, hw, C)
+    n = torch.nn.functional.layer_norm(x, (C,), gamma, beta, 1e-5)
+    q = torch.nn.functional.linear(n, bw(wq)).view(nimg, hw, H, C // H).transpose(1, 2)                      # [img, head, hw, d]
+    ctx_of = torch.arange(nimg, device="cuda") // ipc
+    kf = kv.float().view(nctx, Lk, 2 * C)
+    k = kf[ctx_of, :, :C].reshape(nimg, Lk, H, C // H).transpose(1, 2)
+    v = kf[ctx_of, :, C:].reshape(nimg, Lk, H, C // H).transpose(1, 2)
+    a = torch.softmax(q @ k.transpose(-1, -2) * (C // H) ** -0.5, dim=-1) @ v
+    ref = x + torch.nn.functional.linear(a.transpose(1, 2).reshape(nimg, hw, C), bw(wo), bo)
+    t1 = t.clone()
+    out = ops.xattn_fused(t1, nimg, hw, ipc, gamma, beta, wq, wo, bo, kv, Lk)
+    _cmp(f"fused cross-attention block nimg={nimg} hw={hw} ipc={ipc} Lk={Lk}", out.view(nimg, hw, C), ref)
+    t2 = t.clone()
+    assert torch.equal(out, ops.xattn_fused(t2, nimg, hw, ipc, gamma, beta, wq, wo, bo, kv, Lk))
