@@ -74,7 +74,7 @@ size_t nr_xattn_kvstream_bytes(int nctx);
 int nr_xattn_fused_eligible(int C, int heads, int Lk, int hw, long long rows);
 int nr_launch_xattn_w_pack(const bf16* wq, const bf16* wo, bf16* stream, hipStream_t s);
 int nr_launch_xattn_kv_pack(const bf16* kv, int ldkv, int Lk, int nctx, bf16* stream, hipStream_t s);
-int nr_launch_xattn_fused(bf16* t, int nimg, int hw, int img_per_ctx, int Lk, const bf16* wstream, const bf16* kvstream, const float* gamma,
+int nr_launch_xattn_fused(bf16* t, int nimg, int hw, int img_per_ctx, int nctx, int Lk, const bf16* wstream, const bf16* kvstream, const float* gamma,
                           const float* beta, const float* bo, float ln_eps, int norot, hipStream_t s);
 size_t nr_tattn_stream_bytes(void);
 int nr_tattn_fused_eligible(int C, int heads, int frames, int hw, long long rows);
@@ -1016,7 +1016,7 @@ struct nr_net {
         Act kv = new_act_persistent(ctx_bf.nimg, ctx_bf.H, ctx_bf.W, 2 * C);
         ok.out = &kv;
         linear(ctx_bf, w_linear_cat({b + ".attn2.to_k.weight", b + ".attn2.to_v.weight"}, C, cfg.cross_attention_dim), 2 * C, ok);
-        const int nctx = ctx_bf.nimg;
+        const int nctx = (int)(ctx_bf.rows() / ctx_len);      // ctx_bf is ONE "image" of B2 * ctx_len token rows
         Act kvs = new_act_persistent(nctx, 1, 1, (int)(nr_xattn_kvstream_bytes(1) / sizeof(bf16)));
         {
           const bf16* kvp = kv.ptr; bf16* kvsp = kvs.ptr; const int ldkv = kv.ld, Lk = ctx_len;
@@ -1051,7 +1051,7 @@ struct nr_net {
         char d[160];
         snprintf(d, sizeof(d), "xattn_fused M=%d C=%d Lk=%d (LN, q, context attention, to_out + residual)", (int)t.rows(), C, Lk);
         const int norot = det_batch ? 1 : 0;
-        emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_xattn_fused(tp, nimg, hwx, ipc, Lk, wstream, kvsp, gamma, beta, bo, 1e-5f, norot, s)); }, NR_PROF_IGEMM,
+        emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_xattn_fused(tp, nimg, hwx, ipc, nctx, Lk, wstream, kvsp, gamma, beta, bo, 1e-5f, norot, s)); }, NR_PROF_IGEMM,
              2.0 * M * C * 2.0 * C + 4.0 * M * (double)Lk * C, 2.0 * (2.0 * M * C + 2.0 * C * (double)C), d);
         op_tap("xattn_fused", t);
       } else {  // cross-attention on the context (attention.py:100: context repeated per frame)
@@ -2000,6 +2000,15 @@ struct nr_net {
     if (!use_graph) {
       set_timesteps(caller, timesteps);
       run_context(caller);
+      static const bool trace = getenv("NR_TRACE_OPS") != nullptr;      // fault localisation: one line and one stream sync per launch (eager handles only)
+      if (trace) {
+        for (size_t i = 0; i < ops.size(); ++i) {
+          fprintf(stderr, "[nr op %zu] %s\n", i, op_meta[i].desc.c_str());
+          ops[i](caller);
+          HIP_OK(hipStreamSynchronize(caller));
+        }
+        return;
+      }
       for (auto& op : ops) op(caller);
       return;
     }
@@ -2957,7 +2966,7 @@ extern "C" nr_status nr_op_xattn_fused(nr_stream stream, void* t_dev, int32_t ni
     LAUNCH_OK(nr_launch_xattn_w_pack((const bf16*)wq_dev, (const bf16*)wo_dev, (bf16*)ws, (hipStream_t)stream));
     LAUNCH_OK(nr_launch_xattn_kv_pack((const bf16*)kv_dev, ldkv, Lk, nctx, (bf16*)kvs, (hipStream_t)stream));
   }
-  LAUNCH_OK(nr_launch_xattn_fused((bf16*)t_dev, nimg, hw, img_per_ctx, Lk, (const bf16*)ws, (const bf16*)kvs, gamma_dev, beta_dev, bo_dev, ln_eps,
+  LAUNCH_OK(nr_launch_xattn_fused((bf16*)t_dev, nimg, hw, img_per_ctx, nctx, Lk, (const bf16*)ws, (const bf16*)kvs, gamma_dev, beta_dev, bo_dev, ln_eps,
                                   getenv("NR_DETERMINISTIC_BATCH") && getenv("NR_DETERMINISTIC_BATCH")[0] == '1', (hipStream_t)stream));
   NR_CATCH
 }

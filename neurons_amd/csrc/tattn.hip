@@ -81,6 +81,26 @@ __device__ __forceinline__ void mfma_acc_agpr(f32x4& acc, const bf16x8& a, const
 #endif
 }
 
+// own and partner value across 16-lane rows on the VALU (round 5): v_permlane16_swap / v_permlane32_swap with both operands = v give every lane
+// {own, partner} in the two results (lane ^ 16 / lane ^ 32), where __shfl_xor is a ds_bpermute round trip through the LDS -- eight of them per head
+// sat on the latency chain of the attention phases.  max / + are commutative: bit-identical to the shuffle form.
+__device__ __forceinline__ float xmax16(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+}
+__device__ __forceinline__ float xmax32(float v) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+}
+__device__ __forceinline__ float xsum16(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+__device__ __forceinline__ float xsum32(float v) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+
 __device__ __forceinline__ s16x4 pack4(const f32x4& v) {
   bf16x4 b;
 #pragma unroll
@@ -152,16 +172,14 @@ __global__ __launch_bounds__(256) void tattn_fused_kernel(NrTAttnParams p) {
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int e = 0; e < 8; ++e) s += (float)xb[mt][ks][e];
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
+      s = xsum32(xsum16(s));
       mu[mt] = s * (1.0f / C);
       float q = 0.f;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float d = (float)xb[mt][ks][e] - mu[mt]; q += d * d; }
-      q += __shfl_xor(q, 16, 64);
-      q += __shfl_xor(q, 32, 64);
+      q = xsum32(xsum16(q));
       rstd[mt] = rsqrtf(q * (1.0f / C) + p.ln_eps);
     }
     const float* gbr = p.gb + (size_t)fr * C + 8 * fg;
@@ -268,18 +286,18 @@ __global__ __launch_bounds__(256) void tattn_fused_kernel(NrTAttnParams p) {
       } else if (ph == 1) {
         float mx = fmaxf(fmaxf(at_s[0][mt][0], at_s[0][mt][1]), fmaxf(at_s[0][mt][2], at_s[0][mt][3]));
         if constexpr (KT == 2) mx = fmaxf(mx, fmaxf(fmaxf(at_s[1][mt][0], at_s[1][mt][1]), fmaxf(at_s[1][mt][2], at_s[1][mt][3])));
-        at_m[mt] = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        at_m[mt] = xmax16(mx);
       } else if (ph == 2) {
-        at_m[mt] = fmaxf(at_m[mt], __shfl_xor(at_m[mt], 32, 64));
+        at_m[mt] = xmax32(at_m[mt]);
       } else if (ph == 3) {
         float l = 0.f;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) { at_s[kt][mt][r] = __builtin_amdgcn_exp2f((at_s[kt][mt][r] - at_m[mt]) * p.scale_log2e); l += at_s[kt][mt][r]; }
-        at_l[mt] = l + __shfl_xor(l, 16, 64);
+        at_l[mt] = xsum16(l);
       } else if (ph == 4) {
-        at_l[mt] = at_l[mt] + __shfl_xor(at_l[mt], 32, 64);
+        at_l[mt] = xsum32(at_l[mt]);
       } else if (ph == 5) {        // O^T[channel 16 g + 4 fg + r][query fr] = V^T P^T
         if constexpr (KT == 1) {
           const s16x4 pb = pack4(at_s[0][mt]);
@@ -381,18 +399,31 @@ __global__ __launch_bounds__(256) void tattn_fused_kernel(NrTAttnParams p) {
   wait_vmcnt<0>();      // the tail's dummy pieces
 
   asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // the last asm MFMAs' results -> the accumulator reads below (>= 18 wait states, stated not assumed)
-  // ---- epilogue: t <- t + bo + acc (lane: frame fr of pixel mt, channels 16 nt + 4 fg .. +3), in place ----
+  // ---- epilogue: t <- t + bo + acc, in place.  In the accumulator layout a lane holds 4 channels (16 nt + 4 fg .. + 3) of row fr: 8-byte accesses in
+  // 32-byte row segments, and the whole chip runs this phase at once (t in + t out = 42 MB: 23 k of the kernel's 100 k cycles, xattn.hip's timeline, same structure).
+  // v_permlane16_swap between the column tiles (2 k, 2 k + 1) hands every lane 8 CONSECUTIVE channels (even rows: tile 2 k, channels 4 fg .. 4 fg + 7;
+  // odd rows: tile 2 k + 1, channels 4 (fg - 1) ..): 16-byte residual loads and stores in 64-byte row segments, half the vector-memory instructions ----
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
-    bf16* tr = trow[mt] + 4 * fg;
 #pragma unroll
-    for (int nt = 0; nt < NT2; ++nt) {
-      const bf16x4 xv = *(const bf16x4*)(tr + 16 * nt);
-      const f32x4 bb = *(const f32x4*)(p.bo + 16 * nt + 4 * fg);
-      bf16x4 o;
+    for (int k = 0; k < NT2 / 2; ++k) {
+      f32x4 lo = oacc[2 * k][mt], hi = oacc[2 * k + 1][mt];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (bf16)(oacc[nt][mt][e] + bb[e] + (float)xv[e]);
-      nr_store8(tr + 16 * nt, o);
+      for (int e = 0; e < 4; ++e) {
+        auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo[e]), __float_as_uint(hi[e]), false, false);
+        lo[e] = __uint_as_float(sw[0]); hi[e] = __uint_as_float(sw[1]);
+      }
+      const int col0 = 16 * (2 * k + (fg & 1)) + 4 * (fg & 2);      // even rows: own tile's channels 4 fg ..; odd rows: the next tile's 4 (fg - 1) ..
+      bf16* tp = trow[mt] + col0;
+      const bf16x8 xv = *(const bf16x8*)tp;
+      const f32x4 b0 = *(const f32x4*)(p.bo + col0), b1 = *(const f32x4*)(p.bo + col0 + 4);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (bf16)(lo[e] + b0[e] + (float)xv[e]);
+        o[4 + e] = (bf16)(hi[e] + b1[e] + (float)xv[4 + e]);
+      }
+      nr_store16(tp, o);
     }
   }
 }

@@ -373,18 +373,31 @@ __global__ __launch_bounds__(256) void xattn_fused_kernel(NrXAttnParams p) {
   wait_vmcnt<0>();      // the tail's dummy pieces
 
   asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // the last asm MFMAs' results -> the accumulator reads below (>= 18 wait states, stated not assumed)
-  // ---- epilogue: t <- t + bo + acc (lane: row fr of tile mt, channels 16 nt + 4 fg .. +3), in place ----
+  // ---- epilogue: t <- t + bo + acc, in place.  In the accumulator layout a lane holds 4 channels (16 nt + 4 fg .. + 3) of row fr: 8-byte accesses in
+  // 32-byte row segments, and the whole chip runs this phase at once (t in + t out = 42 MB: 23 k of the kernel's 100 k cycles, tools/xattn_timeline.py).
+  // v_permlane16_swap between the column tiles (2 k, 2 k + 1) hands every lane 8 CONSECUTIVE channels (even rows: tile 2 k, channels 4 fg .. 4 fg + 7;
+  // odd rows: tile 2 k + 1, channels 4 (fg - 1) ..): 16-byte residual loads and stores in 64-byte row segments, half the vector-memory instructions ----
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
-    bf16* tr = trow[mt] + 4 * fg;
 #pragma unroll
-    for (int nt = 0; nt < NT2; ++nt) {
-      const bf16x4 xv = *(const bf16x4*)(tr + 16 * nt);
-      const f32x4 bb = *(const f32x4*)(p.bo + 16 * nt + 4 * fg);
-      bf16x4 o;
+    for (int k = 0; k < NT2 / 2; ++k) {
+      f32x4 lo = oacc[2 * k][mt], hi = oacc[2 * k + 1][mt];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (bf16)(oacc[nt][mt][e] + bb[e] + (float)xv[e]);
-      nr_store8(tr + 16 * nt, o);
+      for (int e = 0; e < 4; ++e) {
+        auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo[e]), __float_as_uint(hi[e]), false, false);
+        lo[e] = __uint_as_float(sw[0]); hi[e] = __uint_as_float(sw[1]);
+      }
+      const int col0 = 16 * (2 * k + (fg & 1)) + 4 * (fg & 2);      // even rows: own tile's channels 4 fg ..; odd rows: the next tile's 4 (fg - 1) ..
+      bf16* tp = trow[mt] + col0;
+      const bf16x8 xv = *(const bf16x8*)tp;
+      const f32x4 b0 = *(const f32x4*)(p.bo + col0), b1 = *(const f32x4*)(p.bo + col0 + 4);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (bf16)(lo[e] + b0[e] + (float)xv[e]);
+        o[4 + e] = (bf16)(hi[e] + b1[e] + (float)xv[4 + e]);
+      }
+      nr_store16(tp, o);
     }
   }
   XA_STAMP(51);
@@ -479,9 +492,10 @@ extern "C" int nr_launch_xattn_kv_pack(const bf16* kv, int ldkv, int Lk, int nct
   return 0;
 }
 
-extern "C" int nr_launch_xattn_fused(bf16* t, int nimg, int hw, int img_per_ctx, int Lk, const bf16* wstream, const bf16* kvstream, const float* gamma,
-                                     const float* beta, const float* bo, float ln_eps, int norot, hipStream_t s) {
+extern "C" int nr_launch_xattn_fused(bf16* t, int nimg, int hw, int img_per_ctx, int nctx, int Lk, const bf16* wstream, const bf16* kvstream,
+                                     const float* gamma, const float* beta, const float* bo, float ln_eps, int norot, hipStream_t s) {
   if (nimg <= 0 || hw <= 0 || hw % XA_ROWS != 0 || img_per_ctx <= 0 || Lk <= 0 || Lk > XA_KEYS) return 1;
+  if ((nimg + img_per_ctx - 1) / img_per_ctx > nctx) return 3;      // the kv stream holds nctx contexts: every image's context must be one of them
   NrXAttnParams p;
   p.t = t; p.hw = hw; p.nimg = nimg; p.img_per_ctx = img_per_ctx; p.Lk = Lk; p.norot = norot; p.wstream = wstream; p.kvstream = kvstream;
   p.gamma = gamma; p.beta = beta; p.bo = bo; p.ln_eps = ln_eps;
