@@ -366,7 +366,43 @@ __global__ __launch_bounds__(MT == 2 ? 256 : 512, MT == 2 ? 1 : 2) void ff_fused
   }
 
   wait_vmcnt<0>();      // the tail's dummy pieces
-  // ---- epilogue: out = x + bc + acc, lane holds rows (16 mt + fr), columns 16 nt + 4 fg .. +3 ----
+#ifndef NR_FF_EPI16
+#define NR_FF_EPI16 1
+#endif
+#if NR_FF_EPI16
+  // ---- epilogue: out = x + bc + acc.  In the accumulator layout a lane holds rows (16 mt + fr), columns 16 nt + 4 fg .. +3: 8-byte accesses in 32-byte
+  // row segments.  Round 5 (as xattn.hip / tattn.hip): v_permlane16_swap between the column tiles (2 k, 2 k + 1) hands every lane 8 CONSECUTIVE columns
+  // (even lane rows: tile 2 k, columns 4 fg .. 4 fg + 7; odd: tile 2 k + 1, columns 4 (fg - 1) ..), so residual loads and stores are 16 bytes per lane in
+  // 64-byte row segments and half as many.  The swap partners (fg ^ 1) hold the same row, so the row guard stays lane-consistent; same arithmetic ----
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = mrow0 + 16 * mt + fr;
+    const bool ok = m < p.M;
+#pragma unroll
+    for (int k = 0; k < NT2 / 2; ++k) {
+      f32x4 lo = oacc[2 * k][mt], hi = oacc[2 * k + 1][mt];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo[e]), __float_as_uint(hi[e]), false, false);
+        lo[e] = __uint_as_float(sw[0]); hi[e] = __uint_as_float(sw[1]);
+      }
+      const int col0 = 16 * (2 * k + (fg & 1)) + 4 * (fg & 2);
+      if (ok) {
+        const bf16x8 xv = *(const bf16x8*)(p.x + (size_t)m * p.ldx + col0);
+        const f32x4 b0 = *(const f32x4*)(p.bc + col0), b1 = *(const f32x4*)(p.bc + col0 + 4);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (bf16)(lo[e] + b0[e] + (float)xv[e]);
+          o[4 + e] = (bf16)(hi[e] + b1[e] + (float)xv[4 + e]);
+        }
+        nr_store16(p.out + (size_t)m * p.ldo + col0, o);
+      }
+    }
+  }
+}
+#else
+  // ---- epilogue: out = x + bc + acc, lane holds rows (16 mt + fr), columns 16 nt + 4 fg .. +3 (A/B arm: -DNR_FF_EPI16=0) ----
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = mrow0 + 16 * mt + fr;
@@ -384,6 +420,7 @@ __global__ __launch_bounds__(MT == 2 ? 256 : 512, MT == 2 ? 1 : 2) void ff_fused
     }
   }
 }
+#endif
 
 // Builds the 65-stage weight stream from W1 ([8C][C] bf16, value/gate-interleaved rows: engine w_geglu) and
 // Wc ([C][5C] bf16 = [Wpo | Wpo Wff2], engine w_fold_ff_proj).  One thread per 16-byte chunk of the stream.
