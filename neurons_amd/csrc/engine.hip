@@ -68,6 +68,9 @@ int nr_launch_nhwc_to_ncfhw(const bf16* src, float* dst, int B, int C, int F, in
 int nr_groupnorm_launches(const NrGnParams* p);
 int nr_launch_fold_linear_pair(const float* w2, const float* w1, const float* b2, const float* b1, int C, int J, bf16* wc, float* bc,
                                hipStream_t stream);
+// smallm.hip: panel-resident kernel of the M <= 512 Linears (fragment-major weights)
+int nr_smallm_eligible(const NrGemmParams* pp);
+int nr_launch_smallm_w_pack(const void* w, void* out, int N, int K, hipStream_t stream);
 // tattn.hip: one kernel per temporal-attention block of the C = 320 level
 size_t nr_xattn_wstream_bytes(void);
 size_t nr_xattn_kvstream_bytes(int nctx);
@@ -371,6 +374,23 @@ struct nr_net {
     auto it = dev.find(name);
     if (it != dev.end()) return it->second;
     return make();
+  }
+  // fragment-major copy (smallm.hip) of a converted [N][K] weight matrix, cached as "fm:<its name>"; the row-major matrix stays (launches of
+  // other row counts use it)
+  const bf16* w_fragmajor(const bf16* w, int N, int K) {
+    std::string src;
+    for (const auto& kv : dev) if (kv.second == (const void*)w) { src = kv.first; break; }
+    if (src.empty()) throw NrError(NR_ERR_STATE, "w_fragmajor: not a converted weight matrix");
+    const std::string name = "fm:" + src;
+    return (const bf16*)cached(name, [&]() {
+      void* d = nullptr;
+      const size_t nb = (size_t)N * K * sizeof(bf16);
+      HIP_OK(hipMalloc(&d, nb));
+      LAUNCH_OK(nr_launch_smallm_w_pack(w, d, N, K, nullptr));
+      HIP_OK(hipDeviceSynchronize());
+      dev[name] = d; dev_bytes[name] = nb; weight_bytes += nb;
+      return d;
+    });
   }
   void check_shape(const std::string& key, const HostTensor& t, std::initializer_list<int64_t> want) const {
     std::vector<int64_t> w(want);
@@ -704,6 +724,8 @@ struct nr_net {
     p.out_scale = o.scale; p.geglu = o.geglu; p.pad_tl0 = o.pad_tl0; p.act = o.act; p.ln_c = o.ln_c; p.ln_eps = 1e-5f;
     p.tap_inner = o.tap_inner;
     p.plan_m = det_batch ? (int)det_rows(p.M) : 0;
+    if (ksize == 1 && !x1 && nr_smallm_eligible(&p))        // M <= 512 Linears: the panel-resident kernel reads fragment-major weights
+      p.w_fm = dry ? reinterpret_cast<const bf16*>(uintptr_t(16)) : w_fragmajor(w, Cout, p.K);
     const int outC = o.geglu ? Cout / 2 : Cout;
     Act out = o.out ? *o.out : new_act(x0.nimg, OH, OW, outC);
     if (out.C != outC || out.rows() != p.M) throw NrError(NR_ERR_STATE, "conv: output shape mismatch");
@@ -2767,6 +2789,42 @@ static float* op_workspace(const NrGemmParams& p) {
   return need ? ws : nullptr;
 }
 
+// Test / tool hooks and the panel-resident small-M kernel (smallm.hip): an eligible launch gets a fragment-major copy of its weights, packed on
+// the launch stream into a scratch buffer on EVERY call (tests: always consistent with the tensor passed in); NR_OP_FM_CACHE=1 keeps one
+// copy per weight pointer instead (timing tools that replay graphs over a pool of weights; nr_op_fm_cache_clear when the pool is freed)
+static std::map<const void*, bf16*> g_op_fm_cache;
+extern "C" void nr_op_fm_cache_clear() {
+  (void)hipDeviceSynchronize();
+  for (auto& kv : g_op_fm_cache) (void)hipFree(kv.second);
+  g_op_fm_cache.clear();
+}
+static void op_fragmajor(NrGemmParams& p, hipStream_t s) {
+  if (!nr_smallm_eligible(&p)) return;
+  const size_t need = (size_t)p.N * p.K * sizeof(bf16);
+  const char* e = getenv("NR_OP_FM_CACHE");
+  if (e && e[0] == '1') {
+    auto it = g_op_fm_cache.find(p.w);
+    if (it == g_op_fm_cache.end()) {
+      bf16* d = nullptr;
+      HIP_OK(hipMalloc((void**)&d, need));
+      LAUNCH_OK(nr_launch_smallm_w_pack(p.w, d, p.N, p.K, s));
+      it = g_op_fm_cache.emplace(p.w, d).first;
+    }
+    p.w_fm = it->second;
+    return;
+  }
+  static bf16* scratch = nullptr;
+  static size_t cap = 0;
+  if (need > cap) {
+    HIP_OK(hipDeviceSynchronize());
+    if (scratch) (void)hipFree(scratch);
+    HIP_OK(hipMalloc((void**)&scratch, need));
+    cap = need;
+  }
+  LAUNCH_OK(nr_launch_smallm_w_pack(p.w, scratch, p.N, p.K, s));
+  p.w_fm = scratch;
+}
+
 extern "C" nr_status nr_op_gemm(nr_stream stream, const void* a, int32_t lda, const void* w, const float* bias,
                                 const void* res, int32_t ldr, void* out, int32_t ldo, int32_t M, int32_t N, int32_t K,
                                 int32_t geglu) {
@@ -2776,6 +2834,7 @@ extern "C" nr_status nr_op_gemm(nr_stream stream, const void* a, int32_t lda, co
   p.a0 = (const bf16*)a; p.c0 = K; p.lda0 = lda; p.H = p.W = p.OH = p.OW = 1; p.ksize = 1; p.stride = 1;
   p.w = (const bf16*)w; p.M = M; p.N = N; p.K = K; p.bias = bias; p.res = (const bf16*)res; p.ldr = ldr;
   p.out = (bf16*)out; p.ldo = ldo; p.out_scale = 1.f; p.geglu = geglu; p.rowvec_div = 1;
+  op_fragmajor(p, (hipStream_t)stream);
   LAUNCH_OK(nr_launch_igemm(&p, op_workspace(p), (hipStream_t)stream));
   NR_CATCH
 }
@@ -2804,6 +2863,7 @@ extern "C" nr_status nr_op_ln_gemm(nr_stream stream, const void* a, int32_t lda,
   p.a0 = (const bf16*)a; p.c0 = K; p.lda0 = lda; p.H = p.W = p.OH = p.OW = 1; p.ksize = 1; p.stride = 1;
   p.w = (const bf16*)w_scaled; p.M = M; p.N = N; p.K = K; p.bias = bias_folded; p.res = (const bf16*)res; p.ldr = ldr;
   p.out = (bf16*)out; p.ldo = ldo; p.out_scale = 1.f; p.geglu = geglu; p.rowvec_div = 1; p.ln_c = ln_c; p.ln_eps = eps; p.act = act;
+  op_fragmajor(p, (hipStream_t)stream);
   LAUNCH_OK(nr_launch_igemm(&p, nullptr, (hipStream_t)stream));
   NR_CATCH
 }
@@ -2820,6 +2880,7 @@ extern "C" nr_status nr_op_gemm_ex(nr_stream stream, const void* a, int32_t lda,
   p.out = (bf16*)out; p.ldo = ldo; p.out_scale = out_scale; p.geglu = geglu; p.act = act;
   p.rowvec = rowvec; p.rowvec_div = rowvec_div > 0 ? rowvec_div : 1; p.rowvec_mod = rowvec_mod; p.rowvec_ld = rowvec_ld;
   p.ln_c = ln_c; p.ln_eps = ln_eps;
+  op_fragmajor(p, (hipStream_t)stream);
   LAUNCH_OK(nr_launch_igemm(&p, ln_c ? nullptr : op_workspace(p), (hipStream_t)stream));
   NR_CATCH
 }

@@ -82,8 +82,11 @@ __device__ __forceinline__ int fdiv_small(int a, int d) {
 #define NR_STAMP_SLOTS 48
 __device__ unsigned long long nr_stamp_buf[512][NR_STAMP_SLOTS];
 #define NR_STAMP_AT(slot) do { if (threadIdx.x == 0 && blockIdx.x < 512 && (slot) < NR_STAMP_SLOTS) nr_stamp_buf[blockIdx.x][(slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+// the chip-wide 100 MHz counter (s_memtime counters are not synchronised across the chip): entry spread / kernel span over all workgroups
+#define NR_STAMP_RT(slot) do { if (threadIdx.x == 0 && blockIdx.x < 512) nr_stamp_buf[blockIdx.x][(slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define NR_STAMP_AT(slot) do { } while (0)
+#define NR_STAMP_RT(slot) do { } while (0)
 #endif
 
 // LIN: the launch is a plain Linear (1x1, one source): the im2col / tap / two-source paths are compiled out.  Same arithmetic; what it buys is
@@ -107,6 +110,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (LNF && WGM * WGN == 8) ? 4 : 1) vo
   const int lane = tid & 63;
   const int wave = tid >> 6;
   NR_STAMP_AT(0);
+  NR_STAMP_RT(44);
   const int wm = wave / WGN, wn = wave % WGN;
   const int ntn = (p.N + BN - 1) / BN;
   const int ntm = (p.M + BM - 1) / BM;
@@ -520,6 +524,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (LNF && WGM * WGN == 8) ? 4 : 1) vo
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     NR_STAMP_AT(3);
+    NR_STAMP_RT(45);
     return;
   }
 #pragma unroll
@@ -781,6 +786,9 @@ extern "C" int nr_launch_rowpanel(const NrGemmParams* pp, hipStream_t stream);
 // gemm8p.hip: 256-row ping-pong kernel for the big launches (SparseCtrl groups, several clips per call, 32-frame clips, the VAE)
 extern "C" int nr_g8p_plan(const NrGemmParams* pp);
 extern "C" int nr_launch_g8p(const NrGemmParams* pp, int m_fast, hipStream_t stream);
+// smallm.hip: panel-resident kernel for the M <= 512 Linears; needs the fragment-major copy of the weights (NrGemmParams::w_fm)
+extern "C" int nr_smallm_eligible(const NrGemmParams* pp);
+extern "C" int nr_launch_smallm(const NrGemmParams* pp, hipStream_t stream);
 #ifdef NR_EXPERIMENTS
 // Rejected experiments (csrc/experiments/, built only by `make experiments` into libneurons_amd_exp.so for the A/B tools; never the product):
 // gemm256.hip: 256-row tiles with role-alternating wave groups for the long-K convs / Linears (NR_IGEMM256=2)
@@ -788,9 +796,6 @@ extern "C" int nr_igemm256_plan(const NrGemmParams* pp, int* bn_out, int* splitk
 extern "C" size_t nr_igemm256_workspace_bytes(const NrGemmParams* pp);
 extern "C" int nr_launch_igemm256(const NrGemmParams* pp, float* workspace, int m_fast, int* splitk_used, hipStream_t stream);
 
-// smallm.hip: panel-resident kernel for the small-M Linears (weights straight into registers, no staged k-loop) (NR_SMALLM=1|2)
-extern "C" int nr_smallm_plan(const NrGemmParams* pp, int* ks_out, int* npass_out);
-extern "C" int nr_launch_smallm(const NrGemmParams* pp, hipStream_t stream);
 // gemmws.hip: four MFMA waves + one LDS-DMA wave per 128 x 128 tile (NR_IGEMM_WS=1|2)
 extern "C" int nr_igemm_ws_plan(const NrGemmParams* pp, int* splitk_out);
 extern "C" size_t nr_igemm_ws_workspace_bytes(const NrGemmParams* pp);
@@ -801,9 +806,9 @@ extern "C" int nr_launch_igemm_ws(const NrGemmParams* pp, float* workspace, int 
 extern "C" size_t nr_igemm_workspace_bytes(const NrGemmParams* pp) {
   if (pp->out_f32 || pp->ln_c) return 0;
   if (nr_rowpanel_eligible(pp)) return 0;
+  if (pp->w_fm && !getenv("NR_IGEMM_FORCE") && nr_smallm_eligible(pp)) return 0;
   if (nr_g8p_plan(pp)) return 0;
 #ifdef NR_EXPERIMENTS
-  if (pp->K == pp->ksize * pp->ksize * (pp->c0 + pp->c1) && nr_smallm_plan(pp, nullptr, nullptr)) return 0;
   if (nr_igemm_ws_plan(pp, nullptr)) return nr_igemm_ws_workspace_bytes(pp);
   if (nr_igemm256_plan(pp, nullptr, nullptr)) return nr_igemm256_workspace_bytes(pp);
 #endif
@@ -820,6 +825,8 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
   const int Cin = p.c0 + p.c1;
   // K = 320 Linears on >= 4096 rows: the register-resident row-panel kernel (rowpanel.hip)
   if (p.K == p.ksize * p.ksize * Cin && nr_rowpanel_eligible(pp)) return nr_launch_rowpanel(pp, stream);
+  // M <= 512 Linears with K a multiple of 640 whose weights the caller also holds fragment-major: the panel-resident kernel (smallm.hip)
+  if (p.w_fm && !getenv("NR_IGEMM_FORCE") && nr_smallm_eligible(pp)) return nr_launch_smallm(pp, stream);
   if (const int nt8 = nr_g8p_plan(pp)) {
     // tile order as below: the bigger operand is the one neighbouring tiles share; 8 x 4 blocks of tiles per XCD for weight-heavy shapes
     const double w_e = (double)p.N * p.K;
@@ -830,8 +837,6 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
     return nr_launch_g8p(pp, mf, stream);
   }
 #ifdef NR_EXPERIMENTS
-  // M <= 512 Linears with K a multiple of 640: the panel-resident kernel (smallm.hip)
-  if (p.K == p.ksize * p.ksize * Cin && !getenv("NR_IGEMM_FORCE") && nr_smallm_plan(pp, nullptr, nullptr)) return nr_launch_smallm(pp, stream);
   if (!getenv("NR_IGEMM_FORCE") && nr_igemm_ws_plan(pp, nullptr)) {
     const double w_e = (double)p.N * p.K, a_e = (double)p.M * Cin;
     int mf = w_e > a_e ? 1 : 0;

@@ -448,3 +448,107 @@ def test_fused_cross_attention_block_matches_torch(cuda, nimg, hw, ipc, Lk):
     _cmp(f"fused cross-attention block nimg={nimg} hw={hw} ipc={ipc} Lk={Lk}", out.view(nimg, hw, C), ref)
     t2 = t.clone()
     assert torch.equal(out, ops.xattn_fused(t2, nimg, hw, ipc, gamma, beta, wq, wo, bo, kv, Lk))
+
+
+@pytest.mark.parametrize("M,N,K,kind", [
+    (512, 1280, 1280, "res"),          # NT 5, 16 x 16 workgroups, one slab, panel resident (2 chunks)
+    (512, 1280, 1280, "ln"),
+    (512, 3840, 1280, "ln"),           # 3 slabs per workgroup
+    (512, 10240, 1280, "lngeglu"),     # NT 4, 10 slabs per workgroup
+    (512, 1280, 5120, "res"),          # 8 chunks: the panel streams through the 3-slot ring
+    (512, 1280, 6400, "rv"),           # 10 chunks + row vector + scale + quick_gelu
+    (512, 1280, 2560, "plain"),        # 4 chunks
+    (500, 1280, 1280, "res"),          # ragged last row tile
+    (33, 640, 640, "ln"),              # two row tiles, the second holds one row
+    (1, 1280, 1280, "plain"),
+    (512, 640, 640, "res"),            # one chunk
+    (512, 1920, 640, "ln"),            # NT 4 (120 n-tiles, G = 15, J = 2)
+    (512, 5120, 640, "geglu"),
+    (128, 1280, 1920, "res"),          # 3 chunks resident, NT 4
+    (512, 3840, 5120, "res"),          # slabs x streaming chunks (24 steps)
+    (256, 10240, 1280, "geglu"),
+])
+def test_panel_resident_small_m_gemm_matches_torch(cuda, monkeypatch, M, N, K, kind):
+    """smallm.hip: the M <= 512 Linears with K a multiple of 640 (fragment-major weights, the activation panel resident in LDS) against fp32
+    torch: plain / bias + residual / LayerNorm folded / GEGLU / LayerNorm + GEGLU / row vector + scale + quick_gelu, ragged M, one to ten
+    K chunks, one to ten column slabs per workgroup; and run-to-run bit equality."""
+    from neurons_amd import _lib, ops
+    lib = _lib.load()
+    monkeypatch.setenv("NR_SMALLM", "2")      # also the several-slabs-per-workgroup plans the shipped heuristic leaves to the tiled igemm
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N + K)
+    a = (torch.randn(M, K, generator=g, device="cuda") * 1.5 + 0.3).to(torch.bfloat16)
+    w = torch.randn(N, K, generator=g, device="cuda") * K ** -0.5
+    bias = 0.1 * torch.randn(N, generator=g, device="cuda")
+    gamma = 1.0 + 0.2 * torch.randn(K, generator=g, device="cuda")
+    beta = 0.1 * torch.randn(K, generator=g, device="cuda")
+    ln = kind in ("ln", "lngeglu")
+    geglu = kind in ("geglu", "lngeglu")
+    x = F.layer_norm(a.float(), (K,), gamma, beta, 1e-5) if ln else a.float()
+    h = F.linear(x, w if ln else w.to(torch.bfloat16).float(), bias)
+    nout = N // 2 if geglu else N
+    res = torch.randn(M, nout, generator=g, device="cuda").to(torch.bfloat16)
+
+    def run():
+        if kind == "lngeglu":
+            wf = w.float()
+            ws = (wf * gamma[None]).to(torch.bfloat16)
+            c = ws.float().sum(1)
+            b = (wf.double() @ beta.double()).float() + bias
+            wp, _ = ops.geglu_permute(ws, None)
+            cp, bp = ops.geglu_permute(c[:, None], b)
+            out = torch.empty(M, nout, dtype=torch.bfloat16, device="cuda")
+            _lib.check(lib.nr_op_ln_gemm(torch.cuda.current_stream().cuda_stream, a.data_ptr(), K, wp.data_ptr(), cp.contiguous().data_ptr(),
+                                         bp.data_ptr(), 1e-5, None, 0, out.data_ptr(), nout, M, N, K, 1, 0))
+            return out
+        if kind == "geglu":
+            wp, bp = ops.geglu_permute(w.to(torch.bfloat16), bias)
+            return ops.gemm(a, wp, bp, None, geglu=True)
+        if kind == "ln":
+            return ops.ln_gemm(a, w, gamma, beta, bias, res)
+        if kind == "rv":
+            return ops.gemm_ex(a, w, bias, rowvec=rv, rowvec_div=4, rowvec_mod=16, res=res, act=1, out_scale=0.5)
+        if kind == "res":
+            return ops.gemm(a, w.to(torch.bfloat16), bias, res)
+        return ops.gemm(a, w.to(torch.bfloat16), None, None)
+
+    if geglu:
+        ref = h[:, :N // 2] * F.gelu(h[:, N // 2:])
+    elif kind == "rv":
+        rv = torch.randn(16, N, generator=g, device="cuda")
+        fidx = (torch.arange(M, device="cuda") // 4) % 16
+        hh = (h + rv[fidx]) * 0.5
+        ref = hh * torch.sigmoid(1.702 * hh) + res.float()
+    elif kind == "plain":
+        ref = h - bias
+    else:
+        ref = h + res.float()
+    out = run()
+    _cmp(f"smallm {kind} {M}x{N}x{K}", out, ref)
+    for _ in range(5):
+        assert torch.equal(out, run())
+
+
+def test_panel_resident_small_m_gemm_is_the_kernel_that_runs(cuda):
+    """The op hook hands an eligible launch to smallm.hip (NR_SMALLM unset) and to the tiled igemm with NR_SMALLM=0: different summation orders,
+    so the two results differ in a few last bits while both meet the tolerance -- and the plan query says which one ran."""
+    import os
+    from neurons_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    M, N, K = 512, 1280, 1280
+    a = torch.randn(M, K, generator=g, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    ref = a.float() @ w.float().t()
+    old = os.environ.get("NR_SMALLM")
+    try:
+        os.environ["NR_SMALLM"] = "0"
+        o_igemm = ops.gemm(a, w)
+        os.environ.pop("NR_SMALLM")
+        o_small = ops.gemm(a, w)
+    finally:
+        if old is not None:
+            os.environ["NR_SMALLM"] = old
+        else:
+            os.environ.pop("NR_SMALLM", None)
+    _cmp("igemm", o_igemm, ref)
+    _cmp("smallm", o_small, ref)
+    assert not torch.equal(o_igemm, o_small)

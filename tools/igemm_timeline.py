@@ -29,7 +29,7 @@ SLOTS = 48
 
 
 def stamps(smallm):
-    buf = np.zeros((512, 8 if smallm else SLOTS), dtype=np.uint64)
+    buf = np.zeros((512, 40 if smallm else SLOTS), dtype=np.uint64)
     f = lib.nr_smallm_stamp_read if smallm else lib.nr_stamp_read
     assert f(buf.ctypes.data, buf.nbytes, 1) == 0
     return buf.astype(np.int64)
@@ -42,6 +42,9 @@ def run(M, N, K, res, pool_mb, smallm, force=None):
     b = torch.randn(N, device=dev)
     r = torch.randn(M, N, device=dev).to(torch.bfloat16) if res else None
     os.environ["NR_SMALLM"] = "2" if smallm else "0"
+    if HAS_SMALLM and hasattr(lib, "nr_op_fm_cache_clear"):
+        torch.cuda.synchronize()
+        lib.nr_op_fm_cache_clear()          # NR_SMALLM_FM=1: the fragment-major copies are cached per weight pointer
     if force:
         os.environ["NR_IGEMM_FORCE"] = force
     else:
@@ -58,23 +61,36 @@ def run(M, N, K, res, pool_mb, smallm, force=None):
             continue
         st = st[st[:, 0] > 0]
         t0 = st[:, 0].min()
+        rt0, rt1 = (6, 7) if smallm else (44, 45)      # 100 MHz chip-wide counter at entry / exit: 24 shader cycles per tick at 2.4 GHz
+        spread_us = float(st[:, rt0].max() - st[:, rt0].min()) / 100.0
+        span_us = float(st[:, rt1].max() - st[:, rt0].min()) / 100.0
         if smallm:
-            rows.append(dict(nwg=len(st), entry_spread=st[:, 0].max() - t0, dma_issued=np.median(st[:, 1] - st[:, 0]),
+            rows.append(dict(nwg=len(st), entry_spread_us=spread_us, dma_issued=np.median(st[:, 1] - st[:, 0]),
                              w_issued=np.median(st[:, 2] - st[:, 1]), panel_landed=np.median(st[:, 3] - st[:, 2]),
                              mfma_loop=np.median(st[:, 4] - st[:, 3]), epilogue=np.median(st[:, 5] - st[:, 4]),
-                             wg_total=np.median(st[:, 5] - st[:, 0]), wg_max=(st[:, 5] - st[:, 0]).max(), kernel_span=st[:, 5].max() - t0))
+                             wg_total=np.median(st[:, 5] - st[:, 0]), wg_max=(st[:, 5] - st[:, 0]).max(), kernel_span_us=span_us))
+            nst = int((st[0, 8:38:3] > 0).sum())          # per step: wait (from the previous step's end), barrier, MFMAs + refill issue
+            prev = st[:, 1]
+            steps = []
+            for t_ in range(nst):
+                steps.append("%d/%d/%d" % (np.median(st[:, 8 + 3 * t_] - prev), np.median(st[:, 9 + 3 * t_] - st[:, 8 + 3 * t_]), np.median(st[:, 10 + 3 * t_] - st[:, 9 + 3 * t_])))
+                prev = st[:, 10 + 3 * t_]
+            rows[-1]["_steps"] = " ".join(steps)
         else:
             nk = int((st[0, 4:40] > 0).sum())
-            rows.append(dict(nwg=len(st), nk=nk, entry_spread=st[:, 0].max() - t0, p_tileidx=np.median(st[:, 40] - st[:, 0]), p_rows=np.median(st[:, 41] - st[:, 40]),
+            rows.append(dict(nwg=len(st), nk=nk, entry_spread_us=spread_us, p_tileidx=np.median(st[:, 40] - st[:, 0]), p_rows=np.median(st[:, 41] - st[:, 40]),
                              p_kt=np.median(st[:, 42] - st[:, 41]), p_setup=np.median(st[:, 43] - st[:, 42]), p_issue=np.median(st[:, 1] - st[:, 43]), prologue=np.median(st[:, 1] - st[:, 0]),
                              first_tile=np.median(st[:, 4] - st[:, 1]),
                              per_tile=np.median((st[:, 4 + nk - 1] - st[:, 4]) / max(nk - 1, 1)),
                              loop=np.median(st[:, 2] - st[:, 1]), epilogue=np.median(st[:, 3] - st[:, 2]),
-                             wg_total=np.median(st[:, 3] - st[:, 0]), wg_max=(st[:, 3] - st[:, 0]).max(), kernel_span=st[:, 3].max() - t0))
+                             wg_total=np.median(st[:, 3] - st[:, 0]), wg_max=(st[:, 3] - st[:, 0]).max(), kernel_span_us=span_us))
+    step_txt = rows[-1].pop("_steps", None)
+    for r_ in rows:
+        r_.pop("_steps", None)
     keys = list(rows[0].keys())
     med = {k: float(np.median([r_[k] for r_ in rows])) for k in keys}
     print(f"{'smallm' if smallm else 'igemm '} M={M} N={N} K={K} res={int(res)} pool={pool_mb}MB force={force}: " +
-          " ".join(f"{k}={med[k]:.0f}" for k in keys), flush=True)
+          " ".join(f"{k}={med[k]:.2f}" if k.endswith("_us") else f"{k}={med[k]:.0f}" for k in keys), flush=True)
 
 
 if os.environ.get("TIMELINE_SHAPES"):      # "M,N,K,res;M,N,K,res;..." : the tiled igemm only, hot and HBM-cold weights
@@ -82,6 +98,8 @@ if os.environ.get("TIMELINE_SHAPES"):      # "M,N,K,res;M,N,K,res;..." : the til
         for spec in os.environ["TIMELINE_SHAPES"].split(";"):
             M_, N_, K_, r_ = (int(v) for v in spec.split(","))
             run(M_, N_, K_, bool(r_), pool, False, os.environ.get("TIMELINE_FORCE") or None)
+            if HAS_SMALLM and not os.environ.get("TIMELINE_IGEMM_ONLY"):
+                run(M_, N_, K_, bool(r_), pool, True)
     sys.exit(0)
 for pool in (0, 600):
     for smallm in (False,) if (os.environ.get("TIMELINE_IGEMM_ONLY") or not HAS_SMALLM) else (False, True):

@@ -1,5 +1,5 @@
-"""A/B of the panel-resident small-M GEMM (smallm.hip) against the tiled igemm on the M <= 512 Linears of the U-Net 4x4 level and the sgm
-keyframe model: same inputs, NR_SMALLM=0 vs 1, max |diff| of the outputs, and the time per launch inside a replayed graph of 48 launches that
+"""A/B of the panel-resident small-M GEMM (smallm.hip, fragment-major weights) against the tiled igemm on the M <= 512 Linears of the U-Net 4x4 level and the sgm
+keyframe model: same inputs, NR_SMALLM=0 vs 2, max |diff| of the outputs, and the time per launch inside a replayed graph of 48 launches that
 walk a pool of distinct weight tensors larger than the Infinity Cache (every launch streams its weights from HBM, as in the denoiser).
 Usage (GPU box): python tools/smallm_ab.py > gpurun_out/smallm_ab.txt"""
 import os
@@ -7,7 +7,6 @@ import sys
 
 import torch
 
-os.environ.setdefault("NR_LIB_VARIANT", "exp")      # make -C neurons_amd/csrc experiments
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neurons_amd import ops  # noqa: E402
 
@@ -17,6 +16,8 @@ SHAPES = [(512, 1280, 1280, "res"), (512, 1280, 1280, "ln"), (512, 3840, 1280, "
           (512, 1280, 6400, "res"), (512, 1280, 2560, "plain"), (512, 1280, 1280, "rv"), (500, 1280, 1280, "res"), (128, 1280, 1280, "res"),
           (512, 640, 640, "res"), (512, 1920, 640, "ln"), (512, 5120, 640, "geglu"), (2048, 640, 640, "res"), (2048, 1280, 1280, "res")]
 NCALL = 48
+if os.environ.get("SMALLM_AB_ONLY"):          # comma-separated indices into SHAPES
+    SHAPES = [SHAPES[int(i)] for i in os.environ["SMALLM_AB_ONLY"].split(",")]
 
 
 def make(M, N, K, kind, npool):
@@ -77,20 +78,21 @@ def graph_time(fns):
     return s.elapsed_time(e) / (5 * NCALL) * 1e3
 
 
+os.environ["NR_OP_FM_CACHE"] = "1"       # one fragment-major copy per weight tensor of the pool, packed outside the capture
 for (M, N, K, kind) in SHAPES:
     npool = max(2, min(NCALL, int(600e6 / (N * K * 2))))
     fns = make(M, N, K, kind, npool)
     os.environ["NR_SMALLM"] = "0"
     ref = fns[0]().float()
     t0 = graph_time(fns)
-    line = f"M={M:5d} N={N:5d} K={K:5d} {kind:8s} igemm {t0:6.1f}us |"
-    for split in ("4", "2", "1"):
-        os.environ["NR_SMALLM"] = "2"
-        os.environ["NR_SMALLM_KSPLIT"] = split
-        out = fns[0]().float()
-        t1 = graph_time(fns)
-        err = (out - ref).abs().max().item()
-        rel = ((out - ref).norm() / ref.norm()).item()
-        line += f" split{split} {t1:6.1f}us x{t0/t1:4.2f} max|d|={err:.3g} rel={rel:.1e} |"
-    os.environ.pop("NR_SMALLM_KSPLIT", None)
-    print(line, flush=True)
+    os.environ["NR_SMALLM"] = "2"
+    for f in fns:
+        f()
+    out = fns[0]().float()
+    t1 = graph_time(fns)
+    err = (out - ref).abs().max().item()
+    rel = ((out - ref).norm() / ref.norm()).item()
+    print(f"M={M:5d} N={N:5d} K={K:5d} {kind:8s} igemm {t0:6.1f}us | smallm {t1:6.1f}us x{t0/t1:4.2f} max|d|={err:.3g} rel={rel:.1e}", flush=True)
+    torch.cuda.synchronize()
+    del fns
+    ops._lib.load().nr_op_fm_cache_clear()
