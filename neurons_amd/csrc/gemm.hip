@@ -652,12 +652,16 @@ Plan choose_plan(const NrGemmParams& p) {
   // A 4-deep ring (3 tiles in flight) and, where the epilogue allows, 64x32 tiles (twice the blocks) measured -10 % on the
   // sgm keyframe step (tools/igemm_ab_sgm.sh); deeper rings (6, 8) and split-K + reduce were slower.
   static const bool smallm_rule = !(getenv("NR_IGEMM_SMALLM") && getenv("NR_IGEMM_SMALLM")[0] == '0');   // A/B switch
+  static const bool wide_rule = !(getenv("NR_IGEMM_WIDE") && getenv("NR_IGEMM_WIDE")[0] == '0');         // A/B switch
   if (smallm_rule && p.ksize == 1 && p.M <= 512 && nk >= 8) {
     pl.bm = 64; pl.bn = p.geglu ? 64 : 32; pl.waves = 4; pl.stages = 4;
     // wide GEGLU projections (N = 10240): enough 128x128 tiles for the chip, 22.4 vs 29.9 us; K = 6400 (folded net.2 + proj_out):
     // 64x64 tiles with four K slices, 23.1 vs 29.6 us (tools/sweep_ff.sh)
     if (p.geglu && p.N >= 8192 && p.M >= 256) { pl.bm = 128; pl.bn = 128; pl.waves = 8; pl.stages = 2; }
     else if (!p.geglu && nk >= 96 && !p.ln_c) { pl.bm = 64; pl.bn = 64; pl.stages = 2; pl.splitk = 4; return pl; }
+    // wide projections (q|k|v, N = 3840): 960 tiles of 64 x 32 re-read A 120 times; 240 tiles of 128 x 64 with the same 4-deep ring:
+    // 13.3 vs 19.8 us plain, 15.2 vs 17.5 us LayerNorm-folded (profiles/r05_sweep_ln_ns4.txt, HBM-cold weights)
+    else if (wide_rule && !p.geglu && nblk(64, 32) > 640 && nblk(128, 64) >= 192) { pl.bm = 128; pl.bn = 64; pl.waves = 8; pl.stages = 4; }
   }
   if (!p.geglu) {
     const long long tiles = nblk(pl.bm, pl.bn);
@@ -698,7 +702,7 @@ int launch_cfg(const NrGemmParams& p, unsigned grid, int splitk, float* partial,
   // LayerNorm-fused variant: instantiated for the tiles the transformer GEMMs use (nr_launch_igemm maps others onto them).
   // Its row-statistics exchange buffer lives in the DYNAMIC allocation behind the ring: a static __shared__ array next to
   // > 64 KiB of dynamic LDS made the first launch (and any hipGraph node captured from it) run with a short allocation.
-  constexpr bool LN_OK = (NS == 2 && BM <= 128 && BN <= 128) || (NS == 4 && BM * BN <= 64 * 64);
+  constexpr bool LN_OK = (NS == 2 && BM <= 128 && BN <= 128) || (NS == 4 && (BM * BN <= 64 * 64 || (BM == 128 && BN == 64)));
   if (p.ln_c) {
     if constexpr (LN_OK) {
       const size_t shm_ln = shm + (size_t)2 * WGN * BM * sizeof(float);
@@ -892,7 +896,7 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
     if (p.ksize != 1 || p.a1 || p.out_f32) return 8;
     pl.splitk = 1;
     if (pl.bn == 32) pl.bn = 64;             // every n-tile recomputes the row statistics: keep the n-tiles wide
-    if (!(pl.stages == 4 && pl.bm * pl.bn <= 64 * 64)) pl.stages = 2;
+    if (!(pl.stages == 4 && (pl.bm * pl.bn <= 64 * 64 || (pl.bm == 128 && pl.bn == 64)))) pl.stages = 2;
     if (pl.bm > 128) { pl.bm = 128; pl.bn = 128; pl.waves = 8; }
     if (pl.bn > 128) { pl.bn = 128; pl.waves = 8; }
   }

@@ -337,7 +337,7 @@ bool smallm_plan(const NrGemmParams& p, SmallmPlan* out) {
   if (mode == 1 && Mp > 512) return false;
   const int C = p.K / 640;
   if (C > 16) return false;
-  const int ntm = (p.M + 31) / 32, tiles = p.N / 16;
+  const int ntm = (Mp + 31) / 32, tiles = p.N / 16;      // planned on one clip's rows; the launch covers all of M with the same (nt, G, J)
   // the most workgroups that still fit ONE round of the chip (256 CUs, one workgroup each); ties: the wider slab
   SmallmPlan best{0, 0, 0, C};
   int best_wg = 0;

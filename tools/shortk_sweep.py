@@ -84,7 +84,7 @@ def main():
                 continue
             if c.startswith("64,32") and geglu:
                 continue
-            if geglu >= 2 and (c.startswith("256") or c.startswith("128,160") or (c and c.split(",")[3] not in ("2", "4"))):
+            if geglu >= 2 and (c.startswith("256") or c.startswith("128,160") or (c and c.split(",")[3] not in ("2", "4")) or (c and c.split(",")[2] != "1")):
                 continue                                   # LayerNorm-folded instantiations: 2-stage tiles up to 128x128, 4-stage 64x64
             if c:
                 os.environ["NR_IGEMM_FORCE"] = c
