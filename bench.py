@@ -294,7 +294,8 @@ def keyframe_main(args):
         "config": {"workload": f"BASELINE config 3: {B} keyframe(s) per Euler loop, ({B},4,{L},{L}) latent (CFG batch {2 * B}), {args.keyframe_steps} Euler steps, "
                                f"context 256x1664, 2 501 M-parameter UNetModel, random-init weights",
                    "keyframes_per_call": B, "ms_per_euler_step": round(1e3 * el / args.steps / args.keyframe_steps, 3),
-                   "ms_per_keyframe_step": round(1e3 * el / args.steps / args.keyframe_steps / B, 3), "output_finite": bool(torch.isfinite(out).all())},
+                   "ms_per_keyframe_step": round(1e3 * el / args.steps / args.keyframe_steps / B, 3), "output_finite": bool(torch.isfinite(out).all()),
+                   "resident_weight_gb": round(net.weight_bytes() / 1e9, 2)},
         "roofline": {"bound": "mfma", "kernel": "igemm_bf16_kernel", "achieved": round(ig["flops"] / (ig["ms"] * 1e-3) / 1e12, 2),
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ig["flops"] / (ig["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                      "traffic": keyframe_traffic(B, L), "per_class_ms_per_step": {k: round(v["ms"], 3) for k, v in p.items()},
@@ -638,6 +639,7 @@ def main():
                        "clips_per_gpu": args.steps * Bc, "frame_steps_per_s": round(value * args.ddim_steps, 2),
                        "ms_per_ddim_step": round(1e3 * elapsed / args.steps / args.ddim_steps, 3),
                        "hip_graph": not args.no_graph, "output_finite": finite, "setup_s": round(setup_s, 1),
+                       "resident_weight_gb": round((unet.weight_bytes() + ctrl.weight_bytes()) / 1e9, 2),
                        # whole-step algorithmic HBM bytes (every kernel's operands counted once) / measured wall time of a DDIM step
                        "achieved_hbm_gbs": round(step_bytes / (elapsed / args.steps / args.ddim_steps) / 1e9, 1),
                        "achieved_tflops": round(step_flops / (elapsed / args.steps / args.ddim_steps) / 1e12, 1),

@@ -724,7 +724,7 @@ struct nr_net {
     p.out_scale = o.scale; p.geglu = o.geglu; p.pad_tl0 = o.pad_tl0; p.act = o.act; p.ln_c = o.ln_c; p.ln_eps = 1e-5f;
     p.tap_inner = o.tap_inner;
     p.plan_m = det_batch ? (int)det_rows(p.M) : 0;
-    if (ksize == 1 && !x1 && nr_smallm_eligible(&p))        // M <= 512 Linears: the panel-resident kernel reads fragment-major weights
+    if (ksize == 1 && nr_smallm_eligible(&p))               // M <= 512 Linears: the panel-resident kernel reads fragment-major weights
       p.w_fm = dry ? reinterpret_cast<const bf16*>(uintptr_t(16)) : w_fragmajor(w, Cout, p.K);
     const int outC = o.geglu ? Cout / 2 : Cout;
     Act out = o.out ? *o.out : new_act(x0.nimg, OH, OW, outC);
@@ -2849,6 +2849,7 @@ extern "C" nr_status nr_op_gemm2(nr_stream stream, const void* a0, int32_t c0, i
   p.H = p.W = p.OH = p.OW = 1; p.ksize = 1; p.stride = 1;
   p.w = (const bf16*)w; p.M = M; p.N = N; p.K = p.c0 + p.c1; p.bias = bias; p.res = (const bf16*)res; p.ldr = ldr;
   p.out = (bf16*)out; p.ldo = ldo; p.out_scale = 1.f; p.rowvec_div = 1;
+  op_fragmajor(p, (hipStream_t)stream);
   LAUNCH_OK(nr_launch_igemm(&p, op_workspace(p), (hipStream_t)stream));
   NR_CATCH
 }

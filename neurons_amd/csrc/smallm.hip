@@ -82,6 +82,7 @@ __global__ __launch_bounds__(128 * NT) void smallm_kernel(NrGemmParams p_arg, in
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7, local = orig >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
   }
+  // (an 8 row-tile x 4 column-group block per XCD instead of 16 x 2 -- less panel, more weights fetched per XCD -- was worth 1-2 % at K >= 5120 only)
   const int g = bid / ntm;                    // column group: slabs g J .. g J + J - 1
   const int m0 = (bid - g * ntm) * 32;
   const int T = J * C;                        // steps: (slab, chunk), chunk fastest
@@ -111,7 +112,10 @@ __global__ __launch_bounds__(128 * NT) void smallm_kernel(NrGemmParams p_arg, in
     for (int i = 0; i < PP; ++i) {
       const int q = wave * PP + i;
       const int am = m0 + 8 * (q & 3) + lr;
-      const bf16* src = am < p.M ? p.a0 + (size_t)am * p.lda0 + c * 640 + (q >> 2) * 64 + ((lp ^ lr) << 3) : (const bf16*)smallm_zero16;
+      const int k0 = c * 640 + (q >> 2) * 64 + ((lp ^ lr) << 3);
+      // two-source operand [a0 | a1] (skip concat as a 1x1 GEMM, the [t | g] operand of the folded FeedForward): whole chunks from either
+      const bf16* row = k0 < p.c0 ? p.a0 + (size_t)am * p.lda0 + k0 : p.a1 + (size_t)am * p.lda1 + (k0 - p.c0);
+      const bf16* src = am < p.M ? row : (const bf16*)smallm_zero16;
       glds16_asm(src, lds0 + (unsigned)(slot * SM_CHB + q * 1024));
     }
   };
@@ -133,6 +137,8 @@ __global__ __launch_bounds__(128 * NT) void smallm_kernel(NrGemmParams p_arg, in
   // ---- prologue: everything the first two steps need is requested right after kernel entry ----
   issue_w(wa, 0);
   issue_panel(0);
+  // (a barrier here, so that every wave's chunk-0 requests queue before anybody's chunk-1 requests, moves 1 k cycles from the first wait into the
+  // issue phase and nothing else: profiles/r05_smallm_timeline.txt)
   if (T > 1) { issue_panel(1); issue_w(wb, 1); }
   SM_STAMP_AT(1);
   bool pnext = T > 1;                         // the panel chunk of step t + 1 was issued after step t's weights
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(128 * NT) void smallm_kernel(NrGemmParams p_arg, in
     if (slab_end && kq == 0) {                // epilogue operands, fetched behind this chunk's MFMAs
       if (p.bias) bv = *(const f32x4*)(p.bias + nq);
       if constexpr (LN) cv = *(const f32x4*)(p.ln_c + nq);
-      if constexpr (!GEGLU) {
+      if constexpr (!GEGLU && !LN) {          // (LayerNorm-folded: fetched in the epilogue, the 168-register budget of 10 waves is full)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
           const int m = m0 + 16 * mt + fr;
@@ -203,7 +209,11 @@ __global__ __launch_bounds__(128 * NT) void smallm_kernel(NrGemmParams p_arg, in
     for (int ks = 0; ks < SM_KSW; ++ks) {
       bf16x8 (&xc)[2] = (ks & 1) ? xc2 : xa;
       bf16x8 (&xn)[2] = (ks & 1) ? xa : xc2;
+#ifdef SM_ABLATE_X        // timing experiment (WRONG results): a quarter of the LDS fragment reads
+      if (ks + 1 < SM_KSW && ((ks + 1) & 3) == 0) read_x(xn, ks + 1); else { xn[0] = xc[0]; xn[1] = xc[1]; }
+#else
       if (ks + 1 < SM_KSW) read_x(xn, ks + 1);
+#endif
       acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcur[ks], xc[0], acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcur[ks], xc[1], acc[1], 0, 0, 0);
       if (refill) wcur[ks] = *(const bf16x8*)(wref + ks * 512);
@@ -277,7 +287,11 @@ __global__ __launch_bounds__(128 * NT) void smallm_kernel(NrGemmParams p_arg, in
         const int m = m0 + 16 * mt + fr;
         if (m >= p.M) continue;
         f32x4 v = acc[mt];
-        if constexpr (LN) v = (v - cv * mu[mt]) * rs[mt];
+        if constexpr (LN) {
+          v = (v - cv * mu[mt]) * rs[mt];
+          if (p.rowvec) rvv[mt] = *(const f32x4*)(p.rowvec + rowvec_row(p, m) + nq);
+          if (p.res) rr[mt] = *(const bf16x4*)(p.res + (size_t)m * p.ldr + nq);
+        }
         v += bv;
         if (p.rowvec) v += rvv[mt];
         v *= p.out_scale;
@@ -328,8 +342,9 @@ bool smallm_plan(const NrGemmParams& p, SmallmPlan* out) {
   const char* me = getenv("NR_SMALLM");                                             // read per call: the A/B tools switch it in-process
   const int mode = me ? atoi(me) : 1;                                                 // 0 off, 1 M <= 512 (default), 2 every eligible launch
   if (!mode) return false;
-  if (p.ksize != 1 || p.a1 || p.c1 != 0 || p.stride != 1 || p.ups || p.out_f32 || p.tap_inner) return false;
-  if (p.K != p.c0 || p.K % 640 != 0 || p.N % 16 != 0 || p.M < 1) return false;
+  if (p.ksize != 1 || p.stride != 1 || p.ups || p.out_f32 || p.tap_inner) return false;
+  if (p.a1 ? (p.c0 % 640 != 0 || p.c1 % 640 != 0 || p.lda1 % 8 != 0 || p.ln_c) : p.c1 != 0) return false;      // second source: whole 640-deep chunks
+  if (p.K != p.c0 + p.c1 || p.K % 640 != 0 || p.N % 16 != 0 || p.M < 1) return false;
   if (p.lda0 % 8 != 0 || p.ldo % 4 != 0 || (p.res && p.ldr % 4 != 0)) return false;
   if (p.rowvec && (p.rowvec_div <= 0 || p.rowvec_ld % 4 != 0)) return false;
   if (p.geglu && (p.rowvec || p.res || p.act || p.out_scale != 1.0f)) return false;

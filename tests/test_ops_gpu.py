@@ -467,6 +467,8 @@ def test_fused_cross_attention_block_matches_torch(cuda, nimg, hw, ipc, Lk):
     (128, 1280, 1920, "res"),          # 3 chunks resident, NT 4
     (512, 3840, 5120, "res"),          # slabs x streaming chunks (24 steps)
     (256, 10240, 1280, "geglu"),
+    (512, 1280, 6400, "cat"),          # two sources [1280 | 5120]: the folded net.2 | proj_out operand
+    (500, 1280, 2560, "cat"),          # [1280 | 1280]: a skip concat as a 1x1 GEMM
 ])
 def test_panel_resident_small_m_gemm_matches_torch(cuda, monkeypatch, M, N, K, kind):
     """smallm.hip: the M <= 512 Linears with K a multiple of 640 (fragment-major weights, the activation panel resident in LDS) against fp32
@@ -507,6 +509,8 @@ def test_panel_resident_small_m_gemm_matches_torch(cuda, monkeypatch, M, N, K, k
             return ops.ln_gemm(a, w, gamma, beta, bias, res)
         if kind == "rv":
             return ops.gemm_ex(a, w, bias, rowvec=rv, rowvec_div=4, rowvec_mod=16, res=res, act=1, out_scale=0.5)
+        if kind == "cat":
+            return ops.gemm2(a[:, :1280].contiguous(), a[:, 1280:].contiguous(), w.to(torch.bfloat16), bias, res)
         if kind == "res":
             return ops.gemm(a, w.to(torch.bfloat16), bias, res)
         return ops.gemm(a, w.to(torch.bfloat16), None, None)

@@ -20,7 +20,7 @@ lib = _lib.load()
 HAS_SMALLM = True
 try:
     lib.nr_smallm_stamp_read
-except AttributeError:      # `make stamp` (product kernels only); `make experiments STAMP=1` + NR_LIB_VARIANT=exp has the smallm stamps too
+except AttributeError:      # a build without -DNR_STAMP in smallm.hip
     HAS_SMALLM = False
 for fn in (lib.nr_stamp_read,) + ((lib.nr_smallm_stamp_read,) if HAS_SMALLM else ()):
     fn.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
@@ -90,7 +90,8 @@ def run(M, N, K, res, pool_mb, smallm, force=None):
     keys = list(rows[0].keys())
     med = {k: float(np.median([r_[k] for r_ in rows])) for k in keys}
     print(f"{'smallm' if smallm else 'igemm '} M={M} N={N} K={K} res={int(res)} pool={pool_mb}MB force={force}: " +
-          " ".join(f"{k}={med[k]:.2f}" if k.endswith("_us") else f"{k}={med[k]:.0f}" for k in keys), flush=True)
+          " ".join(f"{k}={med[k]:.2f}" if k.endswith("_us") else f"{k}={med[k]:.0f}" for k in keys) +
+          (f" steps(wait/barrier/mfma)=[{step_txt}]" if step_txt else ""), flush=True)
 
 
 if os.environ.get("TIMELINE_SHAPES"):      # "M,N,K,res;M,N,K,res;..." : the tiled igemm only, hot and HBM-cold weights
