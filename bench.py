@@ -298,6 +298,13 @@ def keyframe_main(args):
                    "resident_weight_gb": round(net.weight_bytes() / 1e9, 2)},
         "roofline": {"bound": "mfma", "kernel": "igemm_bf16_kernel", "achieved": round(ig["flops"] / (ig["ms"] * 1e-3) / 1e12, 2),
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ig["flops"] / (ig["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                     # the event pass launches eagerly (one HIP event pair per launch): with ~730 launches of ~10 us the HOST can be the slower side,
+                     # and the intervals then contain idle time (their sum exceeds the replayed graph's step).  Second reading: the class keeps its
+                     # share of the event pass, applied to the step as the timed region ran it.
+                     "event_pass_ms_per_step": round(sum(v["ms"] for v in p.values()), 3),
+                     "replayed_graph_ms_per_step": round(1e3 * el / args.steps / args.keyframe_steps, 3),
+                     "frac_of_replayed_step_share": round(ig["flops"] / (1e-3 * (1e3 * el / args.steps / args.keyframe_steps) * ig["ms"] /
+                                                                         max(sum(v["ms"] for v in p.values()), 1e-9)) / 1e12 / PEAK_BF16_TFLOPS, 4),
                      "traffic": keyframe_traffic(B, L), "per_class_ms_per_step": {k: round(v["ms"], 3) for k, v in p.items()},
                      "launches_per_step": int(sum(v["launches"] for v in p.values())),
                      "algorithmic_gbytes_per_step": round(sum(v["bytes"] for v in p.values()) / 1e9, 2),

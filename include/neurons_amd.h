@@ -338,6 +338,10 @@ void nr_ff_set_waves(int32_t waves);
 nr_status nr_leaf_forward(nr_net* h, nr_stream stream, const float* x_dev, const float* ctx_dev, int32_t ctx_len, float* out_dev);
 
 /* ---- single-op entry points (used by tests/ to check each kernel against the oracle) --------- */
+/* The GEMM hooks below hand a launch on <= 512 rows with K a multiple of 640 to the panel-resident kernel (smallm.hip; the engine's rule for the
+ * Linears of BasicTransformerBlock at the 4x4 level / the keyframe model, attention.py:256-300) after packing a fragment-major copy of w_dev on
+ * the same stream, on every call.  NR_OP_FM_CACHE=1 keeps one copy per weight pointer instead (timing tools); nr_op_fm_cache_clear frees them. */
+void nr_op_fm_cache_clear(void);
 nr_status nr_op_gemm(nr_stream stream, const void* a_dev, int32_t lda, const void* w_dev, const float* bias_dev,
                      const void* res_dev, int32_t ldr, void* out_dev, int32_t ldo, int32_t M, int32_t N, int32_t K,
                      int32_t geglu);

@@ -109,6 +109,7 @@ SYMBOLS = {
     "nr_net_num_ops": (_I32, [_VP]),
     "nr_net_op_desc": (C.c_char_p, [_VP, _I32]),
     "nr_leaf_forward": (_I32, [_VP, _VP, _VP, _VP, _I32, _VP]),
+    "nr_op_fm_cache_clear": (None, []),
     "nr_op_gemm": (_I32, [_VP, _VP, _I32, _VP, _VP, _VP, _I32, _VP, _I32, _I32, _I32, _I32, _I32]),
     "nr_op_gemm2": (_I32, [_VP, _VP, _I32, _I32, _VP, _I32, _I32, _VP, _VP, _VP, _I32, _VP, _I32, _I32, _I32]),
     "nr_op_ln_gemm": (_I32, [_VP, _VP, _I32, _VP, _VP, _VP, C.c_float, _VP, _I32, _VP, _I32, _I32, _I32, _I32, _I32, _I32]),

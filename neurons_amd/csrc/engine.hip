@@ -724,8 +724,6 @@ struct nr_net {
     p.out_scale = o.scale; p.geglu = o.geglu; p.pad_tl0 = o.pad_tl0; p.act = o.act; p.ln_c = o.ln_c; p.ln_eps = 1e-5f;
     p.tap_inner = o.tap_inner;
     p.plan_m = det_batch ? (int)det_rows(p.M) : 0;
-    if (ksize == 1 && nr_smallm_eligible(&p))               // M <= 512 Linears: the panel-resident kernel reads fragment-major weights
-      p.w_fm = dry ? reinterpret_cast<const bf16*>(uintptr_t(16)) : w_fragmajor(w, Cout, p.K);
     const int outC = o.geglu ? Cout / 2 : Cout;
     Act out = o.out ? *o.out : new_act(x0.nimg, OH, OW, outC);
     if (out.C != outC || out.rows() != p.M) throw NrError(NR_ERR_STATE, "conv: output shape mismatch");
@@ -734,6 +732,8 @@ struct nr_net {
       p.res = o.res->ptr; p.ldr = o.res->ld;
     }
     p.out = out.ptr; p.ldo = out.ld;
+    if (ksize == 1 && nr_smallm_eligible(&p))               // M <= 512 Linears: the panel-resident kernel reads fragment-major weights
+      p.w_fm = dry ? reinterpret_cast<const bf16*>(uintptr_t(16)) : w_fragmajor(w, Cout, p.K);
     {
       const double in_elems = (double)x0.rows() * (p.c0 + p.c1);   // every input element is needed at least once
       const double bytes = 2.0 * (in_elems + (double)p.N * p.K + (double)p.M * outC + (o.res ? (double)p.M * outC : 0.0));

@@ -54,7 +54,10 @@ def run(M, N, K, res, pool_mb, smallm, force=None):
     for it in range(min(npool, 12) + 3):
         w = ws[it % npool]
         torch.cuda.synchronize()
-        ops.gemm(a, w, b, r)
+        if os.environ.get("TIMELINE_GEGLU"):      # the GEGLU projection's epilogue and tile rules (no bias / residual)
+            ops.gemm(a, w, geglu=True)
+        else:
+            ops.gemm(a, w, b, r)
         torch.cuda.synchronize()
         st = stamps(smallm)
         if it < 3:
