@@ -653,11 +653,18 @@ Plan choose_plan(const NrGemmParams& p) {
   // sgm keyframe step (tools/igemm_ab_sgm.sh); deeper rings (6, 8) and split-K + reduce were slower.
   static const bool smallm_rule = !(getenv("NR_IGEMM_SMALLM") && getenv("NR_IGEMM_SMALLM")[0] == '0');   // A/B switch
   static const bool wide_rule = !(getenv("NR_IGEMM_WIDE") && getenv("NR_IGEMM_WIDE")[0] == '0');         // A/B switch
+  static const bool rowwave_rule = !(getenv("NR_IGEMM_ROWWAVE") && getenv("NR_IGEMM_ROWWAVE")[0] == '0');   // A/B switch
   if (smallm_rule && p.ksize == 1 && p.M <= 512 && nk >= 8) {
     pl.bm = 64; pl.bn = p.geglu ? 64 : 32; pl.waves = 4; pl.stages = 4;
     // wide GEGLU projections (N = 10240): enough 128x128 tiles for the chip, 22.4 vs 29.9 us; K = 6400 (folded net.2 + proj_out):
     // 64x64 tiles with four K slices, 23.1 vs 29.6 us (tools/sweep_ff.sh)
     if (p.geglu && p.N >= 8192 && p.M >= 256) { pl.bm = 128; pl.bn = 128; pl.waves = 8; pl.stages = 2; }
+    // ... and exactly 256 tiles of 128 x 160 at M = 512 (one round, one workgroup per CU, ring 3-4 deep: the 320 tiles of 128 x 128 wait for
+    // HBM-cold k-tiles with one in flight): 4 x 1 waves of 32 x 160 so that a wave holds whole (value, gate) pairs; 23.1 vs 28.9 us plain,
+    // 27.0 vs 31.7 us LayerNorm-folded (profiles/r05_sweep_rowwave.txt)
+    if (rowwave_rule && p.geglu && p.N >= 8192 && p.N % 160 == 0 && p.M > 256 && nblk(128, 160) <= 256) {
+      pl.bm = 128; pl.bn = 160; pl.waves = 41; pl.stages = p.ln_c ? 3 : 4;
+    }
     else if (!p.geglu && nk >= 96 && !p.ln_c) { pl.bm = 64; pl.bn = 64; pl.stages = 2; pl.splitk = 4; return pl; }
     // wide projections (q|k|v, N = 3840): 960 tiles of 64 x 32 re-read A 120 times; 240 tiles of 128 x 64 with the same 4-deep ring:
     // 13.3 vs 19.8 us plain, 15.2 vs 17.5 us LayerNorm-folded (profiles/r05_sweep_ln_ns4.txt, HBM-cold weights)
@@ -702,7 +709,8 @@ int launch_cfg(const NrGemmParams& p, unsigned grid, int splitk, float* partial,
   // LayerNorm-fused variant: instantiated for the tiles the transformer GEMMs use (nr_launch_igemm maps others onto them).
   // Its row-statistics exchange buffer lives in the DYNAMIC allocation behind the ring: a static __shared__ array next to
   // > 64 KiB of dynamic LDS made the first launch (and any hipGraph node captured from it) run with a short allocation.
-  constexpr bool LN_OK = (NS == 2 && BM <= 128 && BN <= 128) || (NS == 4 && (BM * BN <= 64 * 64 || (BM == 128 && BN == 64)));
+  constexpr bool LN_OK = (NS == 2 && BM <= 128 && BN <= 128) || (NS == 4 && (BM * BN <= 64 * 64 || (BM == 128 && BN == 64))) ||
+                         (BM == 128 && BN == 160 && WGN == 1 && NS <= 4);      // the row-wave 128x160 tile of the wide GEGLU projections
   if (p.ln_c) {
     if constexpr (LN_OK) {
       const size_t shm_ln = shm + (size_t)2 * WGN * BM * sizeof(float);
@@ -773,11 +781,12 @@ void apply_override(const NrGemmParams& p, Plan& pl, int& m_fast) {
   sscanf(e, "%d,%d,%d,%d,%d,%d", &bm, &bn, &sk, &st, &ord, &wv);
   if (bm > 0 && bn > 0) {
     const bool ok = (bm == 128 && (bn == 160 || bn == 128 || bn == 64)) || (bm == 64 && (bn == 64 || bn == 32)) || (bm == 256 && (bn == 128 || bn == 160));
-    if (ok && !(p.geglu && (bn == 160 || bn == 32))) { pl.bm = bm; pl.bn = bn; }
+    if (ok && !(p.geglu && ((bn == 160 && !(bm == 128 && wv == 41)) || bn == 32))) { pl.bm = bm; pl.bn = bn; }
   }
   if (wv == 4 || wv == 8) pl.waves = wv;
   if (pl.bm == 256 && pl.bn == 128 && wv != 4) pl.waves = 8;
   if (pl.bn == 160 || pl.bm == 64) pl.waves = 4;
+  if (wv == 41 && pl.bm == 128 && pl.bn == 160) pl.waves = 41;      // 4 x 1 waves (32 x 160 each): the row-wave tile
   if (sk > 0 && !p.geglu) { const int nk = p.K / 64; pl.splitk = sk > nk ? nk : sk; }
   if (st >= 2 && st <= 8) pl.stages = st;
   if (ord >= 0) m_fast = ord;
@@ -896,9 +905,10 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
     if (p.ksize != 1 || p.a1 || p.out_f32) return 8;
     pl.splitk = 1;
     if (pl.bn == 32) pl.bn = 64;             // every n-tile recomputes the row statistics: keep the n-tiles wide
-    if (!(pl.stages == 4 && (pl.bm * pl.bn <= 64 * 64 || (pl.bm == 128 && pl.bn == 64)))) pl.stages = 2;
+    if (!(pl.stages == 4 && (pl.bm * pl.bn <= 64 * 64 || (pl.bm == 128 && pl.bn == 64))) && pl.waves != 41) pl.stages = 2;
     if (pl.bm > 128) { pl.bm = 128; pl.bn = 128; pl.waves = 8; }
-    if (pl.bn > 128) { pl.bn = 128; pl.waves = 8; }
+    if (pl.bn > 128 && !(pl.bm == 128 && pl.bn == 160 && pl.waves == 41)) { pl.bn = 128; pl.waves = 8; }
+    if (pl.waves == 41 && pl.stages > 4) pl.stages = 4;
   }
   if (p.out_f32) {   // raw fp32 result: the kernel's slab path with a single K slice, no reduce pass
     if (p.geglu) return 7;
@@ -911,6 +921,9 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
   if (pl.bm == 256 && pl.bn == 160) rc = launch_tile<256, 160, 2, 2>(p, grid, pl, partial, m_fast, stream);
   else if (pl.bm == 256 && pl.waves == 4) rc = launch_tile<256, 128, 2, 2>(p, grid, pl, partial, m_fast, stream);
   else if (pl.bm == 256) rc = launch_tile<256, 128, 4, 2>(p, grid, pl, partial, m_fast, stream);
+  else if (pl.bm == 128 && pl.bn == 160 && pl.waves == 41)      // row-wave tile: rings 3 / 4 deep only (108 / 144 KiB: one workgroup per CU)
+    rc = pl.stages <= 3 ? launch_cfg<128, 160, 3, 4, 1>(p, grid, pl.splitk, partial, m_fast, stream)
+                        : launch_cfg<128, 160, 4, 4, 1>(p, grid, pl.splitk, partial, m_fast, stream);
   else if (pl.bm == 128 && pl.bn == 160) rc = launch_tile<128, 160, 2, 2>(p, grid, pl, partial, m_fast, stream);
   else if (pl.bm == 128 && pl.bn == 128 && pl.waves == 8) rc = launch_tile<128, 128, 2, 4>(p, grid, pl, partial, m_fast, stream);
   else if (pl.bm == 128 && pl.bn == 128) rc = launch_tile<128, 128, 2, 2>(p, grid, pl, partial, m_fast, stream);

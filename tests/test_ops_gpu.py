@@ -286,7 +286,7 @@ def test_ln_gemm_rows_with_large_mean(cuda):
 @pytest.mark.parametrize("M,N,K,geglu,ln", [(32768, 960, 320, False, False), (32768, 2560, 320, True, True), (8192, 1920, 640, False, True),
                                             (8192, 5120, 640, True, False), (9000, 1000 // 8 * 8 + 24, 320, False, True), (8192, 960, 64, False, True),
                                             (8192 + 72, 640, 640, False, False), (2048, 5120, 640, True, True), (40960, 1920, 640, False, True),
-                                            (2048 + 16, 672, 640, False, True)])
+                                            (2048 + 16, 672, 640, False, True), (512, 10240, 1280, True, True), (500, 10240, 1280, True, False)])
 def test_short_k_projection_shapes_match_torch(cuda, M, N, K, geglu, ln):
     """The q|k|v / GEGLU projection shapes of the 32x32 and 16x16 levels (short K, many n-tiles, ragged M and N) against fp32
     torch, with and without the folded LayerNorm / GEGLU epilogue / residual.  K = 320 with M >= 4096 runs on the row-panel kernel,

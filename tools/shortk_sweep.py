@@ -78,13 +78,14 @@ def main():
         a = torch.randn(M, K, generator=gen, device=dev).to(torch.bfloat16)
         res = []
         for c in CANDS:
-            if c.startswith("128,160") and (N % 160 or geglu):
+            rowwave = c.endswith(",41")             # 128 x 160 as 4 x 1 waves: GEGLU / LayerNorm-capable
+            if c.startswith("128,160") and (N % 160 or (geglu and not rowwave)):
                 continue
             if c.startswith("256,160") and (N % 160 or geglu):
                 continue
             if c.startswith("64,32") and geglu:
                 continue
-            if geglu >= 2 and (c.startswith("256") or c.startswith("128,160") or (c and c.split(",")[3] not in ("2", "4")) or (c and c.split(",")[2] != "1")):
+            if geglu >= 2 and not rowwave and (c.startswith("256") or c.startswith("128,160") or (c and c.split(",")[3] not in ("2", "4")) or (c and c.split(",")[2] != "1")):
                 continue                                   # LayerNorm-folded instantiations: 2-stage tiles up to 128x128, 4-stage 64x64
             if c:
                 os.environ["NR_IGEMM_FORCE"] = c
