@@ -641,6 +641,14 @@ Plan choose_plan(const NrGemmParams& p) {
     pl.bm = 128; pl.bn = 160; pl.splitk = 4;
     return pl;
   }
+  // Linears whose 64 x 160 tiling is ONE round of the chip (128-256 tiles: N = 1280 at the 8x8 level, M = 1024 / 2048) with K = 1024..3072: one
+  // workgroup per CU with a 3-deep ring instead of 320-640 smaller tiles two per CU: 16.2 vs 19.2 us at M = 2048, N = K = 1280, 26.5 vs 36.3 at
+  // K = 2560, 17.1 vs 20.1 LayerNorm-folded (2-deep ring there) (profiles/r05_sweep_64x160.txt, HBM-cold weights)
+  static const bool t64x160_rule = !(getenv("NR_IGEMM_T64X160") && getenv("NR_IGEMM_T64X160")[0] == '0');   // A/B switch
+  if (t64x160_rule && p.ksize == 1 && !p.geglu && p.N % 160 == 0 && p.M > 512 && nk >= 16 && nk <= 48 && nblk(64, 160) >= 128 && nblk(64, 160) <= 256) {
+    pl.bm = 64; pl.bn = 160; pl.stages = 3;
+    return pl;
+  }
   const bool n128 = p.N % 128 == 0 || p.N >= 960;          // <= 6 % padded columns otherwise
   if (!p.geglu && p.N % 160 == 0 && p.N < 960 && p.N % 128 != 0 && nk >= 20 && nblk(128, 160) >= 256) { pl.bm = 128; pl.bn = 160; }
   else if (n128 && nblk(128, 128) >= 400) { pl.bm = 128; pl.bn = 128; pl.waves = 8; }
@@ -710,7 +718,8 @@ int launch_cfg(const NrGemmParams& p, unsigned grid, int splitk, float* partial,
   // Its row-statistics exchange buffer lives in the DYNAMIC allocation behind the ring: a static __shared__ array next to
   // > 64 KiB of dynamic LDS made the first launch (and any hipGraph node captured from it) run with a short allocation.
   constexpr bool LN_OK = (NS == 2 && BM <= 128 && BN <= 128) || (NS == 4 && (BM * BN <= 64 * 64 || (BM == 128 && BN == 64))) ||
-                         (BM == 128 && BN == 160 && WGN == 1 && NS <= 4);      // the row-wave 128x160 tile of the wide GEGLU projections
+                         (BM == 128 && BN == 160 && WGN == 1 && NS <= 4) ||     // the row-wave 128x160 tile of the wide GEGLU projections
+                         (BM == 64 && BN == 160 && NS <= 3);                     // the one-round tile of the N = 1280 Linears at M = 1024 / 2048
   if (p.ln_c) {
     if constexpr (LN_OK) {
       const size_t shm_ln = shm + (size_t)2 * WGN * BM * sizeof(float);
@@ -780,7 +789,7 @@ void apply_override(const NrGemmParams& p, Plan& pl, int& m_fast) {
   int bm = -1, bn = -1, sk = -1, st = -1, ord = -1, wv = -1;
   sscanf(e, "%d,%d,%d,%d,%d,%d", &bm, &bn, &sk, &st, &ord, &wv);
   if (bm > 0 && bn > 0) {
-    const bool ok = (bm == 128 && (bn == 160 || bn == 128 || bn == 64)) || (bm == 64 && (bn == 64 || bn == 32)) || (bm == 256 && (bn == 128 || bn == 160));
+    const bool ok = (bm == 128 && (bn == 160 || bn == 128 || bn == 64)) || (bm == 64 && (bn == 64 || bn == 32 || bn == 160)) || (bm == 256 && (bn == 128 || bn == 160));
     if (ok && !(p.geglu && ((bn == 160 && !(bm == 128 && wv == 41)) || bn == 32))) { pl.bm = bm; pl.bn = bn; }
   }
   if (wv == 4 || wv == 8) pl.waves = wv;
@@ -905,9 +914,10 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
     if (p.ksize != 1 || p.a1 || p.out_f32) return 8;
     pl.splitk = 1;
     if (pl.bn == 32) pl.bn = 64;             // every n-tile recomputes the row statistics: keep the n-tiles wide
-    if (!(pl.stages == 4 && (pl.bm * pl.bn <= 64 * 64 || (pl.bm == 128 && pl.bn == 64))) && pl.waves != 41) pl.stages = 2;
+    const bool t64x160 = pl.bm == 64 && pl.bn == 160;
+    if (!(pl.stages == 4 && (pl.bm * pl.bn <= 64 * 64 || (pl.bm == 128 && pl.bn == 64))) && pl.waves != 41 && !(t64x160 && pl.stages <= 3)) pl.stages = 2;
     if (pl.bm > 128) { pl.bm = 128; pl.bn = 128; pl.waves = 8; }
-    if (pl.bn > 128 && !(pl.bm == 128 && pl.bn == 160 && pl.waves == 41)) { pl.bn = 128; pl.waves = 8; }
+    if (pl.bn > 128 && !(pl.bm == 128 && pl.bn == 160 && pl.waves == 41) && !t64x160) { pl.bm = 128; pl.bn = 128; pl.waves = 8; }
     if (pl.waves == 41 && pl.stages > 4) pl.stages = 4;
   }
   if (p.out_f32) {   // raw fp32 result: the kernel's slab path with a single K slice, no reduce pass
@@ -929,8 +939,10 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
   else if (pl.bm == 128 && pl.bn == 128) rc = launch_tile<128, 128, 2, 2>(p, grid, pl, partial, m_fast, stream);
   else if (pl.bm == 128 && pl.bn == 64 && pl.waves == 8) rc = launch_tile<128, 64, 4, 2>(p, grid, pl, partial, m_fast, stream);
   else if (pl.bm == 128 && pl.bn == 64) rc = launch_tile<128, 64, 2, 2>(p, grid, pl, partial, m_fast, stream);
+  else if (pl.bm == 64 && pl.bn == 160) rc = launch_tile<64, 160, 2, 2>(p, grid, pl, partial, m_fast, stream);
   else if (pl.bm == 64 && pl.bn == 32) rc = launch_tile<64, 32, 2, 2>(p, grid, pl, partial, m_fast, stream);
-  else rc = launch_tile<64, 64, 2, 2>(p, grid, pl, partial, m_fast, stream);
+  else if (pl.bm == 64 && pl.bn == 64) rc = launch_tile<64, 64, 2, 2>(p, grid, pl, partial, m_fast, stream);
+  else rc = 9;            // no such tile: never launch another one on a grid computed for this one
   if (rc) return rc;      // no instantiation for this (tile, LayerNorm-fused) request: fail loudly, never skip the launch
   if (pl.splitk > 1) {
     const long long total = (long long)p.M * (p.N / 4);

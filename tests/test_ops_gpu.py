@@ -27,7 +27,7 @@ def _bf(*shape, scale=1.0, dev="cuda"):
     return (torch.randn(*shape, device=dev) * scale).to(torch.bfloat16)
 
 
-@pytest.mark.parametrize("M,N,K", [(512, 1280, 1280), (32768, 320, 320), (154, 640, 768), (2048, 1280, 5120),
+@pytest.mark.parametrize("M,N,K", [(512, 1280, 1280), (32768, 320, 320), (154, 640, 768), (2048, 1280, 5120), (2048, 1280, 1280), (1000, 1280, 2560),
                                    (100, 64, 64), (8192, 960, 320)])
 def test_gemm_bias_res(cuda, M, N, K):
     from neurons_amd import ops
@@ -247,7 +247,7 @@ def test_cfg_ddim_step(cuda):
     assert err < 1e-4
 
 
-@pytest.mark.parametrize("M,N,K", [(1000, 320, 320), (4096, 960, 320), (300, 1280, 1280), (2048, 128, 64), (154, 3072, 768)])
+@pytest.mark.parametrize("M,N,K", [(1000, 320, 320), (4096, 960, 320), (300, 1280, 1280), (2048, 128, 64), (154, 3072, 768), (2048, 1280, 1280)])
 def test_ln_gemm_matches_layernorm_then_linear_and_is_deterministic(cuda, M, N, K):
     """LayerNorm folded into the igemm (row statistics accumulated inside the kernel) vs fp32 torch LN -> Linear."""
     from neurons_amd import ops
@@ -326,7 +326,7 @@ def test_short_k_projection_shapes_match_torch(cuda, M, N, K, geglu, ln):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("M,N,K", [(32768, 960, 320), (4096 + 80, 320, 320), (2048, 1920, 640), (640, 960, 320)])
+@pytest.mark.parametrize("M,N,K", [(32768, 960, 320), (4096 + 80, 320, 320), (2048, 1920, 640), (640, 960, 320), (2048 - 24, 1280, 1280)])
 def test_gemm_ex_temporal_pe_rowvec_scale_act(cuda, M, N, K):
     """The temporal q|k|v projection as the engine issues it: LayerNorm folded into the GEMM and the positional encoding pushed
     through the projection as an fp32 row vector selected by the row's frame, (m // hw) % F (motion_module.py:241-243,274-278),
