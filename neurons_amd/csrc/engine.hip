@@ -2164,7 +2164,8 @@ extern "C" nr_status nr_net_load_tensor(nr_net* h, const char* key, const float*
     if (derived_from(it->first) || (is_temb_src && it->first.rfind("temb", 0) == 0)) {
       (void)hipDeviceSynchronize();
       if (!h->in_import(it->second)) (void)hipFree(it->second);
-      h->dev_bytes.erase(it->first);
+      auto ib = h->dev_bytes.find(it->first);
+      if (ib != h->dev_bytes.end()) { h->weight_bytes -= ib->second; h->dev_bytes.erase(ib); }      // nr_net_weight_bytes stays the sum of what is resident
       it = h->dev.erase(it);
       h->planned = false;
     } else ++it;

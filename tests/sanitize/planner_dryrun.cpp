@@ -204,6 +204,45 @@ int main(int argc, char** argv) {
     OK(nr_leaf_forward(h, nullptr, sample, tr ? ctx : nullptr, tr ? 77 : 0, out));
     nr_net_destroy(h);
   }
+  // ---------------- C = 640 transformer at <= 512 rows: fragment-major weight copies of the panel-resident small-M kernel (smallm.hip) ----------------
+  if (nets.count("leaf_transformer640")) {
+    const Net& n = nets.at("leaf_transformer640");
+    long long bytes_on = 0, bytes_off = 0, bytes_reloaded = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass == 1) setenv("NR_SMALLM", "0", 1);
+      nr_net* h = nullptr;
+      OK(nr_net_create(&n.cfg, &h));
+      load_all(h, n, 9);
+      OK(nr_net_plan(h, 2, 2, 8, 8, 77));                             // 256 rows, K = 640: eligible
+      OK(nr_leaf_forward(h, nullptr, sample, ctx, 77, out));
+      (pass == 0 ? bytes_on : bytes_off) = nr_net_weight_bytes(h);
+      if (pass == 0) {
+        // reloading a tensor drops the converted weights derived from it -- the row-major matrix AND its fragment-major copy -- and the next plan
+        // rebuilds both: same total, nothing leaked
+        const long live_before = nr_stub_live_allocs();
+        for (auto& t : n.tensors)
+          if (t.first.find("attn1.to_out.0.weight") != std::string::npos) {
+            int64_t numel = 1;
+            for (auto d : t.second) numel *= d;
+            std::vector<float> data((size_t)numel, 0.01f);
+            OK(nr_net_load_tensor(h, t.first.c_str(), data.data(), t.second.data(), (int32_t)t.second.size()));
+          }
+        CHECK(nr_leaf_forward(h, nullptr, sample, ctx, 77, out) == NR_ERR_STATE, "forward after a reload must ask for a new plan");
+        OK(nr_net_plan(h, 2, 2, 8, 8, 77));
+        OK(nr_leaf_forward(h, nullptr, sample, ctx, 77, out));
+        bytes_reloaded = nr_net_weight_bytes(h);
+        CHECK(nr_stub_live_allocs() == live_before, "reload + re-plan must not leak converted weights");
+        OK(nr_net_plan(h, 2, 2, 32, 32, 77));                         // 4096 rows: same weights, no new copies
+        OK(nr_leaf_forward(h, nullptr, sample, ctx, 77, out));
+        CHECK(nr_net_weight_bytes(h) >= bytes_reloaded, "weights of another shape only add");
+      }
+      nr_net_destroy(h);
+    }
+    unsetenv("NR_SMALLM");
+    CHECK(bytes_on > bytes_off, "eligible Linears must hold a fragment-major copy of their weights");
+    CHECK(bytes_reloaded == bytes_on, "reload must rebuild exactly the dropped copies");
+    printf("fragment-major copies: %lld bytes on top of %lld\n", bytes_on - bytes_off, bytes_off);
+  }
   // ---------------- the other kinds: sgm U-Net, VAE decoder / encoder, CLIP ----------------
   if (nets.count("tiny_sgm")) {
     const Net& n = nets.at("tiny_sgm");

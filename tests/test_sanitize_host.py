@@ -35,13 +35,14 @@ def _write_schema(path):
     ucfg, ccfg = tiny_unet_config(), tiny_ctrl_config()
     nets.append(("tiny_unet", make_c_config(ucfg, _lib.NR_KIND_UNET3D), state_dict_schema(ucfg, _lib.NR_KIND_UNET3D)))
     nets.append(("tiny_ctrl", make_c_config(ccfg, _lib.NR_KIND_SPARSECTRL), state_dict_schema(ccfg, _lib.NR_KIND_SPARSECTRL)))
-    for name, kind, keys in (("leaf_temporal", _lib.NR_KIND_LEAF_TEMPORAL, _motion_keys("m", 320, 2)),
-                             ("leaf_transformer", _lib.NR_KIND_LEAF_TRANSFORMER3D, _transformer_keys("m", 320, 768))):
+    for name, kind, keys, width in (("leaf_temporal", _lib.NR_KIND_LEAF_TEMPORAL, _motion_keys("m", 320, 2), 320),
+                                    ("leaf_transformer", _lib.NR_KIND_LEAF_TRANSFORMER3D, _transformer_keys("m", 320, 768), 320),
+                                    ("leaf_transformer640", _lib.NR_KIND_LEAF_TRANSFORMER3D, _transformer_keys("m", 640, 768), 640)):
         c = _lib.NrNetConfig()
         c.kind = kind
-        c.in_channels = c.out_channels = 320
+        c.in_channels = c.out_channels = width
         c.num_levels = 1
-        c.block_out_channels[0] = 320
+        c.block_out_channels[0] = width
         c.num_heads, c.cross_attention_dim, c.norm_num_groups, c.norm_eps = 8, 768, 32, 1e-5
         c.use_motion_module, c.motion_num_heads, c.motion_num_attention_blocks, c.motion_pe_max_len = 1, 8, 2, 24
         nets.append((name, c, keys))
