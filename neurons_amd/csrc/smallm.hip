@@ -18,6 +18,12 @@
 //     two chunks ahead right behind the MFMAs that read it), 20 MFMAs, ONE barrier;
 //   * LayerNorm fold (row statistics from the panel, first slab), GEGLU (value / gate n-tiles on neighbouring waves), bias / row vector /
 //     scale / quick_gelu / residual epilogue in fragment layout, as the igemm's.
+//   * two-source operands [a0 | a1] (the skip concat as a 1x1 GEMM, the [t | g] operand of the folded net.2|proj_out): whole 640-deep chunks
+//     from either source.
+// Shipped plans have ONE slab per workgroup (N <= 1280 at M = 512): 1.1-1.66x the tiled igemm per launch; several slabs (N >= 1920) lose to
+// the igemm's bigger tiles and stay there (NR_SMALLM=2 keeps them for the tests).  What bounds it (profiles/r05_smallm_timeline.txt): the ISSUE
+// of 100 KB of weight loads + 40 KB of panel DMA per chunk through the CU's ~64 B/clk address path (2.2-2.5 k cycles for 320 MFMA cycles per
+// wave), with the wait + barrier of a chunk (1.0-1.9 k) not overlapped.
 // Round 3 had rejected the row-major form of this kernel (0.62-0.68x the igemm: 40 fragment-shaped loads took 8,400 cycles to ISSUE);
 // DESIGN_HISTORY.md has that story, profiles/r05_smallm_fm_ab.txt the first fragment-major A/B.
 #include "common.h"
