@@ -36,7 +36,14 @@ PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
 
-CURRENT_ROUND = "r05"      # a committed traffic file of an earlier round is reported as historical
+def current_round():
+    """Label of the newest round that has ANY evidence file under profiles/ ("r06" from profiles/r06_*): a committed traffic file whose
+    label is older than that (a round that kept profiles but forgot its PMC pass) is reported as historical.  Derived, not a constant to edit."""
+    import glob
+    import re
+    labels = [m.group(1) for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*"))
+              for m in [re.match(r"(r\d\d)_", os.path.basename(f))] if m]
+    return max(labels) if labels else None
 
 
 def parse():
@@ -76,23 +83,50 @@ def parse():
     return ap.parse_args()
 
 
+def count_gpus_without_runtime(topology="/sys/class/kfd/kfd/topology/nodes"):
+    """GPUs this process would see, from the KFD topology (nodes with simd_count > 0) cut down by HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES — no HIP runtime call (torch.cuda.device_count() may fall back to hipGetDeviceCount,
+    which initialises the runtime).  None when the topology cannot be read."""
+    try:
+        n = 0
+        for node in sorted(os.listdir(topology)):
+            with open(os.path.join(topology, node, "properties")) as f:
+                props = dict(ln.split(None, 1) for ln in f.read().splitlines() if " " in ln)
+            if int(props.get("simd_count", "0").strip()) > 0:
+                n += 1
+    except (OSError, ValueError):
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with no launcher around it: start N FRESH rank processes of this same script (one per GPU, the layout
     `accelerate launch` gives the reference: /root/reference/train_neurons.sh:92-96, scripts/neuroclips_video.py:39-40,323) and wait.
-    This parent never initialises HIP (torch.cuda.device_count() only counts) and never exec's: the ranks are children, rank 0's stdout
-    (the ONE JSON line) is forwarded, every other stream goes to stderr, the exit code is non-zero if any rank failed."""
+    This parent makes no HIP-runtime call at all, not even through torch (GPUs are counted from the KFD topology in sysfs; when that is unreadable the check is
+    skipped and a rank fails instead) and never exec's: the ranks are children, rank 0's stdout (the ONE JSON line) is forwarded, every
+    other stream goes to stderr, the exit code is non-zero if any rank failed.  Do not run the self-launcher under rocprofv3: the
+    profiler's preloaded library initialises the GPU in this parent before the ranks exist (profile a rank: `--gpus 1`, or torchrun)."""
     import signal
     import socket
     import subprocess
     import threading
     n = args.gpus
     if not args.launch_dry_run:
-        have = torch.cuda.device_count()
-        if have < n:
+        have = count_gpus_without_runtime()
+        if have is not None and have < n:
             raise SystemExit(f"--gpus {n} but this node shows {have} GPU(s)")
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    # the rendezvous port: probed free here, bound by rank 0 a moment later (a small window another process could take it in: the ranks then
+    # fail the rendezvous and the launcher reports it; a caller that needs certainty sets MASTER_PORT itself)
+    if os.environ.get("MASTER_PORT", "").isdigit() and "RANK" not in os.environ:
+        port = int(os.environ["MASTER_PORT"])
+    else:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
     argv = [a for a in sys.argv[1:] if a != "--self-launch"]
     procs = []
     for r in range(n):
@@ -755,7 +789,7 @@ def pmc_traffic():
     name = os.path.basename(files[-1])
     return {"igemm_hbm_gbytes_per_ddim_step": round(d["igemm_hbm_bytes_per_ddim_step"] / 1e9, 2),
             "whole_step_hbm_gbytes": round(d["whole_step_hbm_bytes"] / 1e9, 2), "source": name,
-            "traffic_source_round": name.split("_")[0], "historical": name.split("_")[0] != CURRENT_ROUND,
+            "traffic_source_round": name.split("_")[0], "historical": name.split("_")[0] != current_round(),
             "measured_in_this_run": False}      # a committed profiler measurement of the same command, not a live counter read
 
 

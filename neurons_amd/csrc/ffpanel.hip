@@ -471,7 +471,7 @@ extern "C" int nr_launch_ff_stream_pack(const bf16* w1, const bf16* wc, bf16* st
 
 extern "C" int nr_launch_ff_fused(const bf16* t, int ldt, const bf16* x, int ldx, bf16* out, int ldo, int M, const bf16* stream,
                                   const float* gamma, const float* beta, const float* b1, const float* bc, float ln_eps, int norot, hipStream_t s) {
-  if (M <= 0 || ldt % 8 != 0 || ldx % 4 != 0 || ldo % 4 != 0) return 1;
+  if (M <= 0 || ldt % 8 != 0 || ldx % 8 != 0 || ldo % 8 != 0) return 1;
   NrFFParams p;
   p.t = t; p.ldt = ldt; p.x = x; p.ldx = ldx; p.out = out; p.ldo = ldo; p.M = M; p.stream = stream; p.gamma = gamma; p.beta = beta; p.b1 = b1; p.bc = bc;
   p.ln_eps = ln_eps; p.norot = norot;

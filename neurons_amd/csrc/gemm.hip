@@ -828,7 +828,7 @@ extern "C" int nr_launch_igemm_ws(const NrGemmParams* pp, float* workspace, int 
 extern "C" size_t nr_igemm_workspace_bytes(const NrGemmParams* pp) {
   if (pp->out_f32 || pp->ln_c) return 0;
   if (nr_rowpanel_eligible(pp)) return 0;
-  if (pp->w_fm && !getenv("NR_IGEMM_FORCE") && nr_smallm_eligible(pp)) return 0;
+  if (pp->w_fm) return 0;                      // the caller chose smallm.hip when it built this description (nr_smallm_eligible)
   if (nr_g8p_plan(pp)) return 0;
 #ifdef NR_EXPERIMENTS
   if (nr_igemm_ws_plan(pp, nullptr)) return nr_igemm_ws_workspace_bytes(pp);
@@ -847,8 +847,9 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
   const int Cin = p.c0 + p.c1;
   // K = 320 Linears on >= 4096 rows: the register-resident row-panel kernel (rowpanel.hip)
   if (p.K == p.ksize * p.ksize * Cin && nr_rowpanel_eligible(pp)) return nr_launch_rowpanel(pp, stream);
-  // M <= 512 Linears with K a multiple of 640 whose weights the caller also holds fragment-major: the panel-resident kernel (smallm.hip)
-  if (p.w_fm && !getenv("NR_IGEMM_FORCE") && nr_smallm_eligible(pp)) return nr_launch_smallm(pp, stream);
+  // M <= 512 Linears with K a multiple of 640 whose weights the caller also holds fragment-major: the panel-resident kernel (smallm.hip).
+  // w_fm IS the decision (made once with nr_smallm_eligible when the description was built); a shape the kernel cannot serve is an error here
+  if (p.w_fm) return nr_launch_smallm(pp, stream);
   if (const int nt8 = nr_g8p_plan(pp)) {
     // tile order as below: the bigger operand is the one neighbouring tiles share; 8 x 4 blocks of tiles per XCD for weight-heavy shapes
     const double w_e = (double)p.N * p.K;

@@ -344,10 +344,16 @@ __global__ __launch_bounds__(256) void smallm_w_pack_kernel(const bf16* __restri
 struct SmallmPlan { int nt, G, J, C; };
 
 // shapes this kernel serves and how: nt n-tiles per slab, G column groups x J slabs each, C chunks of 640 along K
-bool smallm_plan(const NrGemmParams& p, SmallmPlan* out) {
-  const char* me = getenv("NR_SMALLM");                                             // read per call: the A/B tools switch it in-process
-  const int mode = me ? atoi(me) : 1;                                                 // 0 off, 1 M <= 512 (default), 2 every eligible launch
-  if (!mode) return false;
+// decided: the caller already chose this kernel (w_fm set at plan time): no environment is read, only the shape rules apply, so a launch can
+// never disagree with the plan that sized its workspace
+bool smallm_plan(const NrGemmParams& p, SmallmPlan* out, bool decided) {
+  int mode = 2;
+  if (!decided) {
+    if (getenv("NR_IGEMM_FORCE")) return false;                                       // plan sweeps of the tiled igemm (tools/gemm_sweep.py)
+    const char* me = getenv("NR_SMALLM");                                             // read when the CHOICE is made (engine: plan time; nr_op_* hooks: per call)
+    mode = me ? atoi(me) : 1;                                                         // 0 off, 1 M <= 512 (default), 2 every eligible launch
+    if (!mode) return false;
+  }
   if (p.ksize != 1 || p.stride != 1 || p.ups || p.out_f32 || p.tap_inner) return false;
   if (p.a1 ? (p.c0 % 640 != 0 || p.c1 % 640 != 0 || p.lda1 % 8 != 0 || p.ln_c) : p.c1 != 0) return false;      // second source: whole 640-deep chunks
   if (p.K != p.c0 + p.c1 || p.K % 640 != 0 || p.N % 16 != 0 || p.M < 1) return false;
@@ -394,13 +400,14 @@ template <int NT> smallm_kern_t smallm_pick(bool ln, bool geglu) {
 
 }  // namespace
 
-// 1 when nr_launch_igemm would hand this launch to the panel-resident kernel GIVEN fragment-major weights (the engine asks before it packs them)
-extern "C" int nr_smallm_eligible(const NrGemmParams* pp) { return smallm_plan(*pp, nullptr) ? 1 : 0; }
+// The CHOICE, made once per launch description: 1 when this shape should run on the panel-resident kernel.  The caller then packs fragment-major
+// weights and sets NrGemmParams::w_fm, and nr_launch_igemm / nr_igemm_workspace_bytes follow w_fm alone (no environment read at launch time)
+extern "C" int nr_smallm_eligible(const NrGemmParams* pp) { return smallm_plan(*pp, nullptr, false) ? 1 : 0; }
 
 extern "C" int nr_launch_smallm(const NrGemmParams* pp, hipStream_t stream) {
   const NrGemmParams& p = *pp;
   SmallmPlan pl;
-  if (!p.w_fm || !smallm_plan(p, &pl)) return 1;
+  if (!p.w_fm || !smallm_plan(p, &pl, true)) return 1;
   const bool ln = p.ln_c != nullptr, gg = p.geglu != 0;
   smallm_kern_t k = pl.nt == 5 ? smallm_pick<5>(ln, gg) : smallm_pick<4>(ln, gg);
   const size_t shm = (size_t)SM_NSLOT * SM_CHB + SM_SCRATCH;           // 140 KiB: one workgroup per CU

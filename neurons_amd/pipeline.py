@@ -318,40 +318,41 @@ class NeuroclipsPipeline:
             assert controlnet_images.shape[2] >= len(controlnet_image_index)
             controlnet_cond[:, :, controlnet_image_index] = controlnet_images[:, :, :len(controlnet_image_index)]
             controlnet_conditioning_mask[:, :, controlnet_image_index] = 1
-            if hasattr(self.controlnet, "set_condition_frames"):
-                # the frames that carry a condition are known here: no tensor scan, no dependence on autograd version counters
-                # (torch.inference_mode tensors have none)
-                self.controlnet.set_condition_frames([int(i) % video_length for i in controlnet_image_index])
-
-        lib = _lib.load()
-        n_lat = latents.numel()
-        for net in (self.unet, getattr(self, "controlnet", None)):
-            if hasattr(net, "set_clip_samples"):       # deterministic-batch mode plans per clip: a clip is 2 samples with guidance, 1 without
-                net.set_clip_samples(2 if do_classifier_free_guidance else 1)
-        fused = use_ctrl and hasattr(self.unet, "forward_with_controlnet") and \
-            getattr(self.controlnet, "set_noisy_sample_input_to_zero", False) and self.overlap_controlnet
-        # grouped schedule: G steps per SparseCtrl evaluation (controlnet_group_size)
-        b2 = latents.shape[0] * (2 if do_classifier_free_guidance else 1)
-        G = controlnet_group_size(len(timesteps_host), b2, latents.shape[2], latents.shape[3], latents.shape[4], self.controlnet_group) \
-            if (fused and hasattr(self.controlnet, "forward_async")) else 1
-        self.last_controlnet_group = G
-        pending = {}
-
-        def launch_group(g):
-            ts = []
-            for tt in groups[g]["timesteps"]:
-                ts += [float(tt)] * b2
-            pending[g] = self.controlnet.forward_async(ts, ctx_group, controlnet_cond, controlnet_conditioning_mask,
-                                                       controlnet_conditioning_scale, slot=groups[g]["slot"])
-
-        if G > 1:
-            groups, plan = controlnet_group_plan(list(timesteps_host), G)
-            ctx_group = text_embeddings.repeat(G, 1, 1)
-            launch_group(0)
         import contextlib
-        with contextlib.ExitStack() as cleanup, self.progress_bar(total=num_inference_steps) as progress_bar:
-            if use_ctrl and hasattr(self.controlnet, "set_condition_frames"):
-                cleanup.callback(self.controlnet.set_condition_frames, None)      # later direct forwards derive the list from their tensors again
+        cleanup = contextlib.ExitStack()
+        if use_ctrl and hasattr(self.controlnet, "set_condition_frames"):
+            # the frames that carry a condition are known here: no tensor scan, no dependence on autograd version counters
+            # (torch.inference_mode tensors have none).  The reset is registered BEFORE anything else can raise: a plan error or an
+            # out-of-memory in forward_async must not leave this call's frame list on the controlnet object (it overrides the tensor
+            # scan of later direct forwards)
+            cleanup.callback(self.controlnet.set_condition_frames, None)
+            self.controlnet.set_condition_frames([int(i) % video_length for i in controlnet_image_index])
+
+        with cleanup, self.progress_bar(total=num_inference_steps) as progress_bar:
+            lib = _lib.load()
+            n_lat = latents.numel()
+            for net in (self.unet, getattr(self, "controlnet", None)):
+                if hasattr(net, "set_clip_samples"):       # deterministic-batch mode plans per clip: a clip is 2 samples with guidance, 1 without
+                    net.set_clip_samples(2 if do_classifier_free_guidance else 1)
+            fused = use_ctrl and hasattr(self.unet, "forward_with_controlnet") and \
+                getattr(self.controlnet, "set_noisy_sample_input_to_zero", False) and self.overlap_controlnet
+            # grouped schedule: G steps per SparseCtrl evaluation (controlnet_group_size)
+            b2 = latents.shape[0] * (2 if do_classifier_free_guidance else 1)
+            G = controlnet_group_size(len(timesteps_host), b2, latents.shape[2], latents.shape[3], latents.shape[4], self.controlnet_group) \
+                if (fused and hasattr(self.controlnet, "forward_async")) else 1
+            self.last_controlnet_group = G
+            pending = {}
+
+            def launch_group(g):
+                ts = []
+                for tt in groups[g]["timesteps"]:
+                    ts += [float(tt)] * b2
+                pending[g] = self.controlnet.forward_async(ts, ctx_group, controlnet_cond, controlnet_conditioning_mask,
+                                                           controlnet_conditioning_scale, slot=groups[g]["slot"])
+            if G > 1:
+                groups, plan = controlnet_group_plan(list(timesteps_host), G)
+                ctx_group = text_embeddings.repeat(G, 1, 1)
+                launch_group(0)
             for i, t in enumerate(timesteps_host):
                 latent_model_input = torch.cat([latents] * 2) if do_classifier_free_guidance else latents
                 latent_model_input = self.scheduler.scale_model_input(latent_model_input, t if own_scheduler else timesteps[i])

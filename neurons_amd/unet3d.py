@@ -292,7 +292,18 @@ def tensor_version(t):
     try:
         return t._version
     except RuntimeError:
+        global _warned_versionless
+        if not _warned_versionless:
+            _warned_versionless = True
+            import warnings
+            warnings.warn("neurons_amd: a tensor created under torch.inference_mode() has no version counter, so the context / "
+                          "condition caches cannot recognise it: every call re-stages it and recomputes the cross-attention K|V "
+                          "(correct, but slower).  Use torch.no_grad() around the pipeline to keep the caches.", RuntimeWarning,
+                          stacklevel=3)
         return object()
+
+
+_warned_versionless = False
 
 
 class _NativeNet:
@@ -345,6 +356,39 @@ class _NativeNet:
         return self
 
     def requires_grad_(self, flag=False):
+        return self
+
+    # Memory-saving switches of the reference classes that its callers flip before building the pipeline
+    # (scripts/neuroclips_video.py:212-214 -> attention.py:228-254; unet.py:251-318; diffusers ModelMixin).  They select
+    # among numerically equivalent PyTorch attention / autograd paths; the HIP engine has one attention path, no autograd
+    # and a planned workspace, so they are accepted and change nothing.  Argument checks the reference makes are kept.
+    def enable_xformers_memory_efficient_attention(self, *args, **kwargs):
+        return None
+
+    def disable_xformers_memory_efficient_attention(self):
+        return None
+
+    def set_use_memory_efficient_attention_xformers(self, valid=True, *args, **kwargs):
+        return None
+
+    def set_attention_slice(self, slice_size="auto"):
+        """unet.py:251-314.  Accepted: "auto", "max", an int, or a list with one entry per attention layer."""
+        if not (slice_size in ("auto", "max") or slice_size is None or isinstance(slice_size, (int, list, tuple))):
+            raise ValueError(f"slice_size must be 'auto', 'max', an int or a list of ints, got {slice_size!r}")
+        return None
+
+    def enable_gradient_checkpointing(self):
+        return None
+
+    def disable_gradient_checkpointing(self):
+        return None
+
+    def _set_gradient_checkpointing(self, module=None, value=False):
+        return None
+
+    def train(self, mode=True):
+        if mode:
+            raise RuntimeError("neurons_amd networks are inference-only (no autograd through the HIP engine)")
         return self
 
     def enable_graph(self, flag=True):

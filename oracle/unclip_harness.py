@@ -1,4 +1,5 @@
-"""Test-local caller with the call sequence of the reference's ``utils.unclip_recon`` (utils.py:302-350), written against the
+"""TEST INFRASTRUCTURE (oracle-type caller restatement; never imported by neurons_amd/ or by bench.py's timed region).
+Caller with the call sequence of the reference's ``utils.unclip_recon`` (utils.py:302-350), written against the
 ATTRIBUTES of a ``diffusion_engine`` object only — exactly what the reference function touches, in its order:
 
     diffusion_engine.ema_scope()                                         (:307)

@@ -42,3 +42,21 @@ def test_parent_makes_no_gpu_call_before_the_ranks_exist():
     assert main_src.index("return self_launch(args)") < main_src.index("torch.cuda.set_device")
     body = src[src.index("def self_launch(args):"):src.index("def launch_dry_run(args):")]
     assert "os.exec" not in body and "set_device" not in body and "is_available" not in body
+    assert "torch.cuda" not in body and "device_count" not in body      # not even a device count through the runtime
+
+
+def test_gpu_count_comes_from_the_kfd_topology(tmp_path, monkeypatch):
+    """bench.count_gpus_without_runtime: nodes with simd_count > 0 are GPUs (the CPU node has 0); *_VISIBLE_DEVICES cut the count down;
+    an unreadable topology gives None (the launcher then skips its pre-check and lets a rank fail)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for i, simd in enumerate([0, 1024, 1024, 1024]):
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {16 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    assert bench.count_gpus_without_runtime(str(tmp_path)) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.count_gpus_without_runtime(str(tmp_path)) == 2
+    assert bench.count_gpus_without_runtime(str(tmp_path / "missing")) is None

@@ -374,3 +374,35 @@ def test_shipped_library_has_no_partially_overlapping_mfma_accumulator_chain():
     assert len(asms) >= 8
     hits = [h for a in asms for h in scan(a)]
     assert not hits, hits[:5]
+
+
+def test_native_networks_accept_every_call_the_reference_script_makes_before_the_pipeline():
+    """scripts/neuroclips_video.py touches the two network objects between construction and NeuroclipsPipeline(...):
+    :122-123 `unet.config.<attr> = ...`, :125 `SparseControlNetModel.from_unet(unet, controlnet_additional_kwargs=...)`,
+    :137-138 `controlnet.load_state_dict(sd)` / `.to(device)`, :212-214 `enable_xformers_memory_efficient_attention()` on both when
+    xformers imports (attention.py:228-254), plus the diffusers ModelMixin switches defined next to it (unet.py:251-318
+    `set_attention_slice`, `_set_gradient_checkpointing`).  The memory switches are documented no-ops here (one attention path, no autograd):
+    they must exist, return None and leave the object usable — an AttributeError on a box that has xformers would break "called unchanged"."""
+    from neurons_amd import NativeSparseCtrl, NativeUNet3D
+    unet = NativeUNet3D(UNet3DConfig(block_out_channels=(64, 64, 128, 128), cross_attention_dim=64))
+    unet.config.num_attention_heads = 8                                 # :122
+    unet.config.projection_class_embeddings_input_dim = None            # :123
+    ctrl = NativeSparseCtrl.from_unet(unet, controlnet_additional_kwargs=dict(
+        set_noisy_sample_input_to_zero=True, use_simplified_condition_embedding=True, conditioning_channels=4))
+    assert ctrl.use_simplified_condition_embedding is True              # read at :278
+    for net in (unet, ctrl):
+        before = dict(vars(net))
+        assert net.enable_xformers_memory_efficient_attention() is None                 # :213-214
+        assert net.enable_xformers_memory_efficient_attention(attention_op=None) is None
+        assert net.disable_xformers_memory_efficient_attention() is None
+        assert net.set_use_memory_efficient_attention_xformers(True) is None
+        for s in ("auto", "max", 4, [4, 4], None):
+            assert net.set_attention_slice(s) is None                                   # unet.py:251
+        with pytest.raises(ValueError):
+            net.set_attention_slice("half")
+        assert net.enable_gradient_checkpointing() is None and net.disable_gradient_checkpointing() is None
+        assert net._set_gradient_checkpointing(None, value=True) is None                # unet.py:316
+        assert net.eval() is net and net.requires_grad_(False) is net and net.train(False) is net
+        with pytest.raises(RuntimeError):
+            net.train()
+        assert dict(vars(net)) == before                                                 # nothing changed

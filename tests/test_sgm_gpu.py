@@ -100,9 +100,9 @@ def _psnr01(got, want):
 
 
 def test_boundary_engine_runs_unclip_recon_call_sequence(cuda):
-    """a test-local function with the call sequence of utils.unclip_recon (tests/unclip_harness.py) drives
+    """a test-local function with the call sequence of utils.unclip_recon (oracle/unclip_harness.py) drives
     NativeDiffusionEngine unchanged; expected pixels from the reference's own function (tests/golden/unclip_tiny.npz)."""
-    from unclip_harness import call_like_unclip_recon
+    from oracle.unclip_harness import call_like_unclip_recon
     eng, g = _tiny_engine(cuda)
     t = {k: torch.from_numpy(g[k]) for k in ("tokens", "vector_suffix", "z", "uc_tokens", "noise", "offset")}
     img = call_like_unclip_recon(t["tokens"].to(cuda), eng, t["vector_suffix"].to(cuda), t, num_samples=1, offset_noise_level=0.04, device=cuda)

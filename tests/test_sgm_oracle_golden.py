@@ -129,7 +129,7 @@ def test_boundary_generic_sampler_with_foreign_denoiser_matches_reference_loop()
 
 @torch.no_grad()
 def test_boundary_unclip_recon_call_sequence_on_cpu_engine():
-    """The call sequence of utils.unclip_recon (tests/unclip_harness.py) against an engine-shaped object whose network is the oracle:
+    """The call sequence of utils.unclip_recon (oracle/unclip_harness.py) against an engine-shaped object whose network is the oracle:
     pins ema_scope / sampler.discretization / sampler.num_steps / denoiser(model, x, sigma, c) / sampler(closure, …) / decode_first_stage
     of the boundary classes against the reference's own output (tests/golden/unclip_tiny.npz)."""
     import contextlib
@@ -138,7 +138,7 @@ def test_boundary_unclip_recon_call_sequence_on_cpu_engine():
     from neurons_amd.vae import vae_random_state_dict
     from oracle import vae_oracle as V
     from tiny_configs import tiny_vae_config
-    from unclip_harness import call_like_unclip_recon
+    from oracle.unclip_harness import call_like_unclip_recon
     g = np.load(os.path.join(HERE, "golden", "unclip_tiny.npz"))
     cfg, vcfg = tiny_sgm_config(), tiny_vae_config()
     vsd = vae_random_state_dict(vcfg, seed=91)
