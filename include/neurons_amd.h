@@ -415,6 +415,15 @@ nr_status nr_op_tattn_fused_frames(nr_stream stream, void* t_dev, int32_t nbatch
                                    const void* wk_dev, const void* wv_dev, const void* wo_dev, const float* gamma_dev, const float* gb_dev,
                                    const float* bo_dev, float ln_eps);
 
+/* The attention of one temporal-attention block ABOVE the C = 320 level up to (not including) to_out, one launch (tattnw.hip, round 6; engine:
+ * temporal_module):  a[:, head] = softmax(q k^T / sqrt(d)) v per pixel over its 16 frames, [q | k | v] = (LayerNorm(t) + pe[frame]) [Wq | Wk | Wv]^T
+ * (motion_module.py:210-218 norm -> VersatileAttention, :270-329; attention arithmetic motion_module_new.py:201-287), with the LayerNorm folded
+ * as everywhere in this library: w_folded bf16 [3C][C] = gamma[k] W[n][k] (rows to_q | to_k | to_v), lnc fp32 [3C] = row sums of w_folded,
+ * bias fp32 [3C] = sum_k beta[k] W[n][k], rowvec fp32 [16][3C] = pe[f] . W[n]^T.  t, a: bf16 [nbatch * 16 * hw][C] in "(b f) (h w) c" row order,
+ * C = 640 (hw a multiple of 8) or 1280 (hw a multiple of 4), 8 heads.  w_folded == NULL re-uses the weight stream packed by the previous call at this C. */
+nr_status nr_op_tattn_head(nr_stream stream, const void* t_dev, void* a_dev, int32_t nbatch, int32_t hw, int32_t C, const void* w_folded_dev,
+                           const float* lnc_dev, const float* bias_dev, const float* rowvec_dev, float ln_eps);
+
 #ifdef __cplusplus
 }
 #endif

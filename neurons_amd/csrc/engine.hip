@@ -84,6 +84,12 @@ int nr_tattn_fused_eligible(int C, int heads, int frames, int hw, long long rows
 int nr_launch_tattn_stream_pack(const bf16* wq, const bf16* wk, const bf16* wv, const bf16* wo, bf16* stream, hipStream_t s);
 int nr_launch_tattn_fused(bf16* t, int nbatch, int frames, int hw, const bf16* stream, const float* gamma, const float* gb, const float* bo, float ln_eps,
                           int norot, hipStream_t s);
+// tattnw.hip: q|k|v projection of one head + F x F attention per (pixel group, head) above the C = 320 level (C = 640 / 1280, F = 16)
+size_t nr_tattnw_stream_bytes(int C);
+int nr_tattnw_eligible(int C, int heads, int frames, int hw);
+int nr_launch_tattnw_stream_pack(const bf16* w_folded, int C, bf16* stream, hipStream_t s);
+int nr_launch_tattnw(const bf16* t, bf16* out, int nbatch, int hw, int C, const bf16* stream, const float* lnc, const float* bias, const float* rowvec,
+                     float ln_eps, hipStream_t s);
 // ffpanel.hip: fused FeedForward(GEGLU) + proj_out of the C = 320 level
 size_t nr_ff_stream_bytes(int C);
 int nr_ff_fused_eligible(int C, long long M);
@@ -439,8 +445,9 @@ struct nr_net {
   // wkeys: matrices [Neach][K] stacked along N (fused q|k|v); bkeys: their biases (empty = none);
   // geglu: single [2*Neach][K] projection with the value/gate row interleave of w_geglu.
   struct LnW { const bf16* w; const float* c; const float* b; };
+  // need_w = false: only c / b' are wanted (the matrix was packed into a kernel's weight stream and dropped again)
   LnW w_ln_linear(const std::vector<std::string>& wkeys, const std::vector<std::string>& bkeys, const std::string& ln, int Neach,
-                  int K, bool geglu) {
+                  int K, bool geglu, bool need_w = true) {
     std::string name = ln + "|";
     const int rows_each = geglu ? 2 * Neach : Neach;
     for (auto& k : wkeys) { check_shape(k, need(k), {rows_each, K}); name += k + "|"; }
@@ -450,8 +457,14 @@ struct nr_net {
     LnW r{nullptr, nullptr, nullptr};
     if (dry) return r;
     const std::string nw = "lnw:" + name, nc = "lnc:" + name, nb = "lnb:" + name;
-    auto it = dev.find(nw);
-    if (it != dev.end()) { r.w = (const bf16*)it->second; r.c = (const float*)dev.at(nc); r.b = (const float*)dev.at(nb); return r; }
+    {
+      auto it = dev.find(nw), ic = dev.find(nc), ib = dev.find(nb);
+      if (ic != dev.end() && ib != dev.end() && (it != dev.end() || !need_w)) {
+        r.w = it != dev.end() ? (const bf16*)it->second : nullptr; r.c = (const float*)ic->second; r.b = (const float*)ib->second;
+        return r;
+      }
+      drop(nw); drop(nc); drop(nb);                                  // partly present (matrix dropped after a stream pack): rebuild all three
+    }
     const HostTensor& g = data_of(ln + ".weight");
     const HostTensor& be = data_of(ln + ".bias");
     const size_t N = (size_t)rows_each * wkeys.size();
@@ -1160,11 +1173,45 @@ struct nr_net {
         op_tap("tattn_fused", t);
         continue;
       }
-      // LayerNorm, then + pe[frame] (motion_module.py:212,277): both folded into the q|k|v GEMM
-      Act qkv = ln_linear(t, b + ".norms." + std::to_string(k), {ab + ".to_q.weight", ab + ".to_k.weight", ab + ".to_v.weight"}, {}, C,
-                          false, 0, true);
-      Act a = attention(2, qkv, nullptr, C, heads);
-      qkv = Act();
+      Act a;
+      if (nr_tattnw_eligible(C, heads, F, x.H * x.W) && t.ld == C) {
+        // C = 640 / 1280, F = 16: LayerNorm + PE (folded), the q|k|v projection of one head and its 16 x 16 attention per (pixel group, head) in
+        // ONE launch (tattnw.hip); q|k|v never reach HBM.  to_out + residual stays the GEMM below.
+        const std::string nrm = b + ".norms." + std::to_string(k);
+        const std::vector<std::string> wk = {ab + ".to_q.weight", ab + ".to_k.weight", ab + ".to_v.weight"};
+        const float* rv = pe_projection(wk, C, C, cfg.motion_pe_max_len);
+        const std::string sname = "taws:" + nrm + "|" + wk[0] + "|" + wk[1] + "|" + wk[2];
+        const bf16* stream = (const bf16*)cached(sname, [&]() {
+          void* d = nullptr;
+          const size_t nb = nr_tattnw_stream_bytes(C);
+          // the folded [3C][C] matrix is only the input of the packed stream: freed again once it exists (unless another plan made it)
+          const std::string lnw_name = "lnw:" + nrm + "|" + wk[0] + "|" + wk[1] + "|" + wk[2] + "|";
+          const bool had = dev.count(lnw_name) != 0;
+          const LnW lwm = w_ln_linear(wk, {}, nrm, C, C, false, true);
+          HIP_OK(hipMalloc(&d, nb));
+          LAUNCH_OK(nr_launch_tattnw_stream_pack(lwm.w, C, (bf16*)d, nullptr));
+          HIP_OK(hipDeviceSynchronize());
+          dev[sname] = d; dev_bytes[sname] = nb; weight_bytes += nb;
+          if (!had) drop(lnw_name);
+          return d;
+        });
+        const LnW lw = w_ln_linear(wk, {}, nrm, C, C, false, false);
+        a = new_act(t.nimg, t.H, t.W, C);
+        const bf16* tp = t.ptr; bf16* ap = a.ptr;
+        const int nb2 = t.nimg / F, hw = x.H * x.W;
+        const float* lc = lw.c; const float* lb = lw.b;
+        const double M = (double)t.rows();
+        char d[160];
+        snprintf(d, sizeof(d), "tattn_head M=%d C=%d F=%d (LN+PE folded, q|k|v of one head, FxF attention)", (int)t.rows(), C, F);
+        emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_tattnw(tp, ap, nb2, hw, C, stream, lc, lb, rv, 1e-5f, s)); }, NR_PROF_IGEMM,
+             2.0 * M * C * 3.0 * C + 4.0 * (M / F) * heads * (double)F * F * (C / heads), 2.0 * (2.0 * M * C + 3.0 * C * (double)C), d);
+        op_tap("tattn_head", a);
+      } else {
+        // LayerNorm, then + pe[frame] (motion_module.py:212,277): both folded into the q|k|v GEMM
+        Act qkv = ln_linear(t, b + ".norms." + std::to_string(k), {ab + ".to_q.weight", ab + ".to_k.weight", ab + ".to_v.weight"}, {}, C,
+                            false, 0, true);
+        a = attention(2, qkv, nullptr, C, heads);
+      }
       GemmOpt oo; oo.bias = w_f32(ab + ".to_out.0.bias", C); oo.res = &t; oo.out = &t;
       linear(a, w_linear(ab + ".to_out.0.weight", C, C), C, oo);
     }
@@ -3031,6 +3078,23 @@ extern "C" nr_status nr_op_xattn_fused(nr_stream stream, void* t_dev, int32_t ni
   }
   LAUNCH_OK(nr_launch_xattn_fused((bf16*)t_dev, nimg, hw, img_per_ctx, nctx, Lk, (const bf16*)ws, (const bf16*)kvs, gamma_dev, beta_dev, bo_dev, ln_eps,
                                   getenv("NR_DETERMINISTIC_BATCH") && getenv("NR_DETERMINISTIC_BATCH")[0] == '1', (hipStream_t)stream));
+  NR_CATCH
+}
+// ---- q|k|v projection of one head + 16 x 16 attention above the C = 320 level (tattnw.hip), op-level entry for tests.  t: bf16 [nbatch * 16 * hw][C]
+// (C = 640 or 1280); a: bf16, same shape (attention output before to_out); w_folded: bf16 [3C][C] = gamma-scaled rows of to_q | to_k | to_v;
+// lnc / bias fp32 [3C]; rowvec fp32 [16][3C] ----
+extern "C" nr_status nr_op_tattn_head(nr_stream stream, const void* t_dev, void* a_dev, int32_t nbatch, int32_t hw, int32_t C, const void* w_folded_dev,
+                                      const float* lnc_dev, const float* bias_dev, const float* rowvec_dev, float ln_eps) {
+  NR_TRY
+  if (!t_dev || !a_dev || !lnc_dev || !bias_dev || !rowvec_dev) throw NrError(NR_ERR_ARG, "null argument");
+  if (!nr_tattnw_stream_bytes(C) || nbatch <= 0 || hw <= 0 || hw % (C == 640 ? 8 : 4) != 0)
+    throw NrError(NR_ERR_UNSUPPORTED, "temporal attention head kernel: C = 640 (hw % 8 == 0) or 1280 (hw % 4 == 0), 8 heads, 16 frames");
+  static void* ws[2] = {nullptr, nullptr};
+  void*& w = ws[C == 640 ? 0 : 1];
+  if (!w) HIP_OK(hipMalloc(&w, nr_tattnw_stream_bytes(C)));
+  // w_folded == NULL: reuse the stream packed by the previous call at this C (timing loops)
+  if (w_folded_dev) LAUNCH_OK(nr_launch_tattnw_stream_pack((const bf16*)w_folded_dev, C, (bf16*)w, (hipStream_t)stream));
+  LAUNCH_OK(nr_launch_tattnw((const bf16*)t_dev, (bf16*)a_dev, nbatch, hw, C, (const bf16*)w, lnc_dev, bias_dev, rowvec_dev, ln_eps, (hipStream_t)stream));
   NR_CATCH
 }
 extern "C" nr_status nr_op_tattn_fused(nr_stream stream, void* t_dev, int32_t nbatch, int32_t hw, const void* wq_dev, const void* wk_dev,

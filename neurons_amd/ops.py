@@ -269,6 +269,24 @@ def tattn_fused(t, nbatch, hw, gamma, beta, wq, wk, wv, wo, bo, eps=1e-5, reuse_
     return t
 
 
+def tattn_head(t, nbatch, hw, gamma, beta, wq, wk, wv, eps=1e-5, reuse_stream=False):
+    """a = temporal self-attention(LayerNorm(t) + pe) over the 16 frames of every pixel, BEFORE to_out, at C = 640 or 1280 (8 heads), ONE launch
+    (tattnw.hip).  t: [nbatch * 16 * hw, C] bf16 in "(b f) (h w) c" row order; w*: [C, C]; returns a (same shape, bf16).  The LayerNorm fold is
+    prepared here the way the engine prepares it (w_ln_linear / pe_projection): W' = bf16(gamma * W), c = row sums of W', b' = W beta, rv = pe W^T."""
+    _chk_bf16(t)
+    C, F = t.shape[1], 16
+    assert C in (640, 1280) and t.shape[0] == nbatch * F * hw
+    w = torch.cat([x.float() for x in (wq, wk, wv)], 0)                                  # [3C][C]
+    wf = (w * gamma.float()[None, :]).to(torch.bfloat16).contiguous()
+    lnc = wf.float().sum(1).contiguous()
+    bias = (w.double() @ beta.double()).float().contiguous()
+    rv = (temporal_pe_table(F, C, t.device).double() @ w.double().t()).float().contiguous()   # [16][3C]
+    a = torch.empty_like(t)
+    _lib.check(_lib.load().nr_op_tattn_head(_stream(), _ptr(t), _ptr(a), nbatch, hw, C, None if reuse_stream else _ptr(wf), _ptr(lnc), _ptr(bias),
+                                            _ptr(rv), float(eps)))
+    return a
+
+
 def xattn_fused(t, nimg, hw, img_per_ctx, gamma, beta, wq, wo, bo, kv, Lk, eps=1e-5, reuse_streams=False):
     """t <- t + to_out(cross-attention(LayerNorm(t), context K | V)) at C = 320, 8 heads, in ONE launch (xattn.hip).  t: [nimg * hw, 320] bf16 in
     "(b f) (h w) c" row order, updated IN PLACE and returned; image i attends to context i // img_per_ctx; kv: [nctx * Lk, 640] bf16 (K | V columns:

@@ -416,6 +416,42 @@ def test_fused_temporal_attention_block_matches_torch(cuda, nbatch, hw, F):
     assert torch.equal(out, ops.tattn_fused(t2, nbatch, hw, gamma, beta, wq, wk, wv, wo, bo, frames=F))
 
 
+@pytest.mark.parametrize("C,nbatch,hw", [(640, 2, 256), (640, 1, 24), (640, 3, 8), (1280, 2, 64), (1280, 1, 16), (1280, 5, 4), (1280, 3, 12)])
+def test_temporal_attention_head_kernel_matches_torch(cuda, C, nbatch, hw):
+    """tattnw.hip (round 6): norm -> (+ positional encoding) -> to_q|k|v -> softmax(q k^T / sqrt(d)) v over the 16 frames of each pixel, d = 80 / 160,
+    8 heads, one launch, output a BEFORE to_out; against the fp32 torch composition of the reference (motion_module.py:210-218 block, :270-329
+    VersatileAttention incl. the "(b f) d c -> (b d) f c" regroup, :225-243 PositionalEncoding; motion_module_new.py:201-287 attention arithmetic).
+    Shapes: the headline's (C = 640: 2 x 16 x 16 pixels; C = 1280: 2 x 8 x 8 and 4 x 4), pixel-group counts that are not a multiple of 8 (the other
+    workgroup -> XCD mapping at C = 640), an odd CFG batch.  Tolerance as the other MFMA ops (bf16 operands, fp32 accumulation and statistics)."""
+    from neurons_amd import ops
+    H, F = 8, 16
+    g = torch.Generator(device="cuda").manual_seed(C + nbatch * 1000 + hw)
+    t = (torch.randn(nbatch * F * hw, C, generator=g, device="cuda") * 1.1 + 0.1).to(torch.bfloat16)
+    gamma = 1.0 + 0.2 * torch.randn(C, generator=g, device="cuda")
+    beta = 0.1 * torch.randn(C, generator=g, device="cuda")
+    wq, wk, wv = (torch.randn(C, C, generator=g, device="cuda") * C ** -0.5 for _ in range(3))
+    wq = wq * 2.0                                  # sharper softmax: exercises the max subtraction
+    x = t.float().view(nbatch, F, hw, C)
+    n = torch.nn.functional.layer_norm(x, (C,), gamma, beta, 1e-5) + ops.temporal_pe_table(F, C, t.device)[None, :, None, :]
+    seq = n.permute(0, 2, 1, 3).reshape(nbatch * hw, F, C)                     # (b d) f c
+    q, k, v = (torch.nn.functional.linear(seq, w).view(-1, F, H, C // H).transpose(1, 2) for w in (wq, wk, wv))
+    a = torch.softmax(q @ k.transpose(-1, -2) * (C // H) ** -0.5, dim=-1) @ v
+    ref = a.transpose(1, 2).reshape(nbatch, hw, F, C).permute(0, 2, 1, 3)
+    out = ops.tattn_head(t, nbatch, hw, gamma, beta, wq, wk, wv)
+    _cmp(f"temporal attention head kernel C={C} nbatch={nbatch} hw={hw}", out.view(nbatch, F, hw, C), ref)
+    assert torch.equal(out, ops.tattn_head(t, nbatch, hw, gamma, beta, wq, wk, wv))
+    # row statistics under a large common offset (|mean| >> std: the cancellation case of the folded LayerNorm)
+    t2 = (t.float() + 6.0).to(torch.bfloat16)
+    x2 = t2.float().view(nbatch, F, hw, C)
+    n2 = torch.nn.functional.layer_norm(x2, (C,), gamma, beta, 1e-5) + ops.temporal_pe_table(F, C, t.device)[None, :, None, :]
+    seq2 = n2.permute(0, 2, 1, 3).reshape(nbatch * hw, F, C)
+    q, k, v = (torch.nn.functional.linear(seq2, w).view(-1, F, H, C // H).transpose(1, 2) for w in (wq, wk, wv))
+    a2 = torch.softmax(q @ k.transpose(-1, -2) * (C // H) ** -0.5, dim=-1) @ v
+    ref2 = a2.transpose(1, 2).reshape(nbatch, hw, F, C).permute(0, 2, 1, 3)
+    _cmp(f"temporal attention head kernel C={C} (rows offset by 6 sigma)", ops.tattn_head(t2, nbatch, hw, gamma, beta, wq, wk, wv).view(nbatch, F, hw, C),
+         ref2, max_tol=4e-2, mean_tol=8e-3)
+
+
 @pytest.mark.parametrize("nimg,hw,ipc,Lk", [(4, 1024, 2, 77), (6, 256, 3, 77), (2, 128, 1, 80), (3, 384, 3, 33)])
 def test_fused_cross_attention_block_matches_torch(cuda, nimg, hw, ipc, Lk):
     """xattn.hip (round 5): norm2 -> to_q -> softmax(q K^T / sqrt(40)) V on the cached context K | V of the row's clip -> to_out (+bias) -> + residual,

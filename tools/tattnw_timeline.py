@@ -1,0 +1,47 @@
+"""In-kernel timeline of the temporal attention head kernel (tattnw.hip; diagnostic build `make -C neurons_amd/csrc stamp`, NR_LIB_VARIANT=stamp):
+shader-clock stamps of wave 0 of the first 512 workgroups.  Per shape: medians over workgroups (cycles) of prologue, per-stage wait / barrier /
+compute, the epilogue (fold + attention + stores), workgroup lifetime, the span first entry -> last exit, and which XCDs ran the heads of one pixel group.
+Usage (GPU box): NR_LIB_VARIANT=stamp python tools/tattnw_timeline.py"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+os.environ.setdefault("NR_LIB_VARIANT", "stamp")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from neurons_amd import _lib, ops  # noqa: E402
+
+lib = _lib.load()
+lib.nr_tattnw_stamp_read.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+lib.nr_tattnw_stamp_read.restype = C.c_int
+dev = torch.device("cuda", 0)
+for Cc, nbatch, hw in ((640, 2, 256), (1280, 2, 64), (1280, 2, 16)):
+    S = Cc // 32
+    g = torch.Generator(device=dev).manual_seed(0)
+    t = torch.randn(nbatch * 16 * hw, Cc, generator=g, device=dev).to(torch.bfloat16)
+    gamma, beta = torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev)
+    wq, wk, wv = (torch.randn(Cc, Cc, generator=g, device=dev) * Cc ** -0.5 for _ in range(3))
+    buf = np.zeros((512, 128), dtype=np.uint64)
+    rows = []
+    for it in range(8):
+        ops.tattn_head(t, nbatch, hw, gamma, beta, wq, wk, wv, reuse_stream=it > 0)
+        torch.cuda.synchronize()
+        assert lib.nr_tattnw_stamp_read(buf.ctypes.data, buf.nbytes, 1) == 0
+        if it < 3:
+            continue
+        st = buf.astype(np.int64)
+        st = st[st[:, 0] > 0]
+        wait = np.mean([st[:, 2 + 3 * s] - (st[:, 1] if s == 0 else st[:, 4 + 3 * (s - 1)]) for s in range(S)], axis=0)
+        bar = np.mean([st[:, 3 + 3 * s] - st[:, 2 + 3 * s] for s in range(S)], axis=0)
+        comp = np.mean([st[:, 4 + 3 * s] - st[:, 3 + 3 * s] for s in range(S)], axis=0)
+        first = st[:, 2] - st[:, 1]
+        rows.append(dict(wgs=len(st), prologue=np.median(st[:, 1] - st[:, 0]), first_wait=np.median(first), wait=np.median(wait), barrier=np.median(bar),
+                         compute=np.median(comp), loop=np.median(st[:, 125] - st[:, 1]), epilogue=np.median(st[:, 126] - st[:, 125]),
+                         life=np.median(st[:, 126] - st[:, 0]), span=float(st[:, 126].max() - st[:, 0].min())))
+        xcc = st[:, 127]
+    med = {k: float(np.median([r[k] for r in rows])) for k in rows[0]}
+    print(f"tattn_head C={Cc} M={nbatch * 16 * hw} ({int(med['wgs'])} stamped workgroups, {S} stages): " + " ".join(f"{k}={v:.0f}" for k, v in med.items() if k != "wgs"))
+    print(f"   per stage: wait {med['wait']:.0f} + barrier {med['barrier']:.0f} + compute {med['compute']:.0f} = {med['wait'] + med['barrier'] + med['compute']:.0f} cycles;"
+          f" XCC ids of workgroups 0..15: {xcc[:16].tolist()}")
