@@ -88,8 +88,9 @@ int nr_launch_tattn_fused(bf16* t, int nbatch, int frames, int hw, const bf16* s
 size_t nr_tattnw_stream_bytes(int C);
 int nr_tattnw_eligible(int C, int heads, int frames, int hw);
 int nr_launch_tattnw_stream_pack(const bf16* w_folded, int C, bf16* stream, hipStream_t s);
-int nr_launch_tattnw(const bf16* t, bf16* out, int nbatch, int hw, int C, const bf16* stream, const float* lnc, const float* bias, const float* rowvec,
-                     float ln_eps, hipStream_t s);
+size_t nr_tattnw_table_bytes(int C);
+int nr_launch_tattnw_table_pack(const float* lnc, const float* bias, const float* rowvec, int C, float* table, hipStream_t s);
+int nr_launch_tattnw(const bf16* t, bf16* out, int nbatch, int hw, int C, const bf16* stream, const float* table, float ln_eps, hipStream_t s);
 // ffpanel.hip: fused FeedForward(GEGLU) + proj_out of the C = 320 level
 size_t nr_ff_stream_bytes(int C);
 int nr_ff_fused_eligible(int C, long long M);
@@ -1195,15 +1196,25 @@ struct nr_net {
           if (!had) drop(lnw_name);
           return d;
         });
-        const LnW lw = w_ln_linear(wk, {}, nrm, C, C, false, false);
+        // the head-major epilogue table (LayerNorm-fold vectors + positional-encoding projections) the kernel stages through LDS
+        const std::string tname = "tawe:" + std::to_string(cfg.motion_pe_max_len) + ":" + nrm + "|" + wk[0] + "|" + wk[1] + "|" + wk[2];
+        const float* table = (const float*)cached(tname, [&]() {
+          const LnW lw = w_ln_linear(wk, {}, nrm, C, C, false, false);
+          void* d = nullptr;
+          const size_t nb = nr_tattnw_table_bytes(C);
+          HIP_OK(hipMalloc(&d, nb));
+          LAUNCH_OK(nr_launch_tattnw_table_pack(lw.c, lw.b, rv, C, (float*)d, nullptr));
+          HIP_OK(hipDeviceSynchronize());
+          dev[tname] = d; dev_bytes[tname] = nb; weight_bytes += nb;
+          return d;
+        });
         a = new_act(t.nimg, t.H, t.W, C);
         const bf16* tp = t.ptr; bf16* ap = a.ptr;
         const int nb2 = t.nimg / F, hw = x.H * x.W;
-        const float* lc = lw.c; const float* lb = lw.b;
         const double M = (double)t.rows();
         char d[160];
         snprintf(d, sizeof(d), "tattn_head M=%d C=%d F=%d (LN+PE folded, q|k|v of one head, FxF attention)", (int)t.rows(), C, F);
-        emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_tattnw(tp, ap, nb2, hw, C, stream, lc, lb, rv, 1e-5f, s)); }, NR_PROF_IGEMM,
+        emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_tattnw(tp, ap, nb2, hw, C, stream, table, 1e-5f, s)); }, NR_PROF_IGEMM,
              2.0 * M * C * 3.0 * C + 4.0 * (M / F) * heads * (double)F * F * (C / heads), 2.0 * (2.0 * M * C + 3.0 * C * (double)C), d);
         op_tap("tattn_head", a);
       } else {
@@ -3090,11 +3101,17 @@ extern "C" nr_status nr_op_tattn_head(nr_stream stream, const void* t_dev, void*
   if (!nr_tattnw_stream_bytes(C) || nbatch <= 0 || hw <= 0 || hw % (C == 640 ? 8 : 4) != 0)
     throw NrError(NR_ERR_UNSUPPORTED, "temporal attention head kernel: C = 640 (hw % 8 == 0) or 1280 (hw % 4 == 0), 8 heads, 16 frames");
   static void* ws[2] = {nullptr, nullptr};
+  static void* tbl[2] = {nullptr, nullptr};
   void*& w = ws[C == 640 ? 0 : 1];
+  void*& tb = tbl[C == 640 ? 0 : 1];
   if (!w) HIP_OK(hipMalloc(&w, nr_tattnw_stream_bytes(C)));
-  // w_folded == NULL: reuse the stream packed by the previous call at this C (timing loops)
-  if (w_folded_dev) LAUNCH_OK(nr_launch_tattnw_stream_pack((const bf16*)w_folded_dev, C, (bf16*)w, (hipStream_t)stream));
-  LAUNCH_OK(nr_launch_tattnw((const bf16*)t_dev, (bf16*)a_dev, nbatch, hw, C, (const bf16*)w, lnc_dev, bias_dev, rowvec_dev, ln_eps, (hipStream_t)stream));
+  if (!tb) HIP_OK(hipMalloc(&tb, nr_tattnw_table_bytes(C)));
+  // w_folded == NULL: reuse the stream and the epilogue table packed by the previous call at this C (timing loops)
+  if (w_folded_dev) {
+    LAUNCH_OK(nr_launch_tattnw_stream_pack((const bf16*)w_folded_dev, C, (bf16*)w, (hipStream_t)stream));
+    LAUNCH_OK(nr_launch_tattnw_table_pack(lnc_dev, bias_dev, rowvec_dev, C, (float*)tb, (hipStream_t)stream));
+  }
+  LAUNCH_OK(nr_launch_tattnw((const bf16*)t_dev, (bf16*)a_dev, nbatch, hw, C, (const bf16*)w, (const float*)tb, ln_eps, (hipStream_t)stream));
   NR_CATCH
 }
 extern "C" nr_status nr_op_tattn_fused(nr_stream stream, void* t_dev, int32_t nbatch, int32_t hw, const void* wq_dev, const void* wk_dev,

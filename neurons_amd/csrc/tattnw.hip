@@ -96,7 +96,10 @@ template <int D> struct TW {
   static constexpr int PPW = W_PIECES + A_PIECES;             // DMA pieces per wave and stage: 6 / 9
   static constexpr int PPS = 2;                               // pieces issued behind each MFMA group (NG groups per stage: 6 / 10 slots)
   static constexpr int WG_PER_CU = D == 80 ? 2 : 1;
-  static_assert(NT % GS == 0 && NG * PPS >= PPW && NS >= 3 && NS <= 4 && NT * 1024 <= W_STAGE, "piece schedule / wait counts");
+  static constexpr int TBL_HEAD = D == 80 ? 16 * 1024 : 32 * 1024;   // epilogue table of one head: 17 x 3 d floats (16 320 / 32 640 B) padded to whole pieces
+  static constexpr int TBL_PIECES = TBL_HEAD / 4096;          // per wave: 4 / 8
+  static_assert(17 * 3 * D * 4 <= TBL_HEAD && TBL_HEAD <= STAGE, "the epilogue table lands in one free ring slot");
+  static_assert(NT % GS == 0 && NG * PPS >= PPW && NG * PPS >= (D == 80 ? 4 : 8) && NS >= 3 && NS <= 4 && NT * 1024 <= W_STAGE, "piece schedule / wait counts");
 };
 
 struct NrTAttnWParams {
@@ -105,9 +108,8 @@ struct NrTAttnWParams {
   int hw, nbatch;          // pixels per frame-image, CFG batch
   int xcd_mode;            // 0: the 8 heads of a pixel group share an XCD (needs pixel groups % 8 == 0); 1: head h on XCD h
   const bf16* stream;      // [8 heads][S stages][W_STAGE] fragment-major folded weights (tattnw_stream_pack_kernel)
-  const float* lnc;        // [3 C] c[n] = sum_k W'[n][k]            (rows: q | k | v)
-  const float* bias;       // [3 C] b'[n] = sum_k beta[k] W[n][k]
-  const float* rowvec;     // [>= F][3 C] pe[f] . W[n]^T
+  const float* table;      // [8 heads][TBL_HEAD bytes]: per head [17][3 d] fp32 = row 0: c[n] = sum_k W'[n][k]; row 1 + f: b'[n] + pe[f] . W[n]^T
+                           // (n = the head's q | k | v rows; tattnw_table_pack_kernel), padded to whole DMA pieces
   float ln_eps;
   float scale_log2e;       // d^-0.5 * log2(e)
 };
@@ -143,11 +145,18 @@ __global__ __launch_bounds__(256, TW<D>::WG_PER_CU) void tattn_head_kernel(NrTAt
     const int r = lane >> 2;
     arow[a] = p.t + ((size_t)(b * TW_F + r) * p.hw + pix0 + a) * C + (((lane & 3) ^ ((-(r >> 2)) & 3)) << 3);
   }
+  // Every workgroup walks the k-steps from its own starting point (rot = its pixel group's position in the image, so a row's arithmetic does not
+  // depend on the batch it runs in): the 32-64 workgroups of an XCD that stream the SAME head would otherwise request the same KiB of the stream
+  // from the same L2 channels in lock-step (tattn.hip rotates its heads for the same reason; first builds of this kernel waited 860 cycles per
+  // 36-KiB stage = 18 B/clk per CU, profiles/r06_tattnw_timeline.txt)
+  const int rot = (pg - b * groups_per_img) % T::S;
   auto issue_piece = [&](int s, int slot, int i) {
     const unsigned dst = lds0 + (unsigned)(slot * T::STAGE);
-    if (i < T::W_PIECES) glds16(wsrc + (size_t)s * T::W_STAGE + (size_t)i * 1024, dst + (unsigned)((wave * T::W_PIECES + i) * 1024));
-    else glds16(arow[i - T::W_PIECES] + 32 * s, dst + (unsigned)(T::W_STAGE + wave * (T::ROWS_W * 64) + (i - T::W_PIECES) * 1024));
+    int ks = s + rot; if (ks >= T::S) ks -= T::S;
+    if (i < T::W_PIECES) glds16(wsrc + (size_t)ks * T::W_STAGE + (size_t)i * 1024, dst + (unsigned)((wave * T::W_PIECES + i) * 1024));
+    else glds16(arow[i - T::W_PIECES] + 32 * ks, dst + (unsigned)(T::W_STAGE + wave * (T::ROWS_W * 64) + (i - T::W_PIECES) * 1024));
   };
+  const char* tsrc = reinterpret_cast<const char*>(p.table) + (size_t)head * T::TBL_HEAD + (size_t)(wave * T::TBL_PIECES) * 1024 + (size_t)lane * 16;
   // prologue: stages 0 .. NS - 2
 #pragma unroll
   for (int s = 0; s < T::NS - 1; ++s)
@@ -213,6 +222,12 @@ __global__ __launch_bounds__(256, TW<D>::WG_PER_CU) void tattn_head_kernel(NrTAt
           const int i = g * T::PPS + q;
           if (i < T::PPW) issue_piece(s_next, pslot, i);
         }
+      } else if (s == T::S - 1) {             // last stage: the head's epilogue table into the slot stage S - 2 just left
+#pragma unroll
+        for (int q = 0; q < T::PPS; ++q) {
+          const int i = g * T::PPS + q;
+          if (i < T::TBL_PIECES) glds16(tsrc + (size_t)i * 1024, lds0 + (unsigned)(pslot * T::STAGE + (wave * T::TBL_PIECES + i) * 1024));
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -229,6 +244,11 @@ __global__ __launch_bounds__(256, TW<D>::WG_PER_CU) void tattn_head_kernel(NrTAt
     slot = slot + 1 == T::NS ? 0 : slot + 1;
   }
   TW_STAMP(125);
+  // the epilogue table sits in the slot "before" the last stage's: slot now = (last + 1) % NS, table slot = (last + NS - 1) % NS = (slot + NS - 2) % NS
+  int tslot = slot + T::NS - 2; if (tslot >= T::NS) tslot -= T::NS;
+  const float* tb = reinterpret_cast<const float*>(smem + tslot * T::STAGE);
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
 
   // ---- LayerNorm statistics of the wave's rows: lane (fr, fg) holds a quarter of row fr's sums ----
   float mu[MT], rstd[MT];
@@ -241,21 +261,20 @@ __global__ __launch_bounds__(256, TW<D>::WG_PER_CU) void tattn_head_kernel(NrTAt
   }
 
   // ---- fold epilogue + attention per row tile (pixel); the three tensors as packed bf16 MFMA operands ----
-  const int nq0 = head * D + 4 * fg;             // q / k tiles: this lane's 4 channels of tile nt are nq0 + 16 nt + r
-  const int nv0 = 2 * C + head * D + fr;         // v tiles: this lane's channel of tile nt is nv0 + 16 nt, its 4 frames 4 fg + r
+  // table columns of this lane: q / k tiles nt -> part D + 16 nt + 4 fg .. + 3; v tile nt -> 2 D + 16 nt + fr (its 4 frames 4 fg + r)
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     s16x4 qa[DT], ka[DT], va[DT];
-    const float* rvq = p.rowvec + (size_t)fr * (3 * C);
+    const float* te = tb + (1 + fr) * (3 * D);
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
 #pragma unroll
       for (int nt = 0; nt < DT; ++nt) {
-        const int n = part * C + nq0 + 16 * nt;
-        const f32x4 c4 = *(const f32x4*)(p.lnc + n), b4 = *(const f32x4*)(p.bias + n), r4 = *(const f32x4*)(rvq + n);
+        const int col = part * D + 16 * nt + 4 * fg;
+        const f32x4 c4 = *(const f32x4*)(tb + col), e4 = *(const f32x4*)(te + col);
         f32x4 v = acc[part * DT + nt][mt];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (v[e] - mu[mt] * c4[e]) * rstd[mt] + b4[e] + r4[e];
+        for (int e = 0; e < 4; ++e) v[e] = (v[e] - mu[mt] * c4[e]) * rstd[mt] + e4[e];
         if (part == 0) qa[nt] = pack4(v); else ka[nt] = pack4(v);
       }
     }
@@ -264,11 +283,11 @@ __global__ __launch_bounds__(256, TW<D>::WG_PER_CU) void tattn_head_kernel(NrTAt
     for (int r = 0; r < 4; ++r) { muf[r] = __shfl(mu[mt], 4 * fg + r, 64); rsf[r] = __shfl(rstd[mt], 4 * fg + r, 64); }
 #pragma unroll
     for (int nt = 0; nt < DT; ++nt) {
-      const int n = nv0 + 16 * nt;
-      const float cs = p.lnc[n], bs = p.bias[n];
+      const int col = 2 * D + 16 * nt + fr;
+      const float cs = tb[col];
       f32x4 v = acc[2 * DT + nt][mt];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = (v[r] - muf[r] * cs) * rsf[r] + bs + p.rowvec[(size_t)(4 * fg + r) * (3 * C) + n];
+      for (int r = 0; r < 4; ++r) v[r] = (v[r] - muf[r] * cs) * rsf[r] + tb[(1 + 4 * fg + r) * (3 * D) + col];
       va[nt] = pack4(v);
     }
     // S^T[key 4 fg + r][query fr] = sum_c K[key][c] Q[query][c]
@@ -326,6 +345,24 @@ __global__ __launch_bounds__(256) void tattnw_stream_pack_kernel(const bf16* __r
   *(bf16x8*)(stream + (size_t)idx * 8) = v;
 }
 
+// epilogue table: per head [17][3 d] fp32 (row 0: c, row 1 + f: b' + pe[f] W^T) from the engine's LayerNorm-fold vectors (rows q | k | v of [3 C])
+template <int D>
+__global__ __launch_bounds__(256) void tattnw_table_pack_kernel(const float* __restrict__ lnc, const float* __restrict__ bias, const float* __restrict__ rowvec,
+                                                                float* __restrict__ table) {
+  using T = TW<D>;
+  constexpr int C = T::C, PER_HEAD = T::TBL_HEAD / 4;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= TW_HEADS * PER_HEAD) return;
+  const int head = idx / PER_HEAD, e = idx - head * PER_HEAD;
+  float v = 0.f;
+  if (e < 17 * 3 * D) {
+    const int row = e / (3 * D), j = e - row * (3 * D);
+    const int n = (j / D) * C + head * D + (j % D);
+    v = row == 0 ? lnc[n] : bias[n] + rowvec[(size_t)(row - 1) * (3 * C) + n];
+  }
+  table[idx] = v;
+}
+
 unsigned long long g_tw_attr = 0;
 
 }  // namespace
@@ -361,13 +398,23 @@ extern "C" int nr_launch_tattnw_stream_pack(const bf16* w_folded, int C, bf16* s
   return 0;
 }
 
-extern "C" int nr_launch_tattnw(const bf16* t, bf16* out, int nbatch, int hw, int C, const bf16* stream, const float* lnc, const float* bias,
-                                const float* rowvec, float ln_eps, hipStream_t s) {
+extern "C" size_t nr_tattnw_table_bytes(int C) { return C == 640 ? (size_t)TW_HEADS * TW<80>::TBL_HEAD : (C == 1280 ? (size_t)TW_HEADS * TW<160>::TBL_HEAD : 0); }
+
+extern "C" int nr_launch_tattnw_table_pack(const float* lnc, const float* bias, const float* rowvec, int C, float* table, hipStream_t s) {
+  const int total = (int)(nr_tattnw_table_bytes(C) / 4);
+  if (!total) return 1;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (C == 640) hipLaunchKernelGGL(tattnw_table_pack_kernel<80>, grid, dim3(256), 0, s, lnc, bias, rowvec, table);
+  else hipLaunchKernelGGL(tattnw_table_pack_kernel<160>, grid, dim3(256), 0, s, lnc, bias, rowvec, table);
+  return 0;
+}
+
+extern "C" int nr_launch_tattnw(const bf16* t, bf16* out, int nbatch, int hw, int C, const bf16* stream, const float* table, float ln_eps, hipStream_t s) {
   if (nbatch <= 0 || hw <= 0 || !nr_tattnw_stream_bytes(C)) return 1;
   const int pix_wg = C == 640 ? TW<80>::PIX_WG : TW<160>::PIX_WG;
   if (hw % pix_wg != 0) return 1;
   NrTAttnWParams p;
-  p.t = t; p.out = out; p.hw = hw; p.nbatch = nbatch; p.stream = stream; p.lnc = lnc; p.bias = bias; p.rowvec = rowvec; p.ln_eps = ln_eps;
+  p.t = t; p.out = out; p.hw = hw; p.nbatch = nbatch; p.stream = stream; p.table = table; p.ln_eps = ln_eps;
   const int d = C / TW_HEADS;
   p.scale_log2e = 1.4426950408889634f / sqrtf((float)d);
   const int npg = nbatch * (hw / pix_wg);
