@@ -293,6 +293,14 @@ nr_status nr_net_set_deterministic_batch(nr_net* h, int32_t enable);
  * off, do_classifier_free_guidance false: the batch holds one sample per clip).  Only read in deterministic-batch mode, where "the rows of
  * one clip" is what every plan choice is made for; the pipeline sets it per call.  Changing it in that mode invalidates the plan. */
 nr_status nr_net_set_clip_samples(nr_net* h, int32_t samples);
+/* Classifier-free-guidance de-duplication (U-Net handles; round 6).  With enable != 0 the caller PROMISES, for every forward until it is cleared,
+ * that the second half of the batch repeats the first: sample[b] == sample[b + B/2] and timestep[b] == timestep[b + B/2] -- what the reference's
+ * denoising loop feeds (`torch.cat([latents] * 2)` with one timestep, pipeline_neuroclips.py:435); only encoder_hidden_states differ.  The engine
+ * then evaluates everything in front of the first cross-attention (conv_in, down_blocks[0].resnets[0], norm / proj_in / norm1 / attn1 of
+ * down_blocks[0].attentions[0]: unet.py:395-400, attention.py:256-280) on B/2 samples and broadcasts: exact algebra, the same kernels on half the
+ * rows.  Ignored in deterministic-batch mode and with debug taps.  Default off: a caller that passes arbitrary batches (the plain
+ * nr_unet3d_forward contract) never sets it.  Changing it invalidates the plan. */
+nr_status nr_net_set_cfg_pair_identical(nr_net* h, int32_t enable);
 
 /* ---- converted-weight exchange between handles (multi-GPU start-up) -----------------
  * The reference shards clips over processes and every process loads the checkpoints itself (scripts/neuroclips_video.py:

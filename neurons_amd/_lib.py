@@ -98,6 +98,7 @@ SYMBOLS = {
     "nr_net_set_attention_fp8": (_I32, [_VP, _I32]),
     "nr_net_set_deterministic_batch": (_I32, [_VP, _I32]),
     "nr_net_set_clip_samples": (_I32, [_VP, _I32]),
+    "nr_net_set_cfg_pair_identical": (_I32, [_VP, _I32]),
     "nr_sparsectrl_set_condition_frames": (_I32, [_VP, C.POINTER(_I32), _I32]),
     "nr_net_set_debug": (_I32, [_VP, _I32]),
     "nr_net_num_taps": (_I32, [_VP]),

@@ -147,6 +147,9 @@ struct NrGemmParams {
   int tap_inner;       // 3x3, stride 1, single source: K walks (64-channel chunk, tap) with the TAP fastest; weights [N][Cin/64][9][64].
                        // The 9 re-reads of an activation row segment then fall into 9 consecutive k-tiles (L2 hits) instead of being
                        // spread over the whole K loop (tap-major order: the working set of the tiles in flight exceeds the 4 MiB L2)
+  int* sk_ctr;         // non-null: a split-K launch of this description reduces IN the launch (gemm.hip, l2red): one int per output tile, zero before
+                       // the first launch and left zero by every launch; owned by this launch description (concurrent streams never share one).
+                       // null: fp32 slabs + splitk_reduce_kernel.  Ask nr_igemm_splitk_l2_tiles() how many ints a description needs (0 = not eligible)
   const bf16* w_fm;    // non-null: the same weights in FRAGMENT-MAJOR order for smallm.hip: [N/16][K/32][64 lanes][8], lane (fr, fg) of block
                        // (T, ks) holds W[16 T + fr][32 ks + 8 fg .. + 7], so a wave's MFMA A-operand load is one contiguous KiB (nr_launch_smallm_w_pack)
 };
@@ -158,7 +161,7 @@ __device__ __forceinline__ NrGemmParams nr_pin_params(NrGemmParams p) {
   p.rowvec = nr_pin(p.rowvec); p.rowvec_div = nr_pin(p.rowvec_div); p.rowvec_mod = nr_pin(p.rowvec_mod); p.rowvec_ld = nr_pin(p.rowvec_ld);
   p.res = nr_pin(p.res); p.ldr = nr_pin(p.ldr); p.out = nr_pin(p.out); p.ldo = nr_pin(p.ldo); p.out_scale = nr_pin(p.out_scale);
   p.geglu = nr_pin(p.geglu); p.ln_c = nr_pin(p.ln_c); p.ln_eps = nr_pin(p.ln_eps); p.act = nr_pin(p.act); p.pad_tl0 = nr_pin(p.pad_tl0);
-  p.out_f32 = nr_pin(p.out_f32); p.tap_inner = nr_pin(p.tap_inner); p.w_fm = nr_pin(p.w_fm);
+  p.out_f32 = nr_pin(p.out_f32); p.tap_inner = nr_pin(p.tap_inner); p.w_fm = nr_pin(p.w_fm); p.sk_ctr = nr_pin(p.sk_ctr);
   return p;
 }
 

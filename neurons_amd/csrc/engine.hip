@@ -30,6 +30,7 @@
 extern "C" {
 int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStream_t stream);
 size_t nr_igemm_workspace_bytes(const NrGemmParams* pp);
+int nr_igemm_splitk_l2_tiles(const NrGemmParams* pp);
 int nr_gn_workspace_floats(int nimg, int hw, int groups, int* pix_per_blk_out, int* nchunk_out);
 int nr_launch_groupnorm(NrGnParams* pp, hipStream_t stream);
 int nr_launch_layernorm(const bf16* x, int ldx, bf16* out, int ldo, int M, int C, const float* gamma, const float* beta,
@@ -287,6 +288,7 @@ struct nr_net {
   // representative of the rest and are broadcast before motion_modules[0].  Exact (per-frame operators, identical inputs); < 0 = off.
   int n_cond_frames = -1;
   int cond_frames[64] = {0};
+  bool cfg_dup = false;          // nr_net_set_cfg_pair_identical: the caller promises sample[b] == sample[b + B2/2] and timestep[b] == timestep[b + B2/2]
   bool attn_fp8 = false;         // nr_net_set_attention_fp8: spatial / cross attention on e4m3 MFMA operands (config 5)
   IO io;
   int n_res = 0;
@@ -753,13 +755,20 @@ struct nr_net {
       const double bytes = 2.0 * (in_elems + (double)p.N * p.K + (double)p.M * outC + (o.res ? (double)p.M * outC : 0.0));
       char d[160];
       snprintf(d, sizeof(d), "igemm ks=%d s=%d ups=%d M=%d N=%d K=%d geglu=%d res=%d", ksize, stride, ups, p.M, p.N, p.K, p.geglu, o.res ? 1 : 0);
+      // in-launch split-K reduction (experiment NR_SPLITK_L2=1, gemm.hip l2red): one zeroed, self-cleaning counter per output tile, owned by
+      // this launch description for the lifetime of the plan (the two streams never share counters)
+      if (const int sk_tiles = nr_igemm_splitk_l2_tiles(&p)) {
+        Act ctr = new_act_persistent(1, 1, 1, 2 * ((sk_tiles + 3) & ~3));
+        ctx_persist.push_back(ctr);
+        if (!dry) { HIP_OK(hipMemset(ctr.ptr, 0, (size_t)sk_tiles * sizeof(int))); p.sk_ctr = reinterpret_cast<int*>(ctr.ptr); }
+      }
       // split-K slabs (small-M / huge-K layers): scratch with the lifetime of this launch
       const size_t wsb = nr_igemm_workspace_bytes(&p);
       float* ws = nullptr;
       std::shared_ptr<Buf> wsbuf;
       if (wsb) { wsbuf = new_tmp(wsb); ws = at<float>(wsbuf->off); }
       emit([p, ws](hipStream_t s) { LAUNCH_OK(nr_launch_igemm(&p, ws, s)); }, NR_PROF_IGEMM, 2.0 * p.M * (double)p.N * p.K, bytes, d);
-      if (wsb) last_op_launches(2);          // split-K: the igemm + its reduce kernel
+      if (wsb) last_op_launches(p.sk_ctr ? 1 : 2);          // split-K: the igemm + its reduce kernel (one launch with the in-launch reduction)
       op_tap(ksize == 3 ? "conv3" : (p.ln_c ? "lngemm" : "gemm"), out);
     }
     return out;
@@ -1025,10 +1034,35 @@ struct nr_net {
     return conv(t, &g, fw.w, C, 1, 1, 0, op);
   }
 
+  // Exact classifier-free-guidance de-duplication (U-Net only, cfg_dup): the pipeline feeds cat([latents] * 2) with ONE timestep
+  // (pipeline_neuroclips.py:435), so the two halves of the batch are identical until the first cross-attention reads the (different) text
+  // contexts: conv_in, down_blocks[0].resnets[0] and norm / proj_in / norm1 / attn1 of down_blocks[0].attentions[0] (attention.py:256-280) are
+  // evaluated on B2 / 2 samples and broadcast.  Not in deterministic-batch mode (its plan unit is the CFG pair) and not with debug taps.
+  bool cfg_dedup_active() const {
+    static const bool off = getenv("NR_CFG_DEDUP") && getenv("NR_CFG_DEDUP")[0] == '0';      // A/B switch
+    return !off && cfg_dup && cfg.kind == NR_KIND_UNET3D && B2 % 2 == 0 && B2 <= 64 && !det_batch && !keep_all && cfg.down_block_has_attn[0];
+  }
+  // [h; h]: the half-batch activation repeated for the second half of the batch (one gather launch)
+  Act expand_cfg(const Act& h) {
+    if (h.ld != h.C) throw NrError(NR_ERR_STATE, "expand_cfg: strided activation");
+    const int Bh = B2 / 2;
+    Act f = new_act(h.nimg * 2, h.H, h.W, h.C);
+    const long long fe = (long long)(h.nimg / Bh) * h.H * h.W * h.C;      // elements of one sample
+    const bf16* sp = h.ptr; bf16* dp = f.ptr; const int b2n = B2;
+    std::vector<int> mp(B2);
+    for (int i = 0; i < B2; ++i) mp[i] = i % Bh;
+    emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_frame_gather(sp, dp, 1, Bh, b2n, fe, mp.data(), s)); }, NR_PROF_OTHER, 0.0, 2.0 * 3.0 * (double)h.rows() * h.C,
+         "cfg broadcast rows=" + std::to_string(h.rows()) + " C=" + std::to_string(h.C));
+    return f;
+  }
+
   // Transformer3DModel.forward (attention.py:95-142) with one BasicTransformerBlock (:256-300); also sgm
   // SpatialTransformer.forward (sgm/modules/attention.py:702-723) with `depth` BasicTransformerBlocks (:551-572):
   // same arithmetic and parameter names (proj_in/out are nn.Linear there: same [C][C] matrix).
-  Act spatial_transformer(const Act& x, const Act& ctx_bf, const std::string& pre, int depth = 1) {
+  // cfg_half: x holds the first half of the batch only (cfg_dedup_active); t and x are broadcast behind the self-attention, the result is full-batch;
+  // *x_full receives the broadcast input (the caller's skip connection)
+  Act spatial_transformer(const Act& x_in, const Act& ctx_bf, const std::string& pre, int depth = 1, bool cfg_half = false, Act* x_full = nullptr) {
+    Act x = x_in;
     const int C = x.C;
     const int heads = cfg.num_head_channels > 0 ? C / cfg.num_head_channels : cfg.num_heads;
     Act hn = groupnorm(x, nullptr, pre + ".norm", 1e-6f, 0);
@@ -1043,6 +1077,11 @@ struct nr_net {
         qkv = Act();
         GemmOpt oo; oo.bias = w_f32(b + ".attn1.to_out.0.bias", C); oo.res = &t; oo.out = &t;
         linear(a, w_linear(b + ".attn1.to_out.0.weight", C, C), C, oo);
+      }
+      if (cfg_half && dd == 0) {      // from here on the two CFG halves differ (their text contexts do)
+        t = expand_cfg(t);
+        x = expand_cfg(x);
+        if (x_full) *x_full = x;
       }
       if (cfg.kind != NR_KIND_SGM_UNET && !attn_fp8 && t.ld == C && nr_xattn_fused_eligible(C, heads, ctx_len, x.H * x.W, det_rows(t.rows()))) {
         // C = 320, 8 heads, <= 80 context tokens, >= 4096 rows: the whole cross-attention block (LayerNorm, q projection, attention on the cached
@@ -1749,13 +1788,14 @@ struct nr_net {
     }
 
     // ---- conv_in ----
-    Act x = new_act(nimg, H, W, C0);
+    const bool cfg_half = cfg_dedup_active();      // conv_in .. attn1 of the first transformer on the first half of the batch only
+    Act x = new_act(cfg_half ? nimg / 2 : nimg, H, W, C0);
     if (cfg.kind == NR_KIND_UNET3D) {
       const float* wT = w_conv_in("conv_in.weight", C0, cfg.in_channels);
       const float* bi = w_f32("conv_in.bias", C0);
-      bf16* xp = x.ptr; const int ic = cfg.in_channels, b2n = B2, Fn = F, Hn = H, Wn = W;
+      bf16* xp = x.ptr; const int ic = cfg.in_channels, b2n = cfg_half ? B2 / 2 : B2, ni = x.nimg, Fn = F, Hn = H, Wn = W;
       emit([=, this](hipStream_t s) {
-        LAUNCH_OK(nr_launch_conv_in_small(io.sample, nullptr, ic, 0, b2n, nimg, Fn, Hn, Wn, wT, bi, nullptr, C0, xp, 1.f, 0.f, s));
+        LAUNCH_OK(nr_launch_conv_in_small(io.sample, nullptr, ic, 0, b2n, ni, Fn, Hn, Wn, wT, bi, nullptr, C0, xp, 1.f, 0.f, s));
       });
     } else {
       // sparse_controlnet.py:467-521: sample := 0 -> conv_in(0) = bias; + cond_embedding(cat[cond, mask])
@@ -1784,7 +1824,7 @@ struct nr_net {
 
     // ---- down blocks ----
     std::vector<Act> skips;
-    skips.push_back(x);
+    skips.push_back(cfg_half ? expand_cfg(x) : x);          // skip connections are full-batch (the ControlNet residuals added to them differ per half)
     // SparseCtrl identical-frame evaluation (see n_cond_frames): distinct frames = the conditioned ones + one representative of the rest
     int nd = 0, fmap_reduce[64], fmap_expand[64];
     if (cfg.kind == NR_KIND_SPARSECTRL && cfg.set_noisy_sample_input_to_zero && cfg.use_motion_module && n_cond_frames >= 0 && !keep_all && F <= 64) {
@@ -1836,7 +1876,7 @@ struct nr_net {
           continue;
         }
         x = resnet(x, nullptr, bp + ".resnets." + std::to_string(j), Cout);
-        if (cfg.down_block_has_attn[i]) x = spatial_transformer(x, ctx_bf, bp + ".attentions." + std::to_string(j));
+        if (cfg.down_block_has_attn[i]) x = spatial_transformer(x, ctx_bf, bp + ".attentions." + std::to_string(j), 1, cfg_half && i == 0 && j == 0);
         if (cfg.use_motion_module) x = temporal_module(x, bp + ".motion_modules." + std::to_string(j));
         skips.push_back(x);
       }
@@ -2413,6 +2453,13 @@ extern "C" nr_status nr_net_set_clip_samples(nr_net* h, int32_t samples) {
   NR_CATCH
 }
 
+extern "C" nr_status nr_net_set_cfg_pair_identical(nr_net* h, int32_t enable) {
+  NR_TRY
+  if (!h) throw NrError(NR_ERR_ARG, "null handle");
+  if (h->cfg_dup != (enable != 0)) { h->cfg_dup = enable != 0; h->planned = false; }
+  NR_CATCH
+}
+
 extern "C" nr_status nr_net_set_attention_fp8(nr_net* h, int32_t enable) {
   NR_TRY
   if (!h) throw NrError(NR_ERR_ARG, "null handle");
@@ -2835,9 +2882,16 @@ extern "C" nr_status nr_net_read_tap(nr_net* h, int32_t i, float* host_out, int6
 }
 
 // ---- single-op entry points ---------------------------------------------------------------------
-static float* op_workspace(const NrGemmParams& p) {
+static float* op_workspace(NrGemmParams& p) {
   static float* ws = nullptr;
   static size_t cap = 0;
+  static int* ctr = nullptr;                     // tile counters of the in-launch split-K reduction (NR_SPLITK_L2=1): zeroed once, self-cleaning
+  const int tiles = nr_igemm_splitk_l2_tiles(&p);
+  if (tiles > 0) {
+    if (tiles > 65536) throw NrError(NR_ERR_UNSUPPORTED, "op hook: too many split-K tiles");
+    if (!ctr) { HIP_OK(hipMalloc((void**)&ctr, 65536 * sizeof(int))); HIP_OK(hipMemset(ctr, 0, 65536 * sizeof(int))); }
+    p.sk_ctr = ctr;
+  }
   const size_t need = nr_igemm_workspace_bytes(&p);
   if (need > cap) {
     HIP_OK(hipDeviceSynchronize());

@@ -123,8 +123,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, (LNF && WGM * WGN == 8) ? 4 : 1) vo
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7, local = orig >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
   }
-  const int slice = splitk > 1 ? fdiv_small(bid, ntn * ntm) : 0;
-  bid -= slice * ntn * ntm;
+  // splitk < 0: |splitk| K-slices with the IN-LAUNCH reduction (round 6, experiment NR_SPLITK_L2=1): the slices of one output tile are
+  // consecutive logical ids, i.e. (the XCD ranges above being contiguous and a multiple of |splitk| long: the launcher checks) they run on ONE
+  // XCD, their fp32 slabs meet in that XCD's L2 and the last arriver sums them and runs the epilogue -- no second launch, no cache-wide fence
+  const bool l2red = splitk < 0;
+  if (l2red) splitk = -splitk;
+  int slice;
+  if (l2red) { const int t = fdiv_small(bid, splitk); slice = bid - t * splitk; bid = t; }
+  else { slice = splitk > 1 ? fdiv_small(bid, ntn * ntm) : 0; bid -= slice * ntn * ntm; }
+  const int tile_id = bid;
   // tile order inside an XCD's range: the operand that is re-used by neighbouring tiles should be the BIG
   // one.  m_fast: neighbours share a weight panel (weight-heavy 4x4 / 8x8 levels); else an activation panel.
   int bm, bn;
@@ -451,7 +458,41 @@ __global__ __launch_bounds__(64 * WGM * WGN, (LNF && WGM * WGN == 8) ? 4 : 1) vo
         nr_store16f(slab + (size_t)m * p.N + n, acc[i][j]);
       }
     }
-    return;
+    if (!l2red) return;
+    // ---- in-launch reduction.  Every thread's slab stores are complete (acknowledged by the L2: the vector L1 is write-through) before the
+    // workgroup's arrival is counted; the counter lives in the XCD's L2 (workgroup-scope atomic: executed there, not at the memory side), and so
+    // do the sibling slabs the last arriver then reads (first touch by this CU in this launch: its L1, invalidated at kernel start, cannot hold
+    // them).  Slices are summed in slice order whoever arrives last: bit-identical to splitk_reduce_kernel. ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* ctr = p.sk_ctr + tile_id;
+    int* flag = reinterpret_cast<int*>(smem);
+    if (tid == 0) {
+      const int old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const int last = old == splitk - 1;
+      if (last) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // self-cleaning: the next launch finds zeros
+      *flag = last;
+    }
+    __syncthreads();
+    const int last = *flag;
+    __syncthreads();                       // (the staged epilogue below re-uses the LDS)
+    if (!last) return;
+    asm volatile("" ::: "memory");
+    const size_t slab_elems = (size_t)p.M * p.N;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int m = m0 + wm * WM + j * 16 + fr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int n = n0 + wn * WN + i * 16 + 4 * fg;
+        if (n >= p.N) continue;
+        const float* src = partial + (size_t)m * p.N + n;
+        f32x4 v = *(const f32x4*)src;
+        for (int sl = 1; sl < splitk; ++sl) v += *(const f32x4*)(src + sl * slab_elems);
+        acc[i][j] = v;
+      }
+    }
   }
   // Staged epilogue (whenever the fp32 C tile fits in the LDS ring): accumulators -> LDS (16-byte chunks
   // XOR-swizzled with row&7: conflict-free both ways) -> each thread handles 8 consecutive output channels of one
@@ -738,7 +779,7 @@ int launch_cfg(const NrGemmParams& p, unsigned grid, int splitk, float* partial,
     (void)hipFuncSetAttribute((const void*)igemm_bf16_kernel<BM, BN, NS, WGM, WGN, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
   }
   static const int adma_min = getenv("NR_IGEMM_ADMA_MINK") ? atoi(getenv("NR_IGEMM_ADMA_MINK")) : 24;   // k-tiles per slice; A/B switch
-  const int nk_slice = (p.K / 64) / (splitk > 0 ? splitk : 1);
+  const int nk_slice = (p.K / 64) / (splitk > 0 ? splitk : (splitk < 0 ? -splitk : 1));
   // plain Linears (1x1, one source) on the instantiation without the conv paths (rings up to 4 deep: the ones Linears are planned with)
   static const bool lin_on = !(getenv("NR_IGEMM_LIN") && getenv("NR_IGEMM_LIN")[0] == '0');            // A/B switch
   if constexpr (NS <= 4) {
@@ -840,6 +881,19 @@ extern "C" size_t nr_igemm_workspace_bytes(const NrGemmParams* pp) {
   return pl.splitk > 1 ? (size_t)pl.splitk * pp->M * pp->N * sizeof(float) : 0;
 }
 
+// Tile counters an in-launch split-K reduction of this description needs (NrGemmParams::sk_ctr), 0 when the launch is not a split-K launch of
+// the tiled igemm, its tile count is not a multiple of 8 (whole tiles per XCD), or the experiment is off (NR_SPLITK_L2=1 turns it on)
+extern "C" int nr_igemm_splitk_l2_tiles(const NrGemmParams* pp) {
+  static const bool on = getenv("NR_SPLITK_L2") && getenv("NR_SPLITK_L2")[0] == '1';
+  if (!on || nr_igemm_workspace_bytes(pp) == 0 || pp->out_f32) return 0;
+  Plan pl = choose_plan(plan_view(*pp));
+  int mf = 0;
+  apply_override(*pp, pl, mf);
+  if (pl.splitk <= 1) return 0;
+  const int tiles = ((pp->M + pl.bm - 1) / pl.bm) * ((pp->N + pl.bn - 1) / pl.bn);
+  return tiles % 8 == 0 ? tiles : 0;
+}
+
 // Host launcher.  Returns 0 on success, nonzero on unsupported shape.  `workspace` must hold
 // nr_igemm_workspace_bytes() bytes when that is nonzero.
 extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStream_t stream) {
@@ -928,6 +982,10 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
   if (pl.splitk > 1 && !workspace) return 6;
   float* partial = p.out_f32 ? p.out_f32 : (pl.splitk > 1 ? workspace : nullptr);
   const unsigned grid = (unsigned)(((p.M + pl.bm - 1) / pl.bm) * ((p.N + pl.bn - 1) / pl.bn) * pl.splitk);
+  // in-launch split-K reduction (the caller provided tile counters): all slices of a tile on one XCD needs whole tiles per XCD range
+  const int sk_slices = pl.splitk;
+  const bool l2red = pl.splitk > 1 && p.sk_ctr && !p.out_f32 && (grid / pl.splitk) % 8 == 0;
+  if (l2red) pl.splitk = -pl.splitk;
   int rc;
   if (pl.bm == 256 && pl.bn == 160) rc = launch_tile<256, 160, 2, 2>(p, grid, pl, partial, m_fast, stream);
   else if (pl.bm == 256 && pl.waves == 4) rc = launch_tile<256, 128, 2, 2>(p, grid, pl, partial, m_fast, stream);
@@ -945,6 +1003,7 @@ extern "C" int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStre
   else if (pl.bm == 64 && pl.bn == 64) rc = launch_tile<64, 64, 2, 2>(p, grid, pl, partial, m_fast, stream);
   else rc = 9;            // no such tile: never launch another one on a grid computed for this one
   if (rc) return rc;      // no instantiation for this (tile, LayerNorm-fused) request: fail loudly, never skip the launch
+  (void)sk_slices;
   if (pl.splitk > 1) {
     const long long total = (long long)p.M * (p.N / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p, pl.splitk,

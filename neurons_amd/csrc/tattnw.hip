@@ -96,6 +96,12 @@ template <int D> struct TW {
   static constexpr int PPW = W_PIECES + A_PIECES;             // DMA pieces per wave and stage: 6 / 9
   static constexpr int PPS = 2;                               // pieces issued behind each MFMA group (NG groups per stage: 6 / 10 slots)
   static constexpr int WG_PER_CU = D == 80 ? 2 : 1;
+  // d = 160 has exactly one workgroup per CU at the headline shape (256 = 32 pixel groups x 8 heads), i.e. one wave per SIMD, and that wave spent
+  // 1 170 cycles per stage issuing 9 DMA pieces + 31 fragment reads around 480 cycles of MFMA (profiles/r06_tattnw_timeline_v3.txt).  So the
+  // workgroup gets four PRODUCER waves (4-7, one per SIMD beside a consumer): they issue every DMA piece and nothing else, the consumer waves
+  // (0-3) only read fragments and issue MFMAs.  At d = 80 two workgroups share a CU and overlap each other instead.
+  static constexpr bool SPLIT = D == 160;
+  static constexpr int THREADS = SPLIT ? 512 : 256;
   static constexpr int TBL_HEAD = D == 80 ? 16 * 1024 : 32 * 1024;   // epilogue table of one head: 17 x 3 d floats (16 320 / 32 640 B) padded to whole pieces
   static constexpr int TBL_PIECES = TBL_HEAD / 4096;          // per wave: 4 / 8
   static_assert(17 * 3 * D * 4 <= TBL_HEAD && TBL_HEAD <= STAGE, "the epilogue table lands in one free ring slot");
@@ -115,14 +121,16 @@ struct NrTAttnWParams {
 };
 
 template <int D>
-__global__ __launch_bounds__(256, TW<D>::WG_PER_CU) void tattn_head_kernel(NrTAttnWParams p) {
+__global__ __launch_bounds__(TW<D>::THREADS, TW<D>::WG_PER_CU) void tattn_head_kernel(NrTAttnWParams p) {
   using T = TW<D>;
   constexpr int C = T::C, DT = T::DT, MT = T::MT, NT = T::NT, GS = T::GS, NG = T::NG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // T::NS slots of T::STAGE bytes: [weights | rows]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = T::SPLIT && wave_id >= 4;       // DMA-only wave (d = 160); it serves the rows / pieces of consumer wave_id - 4
+  const int wave = wave_id & 3;
   const int fr = lane & 15, fg = lane >> 4;
 
   TW_STAMP(0);
@@ -158,10 +166,37 @@ __global__ __launch_bounds__(256, TW<D>::WG_PER_CU) void tattn_head_kernel(NrTAt
   };
   const char* tsrc = reinterpret_cast<const char*>(p.table) + (size_t)head * T::TBL_HEAD + (size_t)(wave * T::TBL_PIECES) * 1024 + (size_t)lane * 16;
   // prologue: stages 0 .. NS - 2
+  if (!T::SPLIT || producer) {
 #pragma unroll
-  for (int s = 0; s < T::NS - 1; ++s)
+    for (int s = 0; s < T::NS - 1; ++s)
 #pragma unroll
-    for (int i = 0; i < T::PPW; ++i) issue_piece(s, s, i);
+      for (int i = 0; i < T::PPW; ++i) issue_piece(s, s, i);
+  }
+  if constexpr (T::SPLIT) {
+    if (producer) {
+      // ---- producer wave: per stage wait for its pieces of stage s, meet the consumers at the barrier, refill the slot they just left ----
+      int pslot = T::NS - 1;
+      for (int s = 0; s < T::S; ++s) {
+        const int rem = T::S - 1 - s;
+        if (rem >= T::NS - 2) wait_vmcnt<(T::NS - 2) * T::PPW>();
+        else if (rem == 1) wait_vmcnt<T::PPW>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        const int s_next = s + T::NS - 1;
+        if (s_next < T::S) {
+#pragma unroll
+          for (int i = 0; i < T::PPW; ++i) issue_piece(s_next, pslot, i);
+        } else if (s == T::S - 1) {           // the head's epilogue table into the slot stage S - 2 just left
+#pragma unroll
+          for (int i = 0; i < T::TBL_PIECES; ++i) glds16(tsrc + (size_t)i * 1024, lds0 + (unsigned)(pslot * T::STAGE + (wave * T::TBL_PIECES + i) * 1024));
+        }
+        pslot = pslot + 1 == T::NS ? 0 : pslot + 1;
+      }
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();           // the table is in LDS: the consumers' epilogue may read it
+      return;
+    }
+  }
 
   TW_STAMP(1);
   f32x4 acc[NT][MT];
@@ -182,15 +217,17 @@ __global__ __launch_bounds__(256, TW<D>::WG_PER_CU) void tattn_head_kernel(NrTAt
   for (int s = 0; s < T::S; ++s) {
     // this wave's pieces of stage s have landed when at most the pieces of the stages issued after it are outstanding
     // (issued so far: stages <= min(s + NS - 2, S - 1); allowed in flight: min(NS - 2, S - 1 - s) stages of PPW pieces)
-    const int rem = T::S - 1 - s;
-    if (rem >= T::NS - 2) wait_vmcnt<(T::NS - 2) * T::PPW>();
-    else if (rem == 1) wait_vmcnt<T::PPW>();
-    else wait_vmcnt<0>();
+    if constexpr (!T::SPLIT) {
+      const int rem = T::S - 1 - s;
+      if (rem >= T::NS - 2) wait_vmcnt<(T::NS - 2) * T::PPW>();
+      else if (rem == 1) wait_vmcnt<T::PPW>();
+      else wait_vmcnt<0>();
+    }
     TW_STAMP(2 + 3 * s);
     __builtin_amdgcn_s_barrier();             // every wave's pieces landed; every wave has left stage s - 1 (its slot may be refilled)
     TW_STAMP(3 + 3 * s);
     const int s_next = s + T::NS - 1;
-    const bool pf = s_next < T::S;
+    const bool pf = !T::SPLIT && s_next < T::S;
     int pslot = slot + T::NS - 1; if (pslot >= T::NS) pslot -= T::NS;
     const unsigned char* base = smem + slot * T::STAGE;
     bf16x8 xa[MT];
@@ -222,7 +259,7 @@ __global__ __launch_bounds__(256, TW<D>::WG_PER_CU) void tattn_head_kernel(NrTAt
           const int i = g * T::PPS + q;
           if (i < T::PPW) issue_piece(s_next, pslot, i);
         }
-      } else if (s == T::S - 1) {             // last stage: the head's epilogue table into the slot stage S - 2 just left
+      } else if (!T::SPLIT && s == T::S - 1) {             // last stage: the head's epilogue table into the slot stage S - 2 just left
 #pragma unroll
         for (int q = 0; q < T::PPS; ++q) {
           const int i = g * T::PPS + q;
@@ -428,7 +465,7 @@ extern "C" int nr_launch_tattnw(const bf16* t, bf16* out, int nbatch, int hw, in
     g_tw_attr |= 1ull << (dev & 63);
   }
   const unsigned grid = (unsigned)(npg * TW_HEADS);
-  if (C == 640) hipLaunchKernelGGL(tattn_head_kernel<80>, dim3(grid), dim3(256), shm, s, p);
-  else hipLaunchKernelGGL(tattn_head_kernel<160>, dim3(grid), dim3(256), shm, s, p);
+  if (C == 640) hipLaunchKernelGGL(tattn_head_kernel<80>, dim3(grid), dim3(TW<80>::THREADS), shm, s, p);
+  else hipLaunchKernelGGL(tattn_head_kernel<160>, dim3(grid), dim3(TW<160>::THREADS), shm, s, p);
   return 0;
 }

@@ -353,6 +353,10 @@ class NeuroclipsPipeline:
                 groups, plan = controlnet_group_plan(list(timesteps_host), G)
                 ctx_group = text_embeddings.repeat(G, 1, 1)
                 launch_group(0)
+            # the loop below builds the U-Net input as cat([latents] * 2) with one timestep (:435): the native U-Net may evaluate what precedes
+            # the first cross-attention once per pair (exact; nr_net_set_cfg_pair_identical).  Own scheduler only: its scale_model_input is the
+            # identity, a foreign one is not known to treat the two halves alike
+            cfg_pair = bool(do_classifier_free_guidance and own_scheduler)
             for i, t in enumerate(timesteps_host):
                 latent_model_input = torch.cat([latents] * 2) if do_classifier_free_guidance else latents
                 latent_model_input = self.scheduler.scale_model_input(latent_model_input, t if own_scheduler else timesteps[i])
@@ -363,14 +367,14 @@ class NeuroclipsPipeline:
                         launch_group(launch)         # runs beside this group's U-Net steps; its buffers were last read in step i - 1
                         pending.pop(g - 1, None)
                     noise_pred = self.unet.forward_after(self.controlnet, groups[g]["slot"], pending[g], p_ * b2, latent_model_input, t,
-                                                         text_embeddings).sample
+                                                         text_embeddings, cfg_pair_identical=cfg_pair).sample
                 elif fused:
                     # same two network evaluations (:460-475), issued as one library call that overlaps them
                     # the next step's SparseCtrl evaluation (independent of the latents) is issued early
                     t_next = timesteps_host[i + 1] if (i + 1 < len(timesteps_host) and self.prefetch_controlnet) else None
                     noise_pred = self.unet.forward_with_controlnet(
                         self.controlnet, latent_model_input, t, text_embeddings, controlnet_cond,
-                        controlnet_conditioning_mask, controlnet_conditioning_scale, next_timestep=t_next).sample
+                        controlnet_conditioning_mask, controlnet_conditioning_scale, next_timestep=t_next, cfg_pair_identical=cfg_pair).sample
                 elif use_ctrl:
                     zc = {"zero_copy": True} if hasattr(self.controlnet, "_out_bufs") else {}    # consumed before the next call
                     down_res, mid_res = self.controlnet(

@@ -420,6 +420,16 @@ class _NativeNet:
             self._plan_key = None
         return self
 
+    def _set_cfg_pair_identical(self, flag):
+        """``nr_net_set_cfg_pair_identical``: the next forwards' batches are [x; x] with one timestep (the denoising loop's CFG input), so the engine may
+        evaluate the layers in front of the first cross-attention on half the batch.  Set by the pipeline-only entry points
+        (``forward_with_controlnet`` / ``forward_after`` with ``cfg_pair_identical=True``), cleared by every plain ``forward``."""
+        flag = bool(flag)
+        if getattr(self, "_cfg_dup", False) != flag:
+            _lib.check(_lib.load().nr_net_set_cfg_pair_identical(self._handle(), 1 if flag else 0))
+            self._cfg_dup = flag
+            self._plan_key = None
+
     def state_dict_keys(self):
         return list(self._schema.keys())
 
@@ -523,6 +533,12 @@ class _NativeNet:
         self._plan_key = None
 
     @_on_device
+    def op_descriptions(self):
+        """One line per launch of the current plan ("igemm ks=... M=...", "tattn_head M=...", "cfg broadcast ..."; ``nr_net_op_desc``): tests assert
+        WHICH kernel serves a layer."""
+        lib = _lib.load()
+        return [lib.nr_net_op_desc(self._h, i).decode() for i in range(lib.nr_net_num_ops(self._h))]
+
     def profile_last(self):
         """Per-kernel-class time / algorithmic work of the most recent forward (HIP events per launch)."""
         prof = _lib.NrProfile()
@@ -632,6 +648,7 @@ class NativeUNet3D(_NativeNet):
         ctx = encoder_hidden_states
         if ctx.shape[0] != b or ctx.shape[2] != self.config.cross_attention_dim:
             raise ValueError(f"encoder_hidden_states shape {tuple(ctx.shape)} does not match batch {b} / cross_attention_dim")
+        self._set_cfg_pair_identical(False)        # arbitrary batches: nothing is assumed about the two halves
         self._ensure_plan(b, f, h, w, ctx.shape[1])
         lib = _lib.load()
         # fixed I/O staging buffers: stable pointers let the engine replay one captured hipGraph
@@ -665,7 +682,7 @@ class NativeUNet3D(_NativeNet):
 
     @_on_device
     def forward_with_controlnet(self, controlnet, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_mask,
-                                conditioning_scale: float = 1.0, next_timestep=None):
+                                conditioning_scale: float = 1.0, next_timestep=None, cfg_pair_identical: bool = False):
         """``controlnet(...)`` then ``self(..., down_block_additional_residuals=..., mid_block_additional_residual=...)``
         (pipeline_neuroclips.py:460-475) as ONE library call that overlaps SparseCtrl with the U-Net encoder
         (C ABI ``nr_denoise_step_forward``).  Returns the same ``.sample`` tensor as the two separate calls.
@@ -684,6 +701,7 @@ class NativeUNet3D(_NativeNet):
         if controlnet.device.type == "cuda" and controlnet.device != self.device:
             raise RuntimeError(f"U-Net on {self.device} but SparseCtrl on {controlnet.device}")
         controlnet.to(self.device)
+        self._set_cfg_pair_identical(cfg_pair_identical and b % 2 == 0 and not torch.is_tensor(timestep))
         self._ensure_plan(b, f, h, w, L)
         controlnet._sync_condition_frames(controlnet_cond, conditioning_mask)
         controlnet._ensure_plan(b, f, h, w, L)
@@ -714,7 +732,7 @@ class NativeUNet3D(_NativeNet):
         return UNet3DConditionOutput(sample=self._io_out.clone())
 
     @_on_device
-    def forward_after(self, controlnet, slot, residual_bufs, sample_index, sample, timestep, encoder_hidden_states):
+    def forward_after(self, controlnet, slot, residual_bufs, sample_index, sample, timestep, encoder_hidden_states, cfg_pair_identical: bool = False):
         """U-Net evaluation that consumes samples ``[sample_index, sample_index + b)`` of the SparseCtrl evaluation pending in ``slot``
         (``NativeSparseCtrl.forward_async``): C ABI ``nr_unet3d_forward_after``.  The encoder overlaps the pending evaluation; the
         residual adds wait for it."""
@@ -725,6 +743,8 @@ class NativeUNet3D(_NativeNet):
         if ctx.shape[0] != b:
             raise ValueError("encoder_hidden_states batch must equal the sample batch")
         L = ctx.shape[1]
+        # cfg_pair_identical: the caller built `sample` as cat([x] * 2) and passes ONE scalar timestep (the denoising loop): CFG de-duplication
+        self._set_cfg_pair_identical(cfg_pair_identical and b % 2 == 0 and not torch.is_tensor(timestep))
         self._ensure_plan(b, f, h, w, L)
         self._io_sample.copy_(sample)
         self._set_context(ctx)
