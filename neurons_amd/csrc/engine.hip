@@ -87,7 +87,7 @@ int nr_launch_tattn_fused(bf16* t, int nbatch, int frames, int hw, const bf16* s
                           int norot, hipStream_t s);
 // tattnw.hip: q|k|v projection of one head + F x F attention per (pixel group, head) above the C = 320 level (C = 640 / 1280, F = 16)
 size_t nr_tattnw_stream_bytes(int C);
-int nr_tattnw_eligible(int C, int heads, int frames, int hw);
+int nr_tattnw_eligible(int C, int heads, int frames, int hw, long long rows);
 int nr_launch_tattnw_stream_pack(const bf16* w_folded, int C, bf16* stream, hipStream_t s);
 size_t nr_tattnw_table_bytes(int C);
 int nr_launch_tattnw_table_pack(const float* lnc, const float* bias, const float* rowvec, int C, float* table, hipStream_t s);
@@ -1214,7 +1214,7 @@ struct nr_net {
         continue;
       }
       Act a;
-      if (nr_tattnw_eligible(C, heads, F, x.H * x.W) && t.ld == C) {
+      if (nr_tattnw_eligible(C, heads, F, x.H * x.W, det_rows(t.rows())) && t.ld == C) {
         // C = 640 / 1280, F = 16: LayerNorm + PE (folded), the q|k|v projection of one head and its 16 x 16 attention per (pixel group, head) in
         // ONE launch (tattnw.hip); q|k|v never reach HBM.  to_out + residual stays the GEMM below.
         const std::string nrm = b + ".norms." + std::to_string(k);

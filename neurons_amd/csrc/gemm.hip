@@ -126,12 +126,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, (LNF && WGM * WGN == 8) ? 4 : 1) vo
   // splitk < 0: |splitk| K-slices with the IN-LAUNCH reduction (round 6, experiment NR_SPLITK_L2=1): the slices of one output tile are
   // consecutive logical ids, i.e. (the XCD ranges above being contiguous and a multiple of |splitk| long: the launcher checks) they run on ONE
   // XCD, their fp32 slabs meet in that XCD's L2 and the last arriver sums them and runs the epilogue -- no second launch, no cache-wide fence
+  // MEASURED SLOWER (0.43-1.00 x, profiles/r06_splitk_xcd_ab.txt: the last arriver reads its tile's slabs alone): experiments library only.
+#ifdef NR_EXPERIMENTS
   const bool l2red = splitk < 0;
   if (l2red) splitk = -splitk;
   int slice;
   if (l2red) { const int t = fdiv_small(bid, splitk); slice = bid - t * splitk; bid = t; }
   else { slice = splitk > 1 ? fdiv_small(bid, ntn * ntm) : 0; bid -= slice * ntn * ntm; }
   const int tile_id = bid;
+#else
+  const int slice = splitk > 1 ? fdiv_small(bid, ntn * ntm) : 0;
+  bid -= slice * ntn * ntm;
+#endif
   // tile order inside an XCD's range: the operand that is re-used by neighbouring tiles should be the BIG
   // one.  m_fast: neighbours share a weight panel (weight-heavy 4x4 / 8x8 levels); else an activation panel.
   int bm, bn;
@@ -458,6 +464,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, (LNF && WGM * WGN == 8) ? 4 : 1) vo
         nr_store16f(slab + (size_t)m * p.N + n, acc[i][j]);
       }
     }
+#ifndef NR_EXPERIMENTS
+    return;
+#else
     if (!l2red) return;
     // ---- in-launch reduction.  Every thread's slab stores are complete (acknowledged by the L2: the vector L1 is write-through) before the
     // workgroup's arrival is counted; the counter lives in the XCD's L2 (workgroup-scope atomic: executed there, not at the memory side), and so
@@ -493,6 +502,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (LNF && WGM * WGN == 8) ? 4 : 1) vo
         acc[i][j] = v;
       }
     }
+#endif
   }
   // Staged epilogue (whenever the fp32 C tile fits in the LDS ring): accumulators -> LDS (16-byte chunks
   // XOR-swizzled with row&7: conflict-free both ways) -> each thread handles 8 consecutive output channels of one
@@ -882,8 +892,12 @@ extern "C" size_t nr_igemm_workspace_bytes(const NrGemmParams* pp) {
 }
 
 // Tile counters an in-launch split-K reduction of this description needs (NrGemmParams::sk_ctr), 0 when the launch is not a split-K launch of
-// the tiled igemm, its tile count is not a multiple of 8 (whole tiles per XCD), or the experiment is off (NR_SPLITK_L2=1 turns it on)
+// the tiled igemm, its tile count is not a multiple of 8 (whole tiles per XCD), or the experiment is off (experiments library + NR_SPLITK_L2=1)
 extern "C" int nr_igemm_splitk_l2_tiles(const NrGemmParams* pp) {
+#ifndef NR_EXPERIMENTS
+  (void)pp;
+  return 0;             // product library: slabs + splitk_reduce_kernel (the in-launch form lost its A/B)
+#endif
   static const bool on = getenv("NR_SPLITK_L2") && getenv("NR_SPLITK_L2")[0] == '1';
   if (!on || nr_igemm_workspace_bytes(pp) == 0 || pp->out_f32) return 0;
   Plan pl = choose_plan(plan_view(*pp));

@@ -418,11 +418,13 @@ extern "C" size_t nr_tattnw_stream_bytes(int C) {
   return C == 640 ? (size_t)TW_HEADS * TW<80>::S * TW<80>::W_STAGE : (C == 1280 ? (size_t)TW_HEADS * TW<160>::S * TW<160>::W_STAGE : 0);
 }
 
-extern "C" int nr_tattnw_eligible(int C, int heads, int frames, int hw) {
+// rows: the launch's row count (deterministic-batch mode: one clip's).  At C = 1280 a launch needs >= 2048 rows: with 512 (the 4 x 4 level at one
+// clip) only 64 workgroups exist, each streaming a head's 1.2 MB alone: 34 us against 27 us for the q|k|v GEMM + attention core (profiles/r06_tattn_head_ab.txt)
+extern "C" int nr_tattnw_eligible(int C, int heads, int frames, int hw, long long rows) {
   static const bool off = getenv("NR_TATTN_HEAD") && getenv("NR_TATTN_HEAD")[0] == '0';   // A/B switch
   if (off || heads != TW_HEADS || frames != TW_F) return 0;
   if (C == 640) return hw % TW<80>::PIX_WG == 0;
-  if (C == 1280) return hw % TW<160>::PIX_WG == 0;
+  if (C == 1280) return hw % TW<160>::PIX_WG == 0 && rows >= 2048;
   return 0;
 }
 

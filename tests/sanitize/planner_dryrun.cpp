@@ -243,6 +243,46 @@ int main(int argc, char** argv) {
     CHECK(bytes_reloaded == bytes_on, "reload must rebuild exactly the dropped copies");
     printf("fragment-major copies: %lld bytes on top of %lld\n", bytes_on - bytes_off, bytes_off);
   }
+  // ---------------- C = 640 temporal module, 16 frames: the attention head kernel's planner logic (tattnw.hip, round 6): the fragment-major weight
+  // stream and the epilogue table are built once, the LayerNorm-folded [3C][C] matrix that feeds the stream is dropped again, a reloaded to_q
+  // drops stream + table + fold vectors, the next plan rebuilds exactly them, nothing leaks; F = 8 (not eligible) plans the three-launch sequence ----------------
+  if (nets.count("leaf_temporal640")) {
+    const Net& n = nets.at("leaf_temporal640");
+    nr_net* h = nullptr;
+    OK(nr_net_create(&n.cfg, &h));
+    load_all(h, n, 13);
+    OK(nr_net_plan(h, 1, 16, 8, 8, 0));
+    OK(nr_leaf_forward(h, nullptr, sample, nullptr, 0, out));
+    int heads = 0, cores = 0;
+    for (int i = 0; i < nr_net_num_ops(h); ++i) {
+      heads += strstr(nr_net_op_desc(h, i), "tattn_head M=1024 C=640") != nullptr;
+      cores += strstr(nr_net_op_desc(h, i), "attention mode=2") != nullptr;
+    }
+    CHECK(heads == 2 && cores == 0, "C = 640, F = 16 must plan one tattn_head launch per attention block");
+    const long long bytes_first = nr_net_weight_bytes(h);
+    const long live_before = nr_stub_live_allocs();
+    for (auto& t : n.tensors)
+      if (t.first.find("attention_blocks.0.to_q.weight") != std::string::npos) {
+        int64_t numel = 1;
+        for (auto d : t.second) numel *= d;
+        std::vector<float> data((size_t)numel, 0.02f);
+        OK(nr_net_load_tensor(h, t.first.c_str(), data.data(), t.second.data(), (int32_t)t.second.size()));
+      }
+    CHECK(nr_net_weight_bytes(h) < bytes_first, "a reloaded to_q must drop the stream / table / fold vectors built from it");
+    CHECK(nr_leaf_forward(h, nullptr, sample, nullptr, 0, out) == NR_ERR_STATE, "forward after a reload must ask for a new plan");
+    OK(nr_net_plan(h, 1, 16, 8, 8, 0));
+    OK(nr_leaf_forward(h, nullptr, sample, nullptr, 0, out));
+    CHECK(nr_net_weight_bytes(h) == bytes_first, "re-plan must rebuild exactly the dropped conversions");
+    CHECK(nr_stub_live_allocs() == live_before, "reload + re-plan must not leak converted weights");
+    OK(nr_net_plan(h, 1, 8, 8, 8, 0));                                // 8 frames: q|k|v GEMM + attention core + to_out (needs the folded matrix again)
+    OK(nr_leaf_forward(h, nullptr, sample, nullptr, 0, out));
+    cores = 0;
+    for (int i = 0; i < nr_net_num_ops(h); ++i) cores += strstr(nr_net_op_desc(h, i), "attention mode=2") != nullptr;
+    CHECK(cores == 2, "F = 8 is not eligible for the head kernel");
+    OK(nr_net_plan(h, 1, 16, 8, 8, 0));                               // and back: stream and table are still cached
+    OK(nr_leaf_forward(h, nullptr, sample, nullptr, 0, out));
+    nr_net_destroy(h);
+  }
   // ---------------- the other kinds: sgm U-Net, VAE decoder / encoder, CLIP ----------------
   if (nets.count("tiny_sgm")) {
     const Net& n = nets.at("tiny_sgm");

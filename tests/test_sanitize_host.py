@@ -37,7 +37,8 @@ def _write_schema(path):
     nets.append(("tiny_ctrl", make_c_config(ccfg, _lib.NR_KIND_SPARSECTRL), state_dict_schema(ccfg, _lib.NR_KIND_SPARSECTRL)))
     for name, kind, keys, width in (("leaf_temporal", _lib.NR_KIND_LEAF_TEMPORAL, _motion_keys("m", 320, 2), 320),
                                     ("leaf_transformer", _lib.NR_KIND_LEAF_TRANSFORMER3D, _transformer_keys("m", 320, 768), 320),
-                                    ("leaf_transformer640", _lib.NR_KIND_LEAF_TRANSFORMER3D, _transformer_keys("m", 640, 768), 640)):
+                                    ("leaf_transformer640", _lib.NR_KIND_LEAF_TRANSFORMER3D, _transformer_keys("m", 640, 768), 640),
+                                    ("leaf_temporal640", _lib.NR_KIND_LEAF_TEMPORAL, _motion_keys("m", 640, 2), 640)):
         c = _lib.NrNetConfig()
         c.kind = kind
         c.in_channels = c.out_channels = width

@@ -43,6 +43,7 @@ def run(kind, x, w, bias, res, ops):
 
 def arm(which, out_path):
     os.environ["NR_SPLITK_L2"] = which
+    os.environ.setdefault("NR_LIB_VARIANT", "exp")          # the in-launch form lives in the experiments library only (make -C neurons_amd/csrc experiments)
     import torch
     from neurons_amd import ops
     dev = torch.device("cuda", 0)
