@@ -35,7 +35,7 @@ def load(d, counter):
             e[0] += v
             e[1] += 1
             if ("igemm_bf16_kernel" in name or "splitk_reduce" in name or "rowpanel_kernel" in name or "ff_fused_kernel" in name
-                    or "tattn_fused_kernel" in name or "g8p_kernel" in name or "smallm_kernel" in name or "xattn_fused_kernel" in name):
+                    or "tattn_fused_kernel" in name or "tattn_head_kernel" in name or "g8p_kernel" in name or "smallm_kernel" in name or "xattn_fused_kernel" in name):
                 ig += v
                 n_ig += 1
     return tot, ig, n_ig
@@ -48,7 +48,7 @@ w_tot, w_ig, _ = load(write_dir, "WRITE_SIZE")
 res = {
     "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --steps 1 --warmup 0 --ddim-steps N "
             f"--no-cpu-baseline: {forwards:g} forwards of each network; FETCH_SIZE doubled per MI355X_MICROARCH.md; units KB*1024; "
-            "library kernels only (setup-time weight conversion and torch kernels excluded); igemm class = igemm + ping-pong (g8p, round 4) + rowpanel + split-K reduce + the fused FeedForward / temporal- / cross-attention block kernels + the panel-resident small-M kernel (round 5)",
+            "library kernels only (setup-time weight conversion and torch kernels excluded); igemm class = igemm + ping-pong (g8p, round 4) + rowpanel + split-K reduce + the fused FeedForward / temporal- / cross-attention block kernels + the panel-resident small-M kernel (round 5) + the temporal attention head kernel (round 6)",
     "igemm_launches_per_ddim_step": n_ig / forwards,
     "igemm_hbm_bytes_per_ddim_step": (2.0 * f_ig + w_ig) * 1024.0 / forwards,
     "igemm_fetch_kb_raw": f_ig / forwards,
