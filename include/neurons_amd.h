@@ -432,6 +432,16 @@ nr_status nr_op_tattn_fused_frames(nr_stream stream, void* t_dev, int32_t nbatch
 nr_status nr_op_tattn_head(nr_stream stream, const void* t_dev, void* a_dev, int32_t nbatch, int32_t hw, int32_t C, const void* w_folded_dev,
                            const float* lnc_dev, const float* bias_dev, const float* rowvec_dev, float ln_eps);
 
+/* The cross-attention of one BasicTransformerBlock ABOVE the C = 320 level up to (not including) to_out, one launch (xattnw.hip, round 6; engine:
+ * spatial_transformer):  a = softmax(q K^T / sqrt(d)) V,  q = LayerNorm(t) Wq^T,  K | V = the context projections of the row's clip (attention.py:281-290,
+ * context repeated per frame :100; motion_module_new.py:201-287), LayerNorm folded as everywhere in this library: wq_folded bf16 [C][C] = gamma[k] Wq[n][k],
+ * lnc fp32 [C] = its row sums, bias fp32 [C] = sum_k beta[k] Wq[n][k].  t, a: bf16 [nimg * hw][C] in "(b f) (h w) c" row order, C = 640 or 1280 (8 heads), hw a
+ * multiple of 64; image i uses context i / img_per_ctx; kv: bf16 [nctx * Lk][ldkv] with K in columns [0, C) and V in [C, 2C), Lk <= 80.
+ * wq_folded == NULL re-uses the streams packed by the previous call at this C. */
+nr_status nr_op_xattn_head(nr_stream stream, const void* t_dev, void* a_dev, int32_t nimg, int32_t hw, int32_t img_per_ctx, int32_t C,
+                           const void* wq_folded_dev, const float* lnc_dev, const float* bias_dev, const void* kv_dev, int32_t ldkv, int32_t Lk,
+                           int32_t nctx, float ln_eps);
+
 #ifdef __cplusplus
 }
 #endif

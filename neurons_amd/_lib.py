@@ -126,6 +126,7 @@ SYMBOLS = {
     "nr_op_xattn_fused": (_I32, [_VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP, C.c_float]),
     "nr_op_tattn_fused_frames": (_I32, [_VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_float]),
     "nr_op_tattn_head": (_I32, [_VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP, _VP, C.c_float]),
+    "nr_op_xattn_head": (_I32, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _I32, _I32, _I32, C.c_float]),
 }
 
 _lib = None

@@ -85,6 +85,16 @@ int nr_tattn_fused_eligible(int C, int heads, int frames, int hw, long long rows
 int nr_launch_tattn_stream_pack(const bf16* wq, const bf16* wk, const bf16* wv, const bf16* wo, bf16* stream, hipStream_t s);
 int nr_launch_tattn_fused(bf16* t, int nbatch, int frames, int hw, const bf16* stream, const float* gamma, const float* gb, const float* bo, float ln_eps,
                           int norot, hipStream_t s);
+// xattnw.hip: q projection + context attention per (64 rows, 160 columns) above the C = 320 level (C = 640 / 1280, <= 80 text tokens)
+size_t nr_xattnw_wstream_bytes(int C);
+size_t nr_xattnw_kvstream_bytes(int C, int nctx);
+size_t nr_xattnw_table_bytes(int C);
+int nr_xattnw_eligible(int C, int heads, int Lk, int hw, long long rows);
+int nr_launch_xattnw_w_pack(const bf16* w_folded, int C, bf16* stream, hipStream_t s);
+int nr_launch_xattnw_table_pack(const float* lnc, const float* bias, int C, float* table, hipStream_t s);
+int nr_launch_xattnw_kv_pack(const bf16* kv, int ldkv, int Lk, int nctx, int C, bf16* kvs, hipStream_t s);
+int nr_launch_xattnw(const bf16* t, bf16* out, int nimg, int hw, int img_per_ctx, int nctx, int Lk, int C, const bf16* wstream, const bf16* kvstream,
+                     const float* table, float ln_eps, hipStream_t s);
 // tattnw.hip: q|k|v projection of one head + F x F attention per (pixel group, head) above the C = 320 level (C = 640 / 1280, F = 16)
 size_t nr_tattnw_stream_bytes(int C);
 int nr_tattnw_eligible(int C, int heads, int frames, int hw, long long rows);
@@ -1129,6 +1139,61 @@ struct nr_net {
         emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_xattn_fused(tp, nimg, hwx, ipc, nctx, Lk, wstream, kvsp, gamma, beta, bo, 1e-5f, norot, s)); }, NR_PROF_IGEMM,
              2.0 * M * C * 2.0 * C + 4.0 * M * (double)Lk * C, 2.0 * (2.0 * M * C + 2.0 * C * (double)C), d);
         op_tap("xattn_fused", t);
+      } else if (cfg.kind != NR_KIND_SGM_UNET && !attn_fp8 && t.ld == C && nr_xattnw_eligible(C, heads, ctx_len, x.H * x.W, det_rows(t.rows()))) {
+        // C = 640 / 1280, 8 heads, <= 80 context tokens: LayerNorm (folded), the q projection and the attention on the cached K | V of the row's
+        // context in ONE launch per block (xattnw.hip); q never reaches HBM.  to_out + residual stays the GEMM below.
+        GemmOpt ok;
+        building_ctx = true;      // K|V of the context + their fragment images: recomputed only when the context changes
+        Act kv = new_act_persistent(ctx_bf.nimg, ctx_bf.H, ctx_bf.W, 2 * C);
+        ok.out = &kv;
+        linear(ctx_bf, w_linear_cat({b + ".attn2.to_k.weight", b + ".attn2.to_v.weight"}, C, cfg.cross_attention_dim), 2 * C, ok);
+        const int nctx = (int)(ctx_bf.rows() / ctx_len);
+        Act kvs = new_act_persistent(1, 1, 1, (int)(nr_xattnw_kvstream_bytes(C, nctx) / sizeof(bf16)));
+        {
+          const bf16* kvp = kv.ptr; bf16* kvsp = kvs.ptr; const int ldkv = kv.ld, Lk = ctx_len, Cc = C;
+          emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_xattnw_kv_pack(kvp, ldkv, Lk, nctx, Cc, kvsp, s)); });
+        }
+        building_ctx = false;
+        ctx_persist.push_back(kv);
+        ctx_persist.push_back(kvs);
+        const std::string nrm = b + ".norm2", wq = b + ".attn2.to_q.weight";
+        const std::string lnw_name = "lnw:" + nrm + "|" + wq + "|";
+        const std::string sname = "xaws:" + nrm + "|" + wq;
+        const bf16* wstream = (const bf16*)cached(sname, [&]() {
+          void* d = nullptr;
+          const size_t nb = nr_xattnw_wstream_bytes(C);
+          const bool had = dev.count(lnw_name) != 0;       // the folded [C][C] matrix is only the input of the packed stream
+          const LnW lwm = w_ln_linear({wq}, {}, nrm, C, C, false, true);
+          HIP_OK(hipMalloc(&d, nb));
+          LAUNCH_OK(nr_launch_xattnw_w_pack(lwm.w, C, (bf16*)d, nullptr));
+          HIP_OK(hipDeviceSynchronize());
+          dev[sname] = d; dev_bytes[sname] = nb; weight_bytes += nb;
+          if (!had) drop(lnw_name);
+          return d;
+        });
+        const std::string tname = "xawt:" + nrm + "|" + wq;
+        const float* table = (const float*)cached(tname, [&]() {
+          const LnW lw = w_ln_linear({wq}, {}, nrm, C, C, false, false);
+          void* d = nullptr;
+          const size_t nb = nr_xattnw_table_bytes(C);
+          HIP_OK(hipMalloc(&d, nb));
+          LAUNCH_OK(nr_launch_xattnw_table_pack(lw.c, lw.b, C, (float*)d, nullptr));
+          HIP_OK(hipDeviceSynchronize());
+          dev[tname] = d; dev_bytes[tname] = nb; weight_bytes += nb;
+          return d;
+        });
+        if (dry) (void)w_ln_linear({wq}, {}, nrm, C, C, false, false);      // shape checks in the sizing pass too
+        Act a = new_act(t.nimg, t.H, t.W, C);
+        const bf16* tp = t.ptr; bf16* ap = a.ptr; const bf16* kvsp = kvs.ptr;
+        const int nimg = t.nimg, hwx = x.H * x.W, ipc = F, Lk = ctx_len, Cc = C;
+        const double M = (double)t.rows();
+        char d[160];
+        snprintf(d, sizeof(d), "xattn_head M=%d C=%d Lk=%d (LN folded, q of 160 columns, context attention)", (int)t.rows(), C, Lk);
+        emit([=](hipStream_t s) { LAUNCH_OK(nr_launch_xattnw(tp, ap, nimg, hwx, ipc, nctx, Lk, Cc, wstream, kvsp, table, 1e-5f, s)); }, NR_PROF_IGEMM,
+             2.0 * M * C * (double)C + 4.0 * M * (double)Lk * C, 2.0 * (2.0 * M * C + C * (double)C), d);
+        op_tap("xattn_head", a);
+        GemmOpt oo; oo.bias = w_f32(b + ".attn2.to_out.0.bias", C); oo.res = &t; oo.out = &t;
+        linear(a, w_linear(b + ".attn2.to_out.0.weight", C, C), C, oo);
       } else {  // cross-attention on the context (attention.py:100: context repeated per frame)
         Act q = ln_linear(t, b + ".norm2", {b + ".attn2.to_q.weight"}, {}, C, false, 0, false);
         GemmOpt ok;
@@ -3143,6 +3208,43 @@ extern "C" nr_status nr_op_xattn_fused(nr_stream stream, void* t_dev, int32_t ni
   }
   LAUNCH_OK(nr_launch_xattn_fused((bf16*)t_dev, nimg, hw, img_per_ctx, nctx, Lk, (const bf16*)ws, (const bf16*)kvs, gamma_dev, beta_dev, bo_dev, ln_eps,
                                   getenv("NR_DETERMINISTIC_BATCH") && getenv("NR_DETERMINISTIC_BATCH")[0] == '1', (hipStream_t)stream));
+  NR_CATCH
+}
+// ---- q projection + context attention above the C = 320 level (xattnw.hip), op-level entry for tests.  t: bf16 [nimg * hw][C] (C = 640 or 1280,
+// hw a multiple of 64); a: bf16, same shape (attention output before to_out); wq_folded: bf16 [C][C] = gamma-scaled rows of to_q; lnc / bias fp32 [C];
+// kv: bf16 [nctx * Lk][ldkv], K in columns [0, C), V in [C, 2C); image i attends to context i / img_per_ctx ----
+extern "C" nr_status nr_op_xattn_head(nr_stream stream, const void* t_dev, void* a_dev, int32_t nimg, int32_t hw, int32_t img_per_ctx, int32_t C,
+                                      const void* wq_folded_dev, const float* lnc_dev, const float* bias_dev, const void* kv_dev, int32_t ldkv, int32_t Lk,
+                                      int32_t nctx, float ln_eps) {
+  NR_TRY
+  if (!t_dev || !a_dev || !kv_dev) throw NrError(NR_ERR_ARG, "null argument");
+  if (!nr_xattnw_wstream_bytes(C) || nimg <= 0 || hw <= 0 || hw % 64 != 0 || Lk < 1 || Lk > 80 || nctx <= 0 || img_per_ctx <= 0 ||
+      (nimg + img_per_ctx - 1) / img_per_ctx > nctx)
+    throw NrError(NR_ERR_UNSUPPORTED, "cross-attention head kernel: C = 640 or 1280, 8 heads, Lk <= 80, hw % 64 == 0, one context per img_per_ctx images");
+  static void* ws[2] = {nullptr, nullptr};
+  static void* tbl[2] = {nullptr, nullptr};
+  static void* kvs = nullptr;
+  static size_t kvs_cap = 0;
+  const int ci = C == 640 ? 0 : 1;
+  if (!ws[ci]) HIP_OK(hipMalloc(&ws[ci], nr_xattnw_wstream_bytes(C)));
+  if (!tbl[ci]) HIP_OK(hipMalloc(&tbl[ci], nr_xattnw_table_bytes(C)));
+  const size_t need = nr_xattnw_kvstream_bytes(C, nctx);
+  if (need > kvs_cap) {
+    HIP_OK(hipDeviceSynchronize());
+    if (kvs) (void)hipFree(kvs);
+    HIP_OK(hipMalloc(&kvs, need));
+    HIP_OK(hipMemset(kvs, 0, need));
+    kvs_cap = need;
+  }
+  // wq_folded == NULL: reuse the streams packed by the previous call at this C (timing loops)
+  if (wq_folded_dev) {
+    if (!lnc_dev || !bias_dev) throw NrError(NR_ERR_ARG, "null argument");
+    LAUNCH_OK(nr_launch_xattnw_w_pack((const bf16*)wq_folded_dev, C, (bf16*)ws[ci], (hipStream_t)stream));
+    LAUNCH_OK(nr_launch_xattnw_table_pack(lnc_dev, bias_dev, C, (float*)tbl[ci], (hipStream_t)stream));
+    LAUNCH_OK(nr_launch_xattnw_kv_pack((const bf16*)kv_dev, ldkv, Lk, nctx, C, (bf16*)kvs, (hipStream_t)stream));
+  }
+  LAUNCH_OK(nr_launch_xattnw((const bf16*)t_dev, (bf16*)a_dev, nimg, hw, img_per_ctx, nctx, Lk, C, (const bf16*)ws[ci], (const bf16*)kvs, (const float*)tbl[ci],
+                             ln_eps, (hipStream_t)stream));
   NR_CATCH
 }
 // ---- q|k|v projection of one head + 16 x 16 attention above the C = 320 level (tattnw.hip), op-level entry for tests.  t: bf16 [nbatch * 16 * hw][C]

@@ -1,0 +1,356 @@
+// The q projection and the attention of one CROSS-attention block above the C = 320 level (C = 640: d = 80, C = 1280: d = 160; 8 heads, <= 80 text
+// tokens) in one launch, one workgroup per (64 rows, 160 q-columns = two heads of d = 80 or one head of d = 160):
+//
+//     a[:, cols]  =  softmax( q K^T / sqrt(d) ) V ,   q = LayerNorm(t) . Wq[cols]^T ,   K | V = the cached projections of the row's text context
+//
+// i.e. BasicTransformerBlock's `norm2 -> attn2` up to (not including) to_out (animatediff/models/attention.py:281-290, context repeated per frame :100;
+// attention arithmetic motion_module_new.py:201-287).  Until round 6 these levels ran the LayerNorm-folded q GEMM (N = K = C: 20 us at M = 8192 / 2048,
+// the short-K shape the tiled igemm serves at 0.13 of peak), the attention core on the q tensor (12-16 us) and the to_out GEMM.  Here q never leaves
+// the registers; to_out (+ bias + residual) stays a GEMM on a.  Same skeleton as tattnw.hip (the temporal blocks of these levels):
+//   * W' = gamma . Wq (LayerNorm folded: q = rstd (x W'^T - mean c) + b'), FRAGMENT-MAJOR, streamed one k-step (32 channels: 10 fragments) per stage
+//     through a 4-slot LDS ring by linear LDS-DMA, the raw rows of t through the same ring (16 rows x 64 bytes per wave and stage, chunk-permuted:
+//     conflict-free fragment reads); every workgroup starts at its own k-step (L2 channel spread); two workgroups per CU;
+//   * q tiles as W' . x^T (lane = 4 channels of its row), row statistics from the fragments that pass (v_dot2c_f32_bf16);
+//   * behind the k-loop the ring is re-used for the K / V^T images of the workgroup's 160 columns for the row's context (packed once per context by
+//     xattnw_kv_pack_kernel: MFMA fragments of v_mfma_f32_16x16x16_bf16, keys >= Lk zero / masked);  S^T = K Q^T (5 key tiles), softmax over the 80 key
+//     slots (4 registers x 5 tiles x 4 lane groups), O^T = V^T P^T, 8-byte stores of a[row][cols].
+#include "common.h"
+#include <cstdlib>
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ void glds16(const void* src, unsigned lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_wave_base) : "memory", "m0");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ float xmax_rows(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float xsum_rows(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ s16x4 pack4(const f32x4& v) {
+  bf16x4 b;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) b[e] = (bf16)v[e];
+  return __builtin_bit_cast(s16x4, b);
+}
+
+// acc += A B (16 x 16 x 16 bf16) with the accumulator TIED (vDst = SrcC).  Left to hipcc 7.2 the five-/ten-long accumulation chains of this kernel are
+// allocated as v[28:31] <- v[30:33] style chains (destination PARTIALLY overlapping the SrcC the previous MFMA wrote) with no wait states between the
+// dependent MFMAs -- the pattern that returned wrong sums on gfx950 in attention.hip (tools/check_mfma_overlap.py scans the shipped ISA for it; it
+// flagged the first build of this file).  An asm MFMA is invisible to the compiler's hazard bookkeeping, so the asm carries its own: the leading
+// s_nop 1 covers a VALU-written operand (the packed q / P tiles, the zeroed accumulator) directly in front of it; mfma_results() puts the wait
+// states of an MFMA result -> VALU read behind the chain.
+__device__ __forceinline__ void mfma16_tied(f32x4& acc, const s16x4& a, const s16x4& b) {
+  asm("s_nop 1\n\tv_mfma_f32_16x16x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_results(f32x4& acc) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc)); }
+
+constexpr int XW_HEADS = 8;
+constexpr int XW_KT = 5;                         // key tiles of 16: 80 key slots, Lk <= 80
+constexpr int XW_COLS = 160, XW_NT = 10;         // q columns / weight fragments of a workgroup
+constexpr int XW_ROWS = 64;                      // rows per workgroup (4 waves x 16)
+constexpr int XW_W_STAGE = 12 * 1024;            // 10 fragments of 1 KiB + 2 KiB pad: 3 DMA pieces per wave
+constexpr int XW_A_STAGE = 4 * 1024;             // 64 rows x 64 B: 1 piece per wave
+constexpr int XW_STAGE = XW_W_STAGE + XW_A_STAGE;
+constexpr int XW_NS = 4;                         // ring slots: 64 KiB
+constexpr int XW_PPW = 4;                        // DMA pieces per wave and stage
+constexpr int XW_KV_BLOCK = 2 * XW_KT * XW_NT * 512;   // K image + V^T image of one 160-column block of one context: 51 200 B
+constexpr int XW_KV_PIECES = 13;                 // per wave: 52 KiB >= XW_KV_BLOCK (the stream is padded)
+constexpr int XW_TBL = 2 * 1024;                 // c[160] at 0, b'[160] at 1 KiB (fp32), one DMA piece each
+static_assert(4 * XW_KV_PIECES * 1024 <= XW_NS * XW_STAGE && 4 * XW_KV_PIECES * 1024 >= XW_KV_BLOCK, "the K / V images re-use the ring");
+
+struct NrXAttnWParams {
+  const bf16* t;           // [nimg * hw][C] residual stream (raw: LayerNorm is folded)
+  bf16* out;               // [nimg * hw][C] attention output a (before to_out)
+  int nrows, hw, img_per_ctx, Lk;
+  int xcd_mode;            // 0: the column blocks of a row group share an XCD (row groups % 8 == 0); 1: plain order
+  const bf16* stream;      // [C / 160 column blocks][C / 32 k-steps][XW_W_STAGE] fragment-major folded q weights
+  const bf16* kvstream;    // [contexts][C / 160][XW_KV_BLOCK] K / V^T fragment images (+ 4 KiB of padding at the end)
+  const float* table;      // [2][C + 256]: c[n] = sum_k W'[n][k], then b'[n] = sum_k beta[k] W[n][k]
+  float ln_eps, scale_log2e;
+};
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void xattn_head_kernel(NrXAttnWParams p) {
+  constexpr int C = XW_HEADS * D, DT = D / 16, HG = XW_COLS / D, S = C / 32, NCB = C / XW_COLS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // XW_NS stages, then XW_TBL bytes
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+
+  int rg, cb;
+  if (p.xcd_mode == 0) { const int j = blockIdx.x >> 3; cb = j % NCB; rg = (j / NCB) * 8 + (int)(blockIdx.x & 7); }
+  else { cb = (int)(blockIdx.x % NCB); rg = blockIdx.x / NCB; }
+  const int r0 = rg * XW_ROWS;
+  const int img = r0 / p.hw;
+  const int ctx = img / p.img_per_ctx;
+  const int rot = ((r0 - img * p.hw) / XW_ROWS) % S;          // position inside the image: batch-independent
+
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lptr_t)smem);
+  const char* wsrc = reinterpret_cast<const char*>(p.stream) + (size_t)cb * ((size_t)S * XW_W_STAGE) + (size_t)(wave * 3) * 1024 + (size_t)lane * 16;
+  const bf16* arow;
+  {
+    const int r = lane >> 2;
+    arow = p.t + (size_t)(r0 + 16 * wave + r) * C + (((lane & 3) ^ ((-(r >> 2)) & 3)) << 3);
+  }
+  auto issue_piece = [&](int s, int slot, int i) {
+    const unsigned dst = lds0 + (unsigned)(slot * XW_STAGE);
+    int ks = s + rot; if (ks >= S) ks -= S;
+    if (i < 3) glds16(wsrc + (size_t)ks * XW_W_STAGE + (size_t)i * 1024, dst + (unsigned)((wave * 3 + i) * 1024));
+    else glds16(arow + 32 * ks, dst + (unsigned)(XW_W_STAGE + wave * 1024));
+  };
+  // the fold vectors of the workgroup's columns: wave 0 fetches c[cols ..], wave 1 b'[cols ..] (1 KiB each: 160 floats + over-read inside the padded table)
+  if (wave < 2) glds16(reinterpret_cast<const char*>(p.table + (size_t)wave * (C + 256) + cb * XW_COLS) + (size_t)lane * 16, lds0 + (unsigned)(XW_NS * XW_STAGE + wave * 1024));
+#pragma unroll
+  for (int s = 0; s < XW_NS - 1; ++s)
+#pragma unroll
+    for (int i = 0; i < XW_PPW; ++i) issue_piece(s, s, i);
+
+  f32x4 acc[XW_NT];
+#pragma unroll
+  for (int n = 0; n < XW_NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float s1 = 0.f, s2 = 0.f;
+  const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
+  const unsigned wl = (unsigned)lane * 16;
+  const unsigned al = (unsigned)(XW_W_STAGE + wave * 1024 + fr * 64 + ((fg ^ ((-(fr >> 2)) & 3)) << 4));
+
+  int slot = 0;
+  for (int s = 0; s < S; ++s) {
+    // outstanding allowed: the stages issued after stage s (min(NS - 2, S - 1 - s) of them); the two table pieces are older than everything
+    const int rem = S - 1 - s;
+    if (rem >= XW_NS - 2) wait_vmcnt<(XW_NS - 2) * XW_PPW>();
+    else if (rem == 1) wait_vmcnt<XW_PPW>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    const int s_next = s + XW_NS - 1;
+    const bool pf = s_next < S;
+    int pslot = slot + XW_NS - 1; if (pslot >= XW_NS) pslot -= XW_NS;
+    const unsigned char* base = smem + slot * XW_STAGE;
+    const bf16x8 xa = *(const bf16x8*)(base + al);
+    bf16x8 w[XW_NT];
+#pragma unroll
+    for (int n = 0; n < XW_NT; ++n) w[n] = *(const bf16x8*)(base + (unsigned)(n * 1024) + wl);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bf16x2 pr = {xa[2 * e], xa[2 * e + 1]};
+      s1 = __builtin_amdgcn_fdot2_f32_bf16(pr, one2, s1, false);
+      s2 = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, s2, false);
+    }
+    if (pf) { issue_piece(s_next, pslot, 0); issue_piece(s_next, pslot, 1); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 0; n < XW_NT / 2; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[n], xa, acc[n], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (pf) { issue_piece(s_next, pslot, 2); issue_piece(s_next, pslot, 3); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = XW_NT / 2; n < XW_NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[n], xa, acc[n], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    slot = slot + 1 == XW_NS ? 0 : slot + 1;
+  }
+
+  // ---- the K / V^T images of (context, column block) into the ring (every wave has left the last stage behind the barrier) ----
+  __builtin_amdgcn_s_barrier();
+  {
+    const char* kvsrc = reinterpret_cast<const char*>(p.kvstream) + ((size_t)ctx * NCB + cb) * XW_KV_BLOCK + (size_t)(wave * XW_KV_PIECES) * 1024 + (size_t)lane * 16;
+#pragma unroll
+    for (int i = 0; i < XW_KV_PIECES; ++i) glds16(kvsrc + (size_t)i * 1024, lds0 + (unsigned)((wave * XW_KV_PIECES + i) * 1024));
+  }
+  // LayerNorm statistics of the wave's 16 rows (lane (fr, fg) holds a quarter of row fr's sums) while the images land
+  const float mu = xsum_rows(s1) * (1.0f / C);
+  const float rstd = rsqrtf(fmaxf(xsum_rows(s2) * (1.0f / C) - mu * mu, 0.f) + p.ln_eps);
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+
+  const float* tb = reinterpret_cast<const float*>(smem + XW_NS * XW_STAGE);
+  s16x4 qa[XW_NT];
+#pragma unroll
+  for (int n = 0; n < XW_NT; ++n) {
+    const int col = 16 * n + 4 * fg;
+    const f32x4 c4 = *(const f32x4*)(tb + col), b4 = *(const f32x4*)(tb + 256 + col);
+    f32x4 v = acc[n];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (v[e] - mu * c4[e]) * rstd + b4[e];
+    qa[n] = pack4(v);
+  }
+  const unsigned char* kimg = smem + (unsigned)lane * 8;                       // K fragment (kt, n10) at ((kt 10 + n10) 64 + lane) 8 B
+  const unsigned char* vimg = smem + XW_KT * XW_NT * 512 + (unsigned)lane * 8;   // V^T fragment (g10, kt) at ((g10 5 + kt) 64 + lane) 8 B
+  bf16* orow = p.out + (size_t)(r0 + 16 * wave + fr) * C + cb * XW_COLS + 4 * fg;
+#pragma unroll
+  for (int hh = 0; hh < HG; ++hh) {
+    f32x4 sc[XW_KT];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < XW_KT; ++kt) {
+      f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int nt = 0; nt < DT; ++nt) {
+        const s16x4 kf = *(const s16x4*)(kimg + (unsigned)((kt * XW_NT + hh * DT + nt) * 512));
+        mfma16_tied(s4, kf, qa[hh * DT + nt]);
+      }
+      mfma_results(s4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (16 * kt + 4 * fg + r >= p.Lk) s4[r] = -1.0e30f;           // key slots beyond the context
+        mx = fmaxf(mx, s4[r]);
+      }
+      sc[kt] = s4;
+    }
+    mx = xmax_rows(mx);
+    float l = 0.f;
+    s16x4 pb[XW_KT];
+#pragma unroll
+    for (int kt = 0; kt < XW_KT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { sc[kt][r] = __builtin_amdgcn_exp2f((sc[kt][r] - mx) * p.scale_log2e); l += sc[kt][r]; }
+      pb[kt] = pack4(sc[kt]);
+    }
+    l = xsum_rows(l);
+    const float inv = __builtin_amdgcn_rcpf(l);
+#pragma unroll
+    for (int g = 0; g < DT; ++g) {
+      f32x4 o4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < XW_KT; ++kt) {
+        const s16x4 vf = *(const s16x4*)(vimg + (unsigned)(((hh * DT + g) * XW_KT + kt) * 512));
+        mfma16_tied(o4, vf, pb[kt]);
+      }
+      mfma_results(o4);
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (bf16)(o4[r] * inv);
+      nr_store8(orow + 16 * (hh * DT + g), o);
+    }
+  }
+}
+
+// fragment-major q weights from the LayerNorm-folded [C][C] bf16 matrix: chunk -> (column block, k-step, fragment n, lane)
+template <int D>
+__global__ __launch_bounds__(256) void xattnw_w_pack_kernel(const bf16* __restrict__ w, bf16* __restrict__ stream) {
+  constexpr int C = XW_HEADS * D, S = C / 32, NCB = C / XW_COLS, CH_STAGE = XW_W_STAGE / 16;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= NCB * S * CH_STAGE) return;
+  const int cb = idx / (S * CH_STAGE);
+  int c = idx - cb * (S * CH_STAGE);
+  const int ks = c / CH_STAGE;
+  c -= ks * CH_STAGE;
+  bf16x8 v = bf16x8_zero();
+  if (c < XW_NT * 64) {
+    const int n = c / 64, lane = c & 63;
+    v = *(const bf16x8*)(w + (size_t)(cb * XW_COLS + 16 * n + (lane & 15)) * C + 32 * ks + 8 * (lane >> 4));
+  }
+  *(bf16x8*)(stream + (size_t)idx * 8) = v;
+}
+
+// K / V^T fragment images per (context, column block) from the cached K | V projection kv [contexts * Lk][ldkv] (K in columns [0, C), V in [C, 2C));
+// one thread per 8-byte chunk
+template <int D>
+__global__ __launch_bounds__(256) void xattnw_kv_pack_kernel(const bf16* __restrict__ kv, int ldkv, int Lk, int nctx, bf16* __restrict__ kvs) {
+  constexpr int C = XW_HEADS * D, NCB = C / XW_COLS, PER = XW_KV_BLOCK / 8, HALF = PER / 2;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)nctx * NCB * PER) return;
+  const int ctx = (int)(idx / (NCB * PER));
+  int e = (int)(idx - (long long)ctx * NCB * PER);
+  const int cb = e / PER;
+  e -= cb * PER;
+  bf16x4 v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = (bf16)0.0f;
+  const int lane = e & 63, lr = lane & 15, lg = lane >> 4;
+  if (e < HALF) {                                  // K: (kt, n10): K[key 16 kt + lr][col 16 n10 + 4 lg + j]
+    const int kt = e / (XW_NT * 64), n10 = (e / 64) % XW_NT;
+    const int key = 16 * kt + lr;
+    if (key < Lk) v = *(const bf16x4*)(kv + (size_t)(ctx * Lk + key) * ldkv + cb * XW_COLS + 16 * n10 + 4 * lg);
+  } else {                                         // V^T: (g10, kt): V[key 16 kt + 4 lg + j][col 16 g10 + lr]
+    const int e2 = e - HALF;
+    const int g10 = e2 / (XW_KT * 64), kt = (e2 / 64) % XW_KT;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int key = 16 * kt + 4 * lg + j;
+      if (key < Lk) v[j] = kv[(size_t)(ctx * Lk + key) * ldkv + C + cb * XW_COLS + 16 * g10 + lr];
+    }
+  }
+  *(bf16x4*)(kvs + (size_t)idx * 4) = v;
+}
+
+__global__ __launch_bounds__(256) void xattnw_table_pack_kernel(const float* __restrict__ lnc, const float* __restrict__ bias, int C, float* __restrict__ table) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int ld = C + 256;
+  if (idx >= 2 * ld) return;
+  const int row = idx / ld, n = idx - row * ld;
+  table[idx] = n < C ? (row == 0 ? lnc[n] : bias[n]) : 0.f;
+}
+
+unsigned long long g_xw_attr = 0;
+
+}  // namespace
+
+extern "C" size_t nr_xattnw_wstream_bytes(int C) { return (C == 640 || C == 1280) ? (size_t)(C / XW_COLS) * (C / 32) * XW_W_STAGE : 0; }
+extern "C" size_t nr_xattnw_kvstream_bytes(int C, int nctx) { return (C == 640 || C == 1280) ? (size_t)nctx * (C / XW_COLS) * XW_KV_BLOCK + 4096 : 0; }
+extern "C" size_t nr_xattnw_table_bytes(int C) { return (C == 640 || C == 1280) ? (size_t)2 * (C + 256) * sizeof(float) : 0; }
+
+// rows: the launch's row count (deterministic-batch mode: one clip's)
+extern "C" int nr_xattnw_eligible(int C, int heads, int Lk, int hw, long long rows) {
+  static const bool off = getenv("NR_XATTN_HEAD") && getenv("NR_XATTN_HEAD")[0] == '0';   // A/B switch
+  return !off && (C == 640 || C == 1280) && heads == XW_HEADS && Lk >= 1 && Lk <= XW_KT * 16 && hw % XW_ROWS == 0 && rows >= 2048;
+}
+
+extern "C" int nr_launch_xattnw_w_pack(const bf16* w_folded, int C, bf16* stream, hipStream_t s) {
+  const int total = (int)(nr_xattnw_wstream_bytes(C) / 16);
+  if (!total) return 1;
+  if (C == 640) hipLaunchKernelGGL(xattnw_w_pack_kernel<80>, dim3((total + 255) / 256), dim3(256), 0, s, w_folded, stream);
+  else hipLaunchKernelGGL(xattnw_w_pack_kernel<160>, dim3((total + 255) / 256), dim3(256), 0, s, w_folded, stream);
+  return 0;
+}
+extern "C" int nr_launch_xattnw_table_pack(const float* lnc, const float* bias, int C, float* table, hipStream_t s) {
+  if (!nr_xattnw_table_bytes(C)) return 1;
+  const int total = 2 * (C + 256);
+  hipLaunchKernelGGL(xattnw_table_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, lnc, bias, C, table);
+  return 0;
+}
+extern "C" int nr_launch_xattnw_kv_pack(const bf16* kv, int ldkv, int Lk, int nctx, int C, bf16* kvs, hipStream_t s) {
+  if (!nr_xattnw_wstream_bytes(C) || nctx <= 0 || Lk < 1 || Lk > XW_KT * 16 || ldkv < 2 * C || ldkv % 4 != 0) return 1;
+  const long long total = (long long)nctx * (C / XW_COLS) * (XW_KV_BLOCK / 8);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (C == 640) hipLaunchKernelGGL(xattnw_kv_pack_kernel<80>, grid, dim3(256), 0, s, kv, ldkv, Lk, nctx, kvs);
+  else hipLaunchKernelGGL(xattnw_kv_pack_kernel<160>, grid, dim3(256), 0, s, kv, ldkv, Lk, nctx, kvs);
+  return 0;
+}
+
+extern "C" int nr_launch_xattnw(const bf16* t, bf16* out, int nimg, int hw, int img_per_ctx, int nctx, int Lk, int C, const bf16* wstream, const bf16* kvstream,
+                                const float* table, float ln_eps, hipStream_t s) {
+  if (!nr_xattnw_wstream_bytes(C) || nimg <= 0 || hw <= 0 || hw % XW_ROWS != 0 || img_per_ctx <= 0 || Lk < 1 || Lk > XW_KT * 16) return 1;
+  if ((nimg + img_per_ctx - 1) / img_per_ctx > nctx) return 1;
+  NrXAttnWParams p;
+  p.t = t; p.out = out; p.nrows = nimg * hw; p.hw = hw; p.img_per_ctx = img_per_ctx; p.Lk = Lk; p.stream = wstream; p.kvstream = kvstream; p.table = table;
+  p.ln_eps = ln_eps;
+  p.scale_log2e = 1.4426950408889634f / sqrtf((float)(C / XW_HEADS));
+  const int nrg = p.nrows / XW_ROWS, ncb = C / XW_COLS;
+  p.xcd_mode = nrg % 8 == 0 ? 0 : 1;
+  constexpr size_t shm = (size_t)XW_NS * XW_STAGE + XW_TBL;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!(g_xw_attr >> (dev & 63) & 1ull)) {
+    if (hipFuncSetAttribute((const void*)xattn_head_kernel<80>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return 2;
+    if (hipFuncSetAttribute((const void*)xattn_head_kernel<160>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return 2;
+    g_xw_attr |= 1ull << (dev & 63);
+  }
+  const unsigned grid = (unsigned)(nrg * ncb);
+  if (C == 640) hipLaunchKernelGGL(xattn_head_kernel<80>, dim3(grid), dim3(256), shm, s, p);
+  else hipLaunchKernelGGL(xattn_head_kernel<160>, dim3(grid), dim3(256), shm, s, p);
+  return 0;
+}

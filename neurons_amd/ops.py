@@ -302,6 +302,24 @@ def xattn_fused(t, nimg, hw, img_per_ctx, gamma, beta, wq, wo, bo, kv, Lk, eps=1
     return t
 
 
+def xattn_head(t, nimg, hw, img_per_ctx, gamma, beta, wq, kv, Lk, eps=1e-5, reuse_streams=False):
+    """a = cross-attention(LayerNorm(t), context K | V) BEFORE to_out at C = 640 or 1280 (8 heads), ONE launch (xattnw.hip).  t: [nimg * hw, C] bf16 in
+    "(b f) (h w) c" row order; image i attends to context i // img_per_ctx; kv: [nctx * Lk, 2C] bf16 (K | V columns); wq: [C, C].  The LayerNorm fold is
+    prepared here the way the engine prepares it (w_ln_linear)."""
+    _chk_bf16(t, kv)
+    C = t.shape[1]
+    assert C in (640, 1280) and t.shape[0] == nimg * hw and kv.shape[1] == 2 * C and kv.shape[0] % Lk == 0
+    nctx = kv.shape[0] // Lk
+    w = wq.float()
+    wf = (w * gamma.float()[None, :]).to(torch.bfloat16).contiguous()
+    lnc = wf.float().sum(1).contiguous()
+    bias = (w.double() @ beta.double()).float().contiguous()
+    a = torch.empty_like(t)
+    _lib.check(_lib.load().nr_op_xattn_head(_stream(), _ptr(t), _ptr(a), nimg, hw, img_per_ctx, C, None if reuse_streams else _ptr(wf), _ptr(lnc), _ptr(bias),
+                                            _ptr(kv), kv.shape[1], Lk, nctx, float(eps)))
+    return a
+
+
 # ---------------------------------------------------------------------------------------------------
 # Leaf-module handles (test hooks): ONE reference module planned as a network of its own, so the reference classes' own
 # outputs (tests/golden/leaf_ops.npz) can be replayed at the row counts where the engine picks its fused kernels.

@@ -452,6 +452,34 @@ def test_temporal_attention_head_kernel_matches_torch(cuda, C, nbatch, hw):
          ref2, max_tol=4e-2, mean_tol=8e-3)
 
 
+@pytest.mark.parametrize("C,nimg,hw,ipc,Lk", [(640, 32, 256, 16, 77), (640, 6, 64, 3, 80), (640, 3, 128, 3, 33), (1280, 32, 64, 16, 77), (1280, 5, 128, 2, 1),
+                                               (1280, 4, 64, 1, 80)])
+def test_cross_attention_head_kernel_matches_torch(cuda, C, nimg, hw, ipc, Lk):
+    """xattnw.hip (round 6): norm2 -> to_q -> softmax(q K^T / sqrt(d)) V on the cached context K | V of the row's clip, d = 80 / 160, 8 heads, one launch,
+    output a BEFORE to_out; against the fp32 torch composition of the reference (attention.py:281-290, context repeated per frame :100;
+    motion_module_new.py:201-287).  Shapes: the headline's (C = 640: 2 x 16 x 16x16, C = 1280: 2 x 16 x 8x8), several contexts with image i -> context
+    i // ipc, row-group counts that are not a multiple of 8 (the other workgroup order), a full 80-key tile, short contexts (masked key slots, Lk = 1)."""
+    from neurons_amd import ops
+    H = 8
+    nctx = (nimg + ipc - 1) // ipc
+    g = torch.Generator(device="cuda").manual_seed(C + nimg * 1000 + hw + Lk)
+    t = (torch.randn(nimg * hw, C, generator=g, device="cuda") * 1.1 + 0.1).to(torch.bfloat16)
+    gamma = 1.0 + 0.2 * torch.randn(C, generator=g, device="cuda")
+    beta = 0.1 * torch.randn(C, generator=g, device="cuda")
+    wq = torch.randn(C, C, generator=g, device="cuda") * C ** -0.5 * 2.0       # sharper softmax: exercises the max subtraction
+    kv = torch.randn(nctx * Lk, 2 * C, generator=g, device="cuda").to(torch.bfloat16)
+    x = t.float().view(nimg, hw, C)
+    q = torch.nn.functional.linear(torch.nn.functional.layer_norm(x, (C,), gamma, beta, 1e-5), wq).view(nimg, hw, H, C // H).transpose(1, 2)
+    ctx_of = torch.arange(nimg, device="cuda") // ipc
+    kf = kv.float().view(nctx, Lk, 2 * C)
+    k = kf[ctx_of, :, :C].view(nimg, Lk, H, C // H).transpose(1, 2)
+    v = kf[ctx_of, :, C:].view(nimg, Lk, H, C // H).transpose(1, 2)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * (C // H) ** -0.5, dim=-1) @ v).transpose(1, 2).reshape(nimg, hw, C)
+    out = ops.xattn_head(t, nimg, hw, ipc, gamma, beta, wq, kv, Lk)
+    _cmp(f"cross-attention head kernel C={C} nimg={nimg} hw={hw} ipc={ipc} Lk={Lk}", out.view(nimg, hw, C), ref)
+    assert torch.equal(out, ops.xattn_head(t, nimg, hw, ipc, gamma, beta, wq, kv, Lk))
+
+
 @pytest.mark.parametrize("nimg,hw,ipc,Lk", [(4, 1024, 2, 77), (6, 256, 3, 77), (2, 128, 1, 80), (3, 384, 3, 33)])
 def test_fused_cross_attention_block_matches_torch(cuda, nimg, hw, ipc, Lk):
     """xattn.hip (round 5): norm2 -> to_q -> softmax(q K^T / sqrt(40)) V on the cached context K | V of the row's clip -> to_out (+bias) -> + residual,
