@@ -31,6 +31,11 @@ extern "C" {
 int nr_launch_igemm(const NrGemmParams* pp, float* workspace, hipStream_t stream);
 size_t nr_igemm_workspace_bytes(const NrGemmParams* pp);
 int nr_igemm_splitk_l2_tiles(const NrGemmParams* pp);
+// lin160.hip: short-K Linears (K = 640 / 1280, N % 160 == 0, >= 2048 rows) on fragment-major weights
+size_t nr_lin160_stream_bytes(int N, int K);
+int nr_lin160_eligible(const NrGemmParams* pp);
+int nr_launch_lin160_w_pack(const bf16* w, int N, int K, bf16* stream, hipStream_t s);
+int nr_launch_lin160(const NrGemmParams* pp, const bf16* stream, hipStream_t s);
 int nr_gn_workspace_floats(int nimg, int hw, int groups, int* pix_per_blk_out, int* nchunk_out);
 int nr_launch_groupnorm(NrGnParams* pp, hipStream_t stream);
 int nr_launch_layernorm(const bf16* x, int ldx, bf16* out, int ldo, int M, int C, const float* gamma, const float* beta,
@@ -411,6 +416,22 @@ struct nr_net {
       return d;
     });
   }
+  // stage stream (lin160.hip) of a converted [N][K] weight matrix, cached as "l160:<its name>"; the row-major matrix stays (other row counts use it)
+  const bf16* w_lin160(const bf16* w, int N, int K) {
+    std::string src;
+    for (const auto& kv : dev) if (kv.second == (const void*)w) { src = kv.first; break; }
+    if (src.empty()) throw NrError(NR_ERR_STATE, "w_lin160: not a converted weight matrix");
+    const std::string name = "l160:" + src;
+    return (const bf16*)cached(name, [&]() {
+      void* d = nullptr;
+      const size_t nb = nr_lin160_stream_bytes(N, K);
+      HIP_OK(hipMalloc(&d, nb));
+      LAUNCH_OK(nr_launch_lin160_w_pack(w, N, K, (bf16*)d, nullptr));
+      HIP_OK(hipDeviceSynchronize());
+      dev[name] = d; dev_bytes[name] = nb; weight_bytes += nb;
+      return d;
+    });
+  }
   void check_shape(const std::string& key, const HostTensor& t, std::initializer_list<int64_t> want) const {
     std::vector<int64_t> w(want);
     int64_t nw = 1; for (auto s : w) nw *= s;
@@ -760,6 +781,16 @@ struct nr_net {
     p.out = out.ptr; p.ldo = out.ld;
     if (ksize == 1 && nr_smallm_eligible(&p))               // M <= 512 Linears: the panel-resident kernel reads fragment-major weights
       p.w_fm = dry ? reinterpret_cast<const bf16*>(uintptr_t(16)) : w_fragmajor(w, Cout, p.K);
+    if (ksize == 1 && !p.w_fm && nr_lin160_eligible(&p)) {
+      // short-K Linear (K = 640 / 1280) on >= 2048 rows: the stage-stream kernel (lin160.hip) instead of the tiled igemm
+      const bf16* stream = dry ? reinterpret_cast<const bf16*>(uintptr_t(16)) : w_lin160(w, Cout, p.K);
+      char d[160];
+      snprintf(d, sizeof(d), "lin160 M=%d N=%d K=%d res=%d", p.M, p.N, p.K, o.res ? 1 : 0);
+      const double bytes = 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N * (o.res ? 2.0 : 1.0));
+      emit([p, stream](hipStream_t s) { LAUNCH_OK(nr_launch_lin160(&p, stream, s)); }, NR_PROF_IGEMM, 2.0 * p.M * (double)p.N * p.K, bytes, d);
+      op_tap("lin160", out);
+      return out;
+    }
     {
       const double in_elems = (double)x0.rows() * (p.c0 + p.c1);   // every input element is needed at least once
       const double bytes = 2.0 * (in_elems + (double)p.N * p.K + (double)p.M * outC + (o.res ? (double)p.M * outC : 0.0));
@@ -3012,6 +3043,20 @@ extern "C" nr_status nr_op_gemm(nr_stream stream, const void* a, int32_t lda, co
   p.a0 = (const bf16*)a; p.c0 = K; p.lda0 = lda; p.H = p.W = p.OH = p.OW = 1; p.ksize = 1; p.stride = 1;
   p.w = (const bf16*)w; p.M = M; p.N = N; p.K = K; p.bias = bias; p.res = (const bf16*)res; p.ldr = ldr;
   p.out = (bf16*)out; p.ldo = ldo; p.out_scale = 1.f; p.geglu = geglu; p.rowvec_div = 1;
+  if (nr_lin160_eligible(&p)) {          // the engine's choice for short-K Linears on >= 2048 rows (lin160.hip): stream packed per call
+    static bf16* l160 = nullptr;
+    static size_t l160_cap = 0;
+    const size_t need = nr_lin160_stream_bytes(N, K);
+    if (need > l160_cap) {
+      HIP_OK(hipDeviceSynchronize());
+      if (l160) (void)hipFree(l160);
+      HIP_OK(hipMalloc((void**)&l160, need));
+      l160_cap = need;
+    }
+    LAUNCH_OK(nr_launch_lin160_w_pack(p.w, N, K, l160, (hipStream_t)stream));
+    LAUNCH_OK(nr_launch_lin160(&p, l160, (hipStream_t)stream));
+    return NR_OK;
+  }
   op_fragmajor(p, (hipStream_t)stream);
   LAUNCH_OK(nr_launch_igemm(&p, op_workspace(p), (hipStream_t)stream));
   NR_CATCH

@@ -1,0 +1,202 @@
+// Short-K Linear above the C = 320 level:  out[M][N] = x[M][K] . W[N][K]^T + bias (+ residual),  K = 640 / 1280, N a multiple of 160 --
+// the `proj_in` / `to_out` Linears of the spatial and temporal transformers at C = 640 / 1280 (animatediff/models/attention.py:110-113,135-140,
+// motion_module.py:146-158; CrossAttention.to_out motion_module_new.py:170-171): 30 launches per level and DDIM step that the tiled igemm serves at
+// 0.33 PFLOP/s (20-21 us for 6.7 GFLOP: 10-20 k-tiles per workgroup, 38 % of a workgroup's life outside the k-loop, 640 tiles = 2.5 rounds;
+// DESIGN 3a).  Same skeleton as the head kernels of round 6 (tattnw.hip / xattnw.hip), reduced to the GEMM:
+//   * one 512-thread workgroup per (BM rows, 160 columns), BM = 128 (wave w: row tile w, all 10 column tiles) or 64 (wave w: row tile w & 3, five
+//     column tiles): two waves per SIMD; the grid is exactly one round of the chip at the headline shapes (64 x 4 and 32 x 8 workgroups);
+//   * W FRAGMENT-MAJOR ([column block][stage][k-step][tile][64 lanes][8]), streamed two k-steps (64 channels: 20 fragments + 4 KiB of padding =
+//     3 DMA pieces per wave) per stage through a 3-slot LDS ring by linear LDS-DMA; the rows of x through the same ring (one 16-row x 64-byte
+//     piece per row tile and k-step, chunk-permuted: conflict-free fragment reads); every workgroup starts at its own stage (L2 channel spread);
+//   * accumulators as W . x^T (lane = 4 consecutive output channels of its row); epilogue: bias, residual, bf16, 8-byte stores (in place when
+//     the residual is the output).
+#include "common.h"
+#include <cstdlib>
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16(const void* src, unsigned lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_wave_base) : "memory", "m0");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+constexpr int L1_BN = 160, L1_NT = 10;
+constexpr int L1_W_STAGE = 24 * 1024;            // 2 k-steps x 10 fragments of 1 KiB + 4 KiB pad: 3 pieces per wave
+constexpr int L1_NS = 3;
+
+struct NrLin160Params {
+  const bf16* x; int lda;
+  const bf16* stream;      // [N / 160][K / 64 stages][L1_W_STAGE]
+  const float* bias;       // [N] or null
+  const bf16* res; int ldr;   // residual [M][ldr] or null (may alias out)
+  bf16* out; int ldo;
+  int M, N, K;
+  int norot;               // 1: every workgroup walks the stages from stage 0 (results independent of the row position: NR_DETERMINISTIC_BATCH)
+};
+
+template <int BM>
+__global__ __launch_bounds__(512) void lin160_kernel(NrLin160Params p) {
+  constexpr int RT = BM / 16;                    // row tiles: 8 / 4
+  constexpr int NTW = BM == 128 ? L1_NT : L1_NT / 2;   // column tiles per wave: 10 / 5
+  constexpr int A_STAGE = BM * 128;              // rows x 2 k-steps x 64 B: 16 / 8 KiB
+  constexpr int A_PW = BM == 128 ? 2 : 1;        // row pieces per wave and stage
+  constexpr int STAGE = L1_W_STAGE + A_STAGE;    // 40 / 32 KiB
+  constexpr int PPW = 3 + A_PW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // L1_NS stages
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int rt = BM == 128 ? wave : (wave & 3);          // this wave's row tile
+  const int n0 = BM == 128 ? 0 : (wave >> 2) * NTW;     // its first column tile
+
+  const int NCB = p.N / L1_BN, S = p.K >> 6;
+  const int nrg = p.M / BM;
+  int rg, cb;
+  if ((nrg & 7) == 0) { const int j = blockIdx.x >> 3; cb = j % NCB; rg = (j / NCB) * 8 + (int)(blockIdx.x & 7); }   // the column blocks of a row group share an XCD
+  else { cb = (int)(blockIdx.x % NCB); rg = blockIdx.x / NCB; }
+  const int r0 = rg * BM;
+  const int rot = p.norot ? 0 : rg % S;
+
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lptr_t)smem);
+  const char* wsrc = reinterpret_cast<const char*>(p.stream) + (size_t)cb * ((size_t)S * L1_W_STAGE) + (size_t)(wave * 3) * 1024 + (size_t)lane * 16;
+  // row pieces: piece (tile, kk) = 16 rows x 64 B of k-step kk; BM = 128: wave w fetches (w, 0) and (w, 1); BM = 64: wave w fetches (w & 3, w >> 2)
+  const bf16* arow;
+  {
+    const int r = lane >> 2;
+    arow = p.x + (size_t)(r0 + 16 * rt + r) * p.lda + (((lane & 3) ^ ((-(r >> 2)) & 3)) << 3);
+  }
+  auto issue_piece = [&](int s, int slot, int i) {
+    const unsigned dst = lds0 + (unsigned)(slot * STAGE);
+    int st = s + rot; if (st >= S) st -= S;
+    if (i < 3) glds16(wsrc + (size_t)st * L1_W_STAGE + (size_t)i * 1024, dst + (unsigned)((wave * 3 + i) * 1024));
+    else {
+      const int kk = BM == 128 ? i - 3 : (wave >> 2);
+      glds16(arow + 64 * st + 32 * kk, dst + (unsigned)(L1_W_STAGE + (kk * RT + rt) * 1024));
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < L1_NS - 1; ++s)
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) issue_piece(s, s, i);
+
+  f32x4 acc[NTW];
+#pragma unroll
+  for (int n = 0; n < NTW; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const unsigned wl = (unsigned)(n0 * 1024 + lane * 16);
+  const unsigned al = (unsigned)(L1_W_STAGE + rt * 1024 + fr * 64 + ((fg ^ ((-(fr >> 2)) & 3)) << 4));
+
+  int slot = 0;
+  for (int s = 0; s < S; ++s) {
+    if (s + 1 < S) wait_vmcnt<(L1_NS - 2) * PPW>(); else wait_vmcnt<0>();      // in flight behind stage s: the one stage issued after it
+    __builtin_amdgcn_s_barrier();             // every wave's pieces landed; every wave has left stage s - 1 (its slot may be refilled)
+    const int s_next = s + L1_NS - 1;
+    const bool pf = s_next < S;
+    int pslot = slot + L1_NS - 1; if (pslot >= L1_NS) pslot -= L1_NS;
+    const unsigned char* base = smem + slot * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const bf16x8 xa = *(const bf16x8*)(base + al + kk * (RT * 1024));
+      bf16x8 w[NTW];
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) w[n] = *(const bf16x8*)(base + (unsigned)((kk * L1_NT + n) * 1024) + wl);
+      if (pf) {
+        if (kk == 0) { issue_piece(s_next, pslot, 0); issue_piece(s_next, pslot, 1); }
+        else { issue_piece(s_next, pslot, 2); issue_piece(s_next, pslot, 3); if (A_PW == 2) issue_piece(s_next, pslot, 4); }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[n], xa, acc[n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    slot = slot + 1 == L1_NS ? 0 : slot + 1;
+  }
+
+  // ---- epilogue: lane holds out[r0 + 16 rt + fr][cb 160 + 16 (n0 + n) + 4 fg .. + 3] ----
+  const int row = r0 + 16 * rt + fr;
+  const int col0 = cb * L1_BN + 16 * n0 + 4 * fg;
+  bf16* orow = p.out + (size_t)row * p.ldo + col0;
+  const bf16* rrow = p.res ? p.res + (size_t)row * p.ldr + col0 : nullptr;
+#pragma unroll
+  for (int n = 0; n < NTW; ++n) {
+    f32x4 v = acc[n];
+    if (p.bias) v += *(const f32x4*)(p.bias + col0 + 16 * n);
+    if (rrow) {
+      const bf16x4 r = *(const bf16x4*)(rrow + 16 * n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+    }
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+    nr_store8(orow + 16 * n, o);
+  }
+}
+
+// fragment-major stream from the row-major [N][K] bf16 matrix: chunk -> (column block, stage, k-step kk, fragment n, lane)
+__global__ __launch_bounds__(256) void lin160_w_pack_kernel(const bf16* __restrict__ w, bf16* __restrict__ stream, int N, int K) {
+  const int S = K >> 6, NCB = N / L1_BN, CH_STAGE = L1_W_STAGE / 16;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)NCB * S * CH_STAGE) return;
+  const int cb = (int)(idx / ((long long)S * CH_STAGE));
+  int c = (int)(idx - (long long)cb * S * CH_STAGE);
+  const int st = c / CH_STAGE;
+  c -= st * CH_STAGE;
+  bf16x8 v = bf16x8_zero();
+  if (c < 2 * L1_NT * 64) {                                    // the tail of a stage is padding
+    const int kk = c / (L1_NT * 64), n = (c / 64) % L1_NT, lane = c & 63;
+    v = *(const bf16x8*)(w + (size_t)(cb * L1_BN + 16 * n + (lane & 15)) * K + 64 * st + 32 * kk + 8 * (lane >> 4));
+  }
+  *(bf16x8*)(stream + (size_t)idx * 8) = v;
+}
+
+unsigned long long g_l1_attr = 0;
+
+}  // namespace
+
+extern "C" size_t nr_lin160_stream_bytes(int N, int K) { return (N % L1_BN == 0 && K % 64 == 0) ? (size_t)(N / L1_BN) * (K / 64) * L1_W_STAGE : 0; }
+
+// The shapes this kernel is chosen for: plain Linear (one source, no GEGLU / LayerNorm fold / row vector / activation / scale), K = 640 or 1280
+// (the short-K regime), N a multiple of 160, >= 2048 rows in whole 64-row groups
+extern "C" int nr_lin160_eligible(const NrGemmParams* pp) {
+  static const bool off = getenv("NR_LIN160") && getenv("NR_LIN160")[0] == '0';   // A/B switch
+  const NrGemmParams& p = *pp;
+  if (off || p.ksize != 1 || p.stride != 1 || p.ups || p.a1 || p.c1 || p.geglu || p.ln_c || p.rowvec || p.act || p.out_f32 || p.tap_inner) return 0;
+  if (p.out_scale != 1.0f || p.K != p.c0 || (p.K != 640 && p.K != 1280) || p.N % L1_BN != 0 || p.N > 1280) return 0;
+  const int Mp = (p.plan_m > 0 && p.plan_m < p.M) ? p.plan_m : p.M;                 // NR_DETERMINISTIC_BATCH: the choice is made per clip
+  if (p.M % 64 != 0 || Mp < 2048) return 0;
+  if (p.lda0 % 8 != 0 || p.ldo % 4 != 0 || (p.res && p.ldr % 4 != 0)) return 0;
+  return 1;
+}
+
+extern "C" int nr_launch_lin160_w_pack(const bf16* w, int N, int K, bf16* stream, hipStream_t s) {
+  const long long total = (long long)(nr_lin160_stream_bytes(N, K) / 16);
+  if (!total) return 1;
+  hipLaunchKernelGGL(lin160_w_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, stream, N, K);
+  return 0;
+}
+
+extern "C" int nr_launch_lin160(const NrGemmParams* pp, const bf16* stream, hipStream_t s) {
+  const NrGemmParams& g = *pp;
+  if (!stream || g.M % 64 != 0 || g.N % L1_BN != 0 || g.K % 64 != 0 || g.K / 64 < L1_NS) return 1;
+  NrLin160Params p;
+  p.x = g.a0; p.lda = g.lda0; p.stream = stream; p.bias = g.bias; p.res = g.res; p.ldr = g.ldr; p.out = g.out; p.ldo = g.ldo; p.M = g.M; p.N = g.N; p.K = g.K; p.norot = g.plan_m > 0 ? 1 : 0;
+  const int Mp = (g.plan_m > 0 && g.plan_m < g.M) ? g.plan_m : g.M;
+  const int ncb = g.N / L1_BN;
+  // 128-row tiles when they still fill the chip (and the row count allows), else 64-row tiles
+  const bool big = g.M % 128 == 0 && (long long)(Mp / 128) * ncb >= 256;
+  constexpr size_t shm128 = (size_t)L1_NS * (L1_W_STAGE + 128 * 128), shm64 = (size_t)L1_NS * (L1_W_STAGE + 64 * 128);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!(g_l1_attr >> (dev & 63) & 1ull)) {
+    if (hipFuncSetAttribute((const void*)lin160_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm128) != hipSuccess) return 2;
+    if (hipFuncSetAttribute((const void*)lin160_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm64) != hipSuccess) return 2;
+    g_l1_attr |= 1ull << (dev & 63);
+  }
+  if (big) hipLaunchKernelGGL(lin160_kernel<128>, dim3((unsigned)((g.M / 128) * ncb)), dim3(512), shm128, s, p);
+  else hipLaunchKernelGGL(lin160_kernel<64>, dim3((unsigned)((g.M / 64) * ncb)), dim3(512), shm64, s, p);
+  return 0;
+}

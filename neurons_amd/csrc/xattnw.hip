@@ -57,6 +57,15 @@ __device__ __forceinline__ void mfma16_tied(f32x4& acc, const s16x4& a, const s1
 }
 __device__ __forceinline__ void mfma_results(f32x4& acc) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc)); }
 
+#ifdef NR_STAMP
+// diagnostic build only (make stamp, tools/tattnw_timeline.py xattn): shader-clock stamps of wave 0 of the first 512 workgroups.  Slots: 0 entry, 1 prologue
+// issued, 2 + 3 s / 3 + 3 s / 4 + 3 s = stage s after its DMA wait / barrier / MFMAs, 123 K|V pieces issued, 124 K|V landed, 125 kernel end
+__device__ unsigned long long xattnw_stamp_buf[512][128];
+#define XW_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 512 && (slot) < 128) xattnw_stamp_buf[blockIdx.x][(slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define XW_STAMP(slot) do { } while (0)
+#endif
+
 constexpr int XW_HEADS = 8;
 constexpr int XW_KT = 5;                         // key tiles of 16: 80 key slots, Lk <= 80
 constexpr int XW_COLS = 160, XW_NT = 10;         // q columns / weight fragments of a workgroup
@@ -92,6 +101,7 @@ __global__ __launch_bounds__(256, 2) void xattn_head_kernel(NrXAttnWParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
 
+  XW_STAMP(0);
   int rg, cb;
   if (p.xcd_mode == 0) { const int j = blockIdx.x >> 3; cb = j % NCB; rg = (j / NCB) * 8 + (int)(blockIdx.x & 7); }
   else { cb = (int)(blockIdx.x % NCB); rg = blockIdx.x / NCB; }
@@ -120,6 +130,7 @@ __global__ __launch_bounds__(256, 2) void xattn_head_kernel(NrXAttnWParams p) {
 #pragma unroll
     for (int i = 0; i < XW_PPW; ++i) issue_piece(s, s, i);
 
+  XW_STAMP(1);
   f32x4 acc[XW_NT];
 #pragma unroll
   for (int n = 0; n < XW_NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -135,7 +146,9 @@ __global__ __launch_bounds__(256, 2) void xattn_head_kernel(NrXAttnWParams p) {
     if (rem >= XW_NS - 2) wait_vmcnt<(XW_NS - 2) * XW_PPW>();
     else if (rem == 1) wait_vmcnt<XW_PPW>();
     else wait_vmcnt<0>();
+    XW_STAMP(2 + 3 * s);
     __builtin_amdgcn_s_barrier();
+    XW_STAMP(3 + 3 * s);
     const int s_next = s + XW_NS - 1;
     const bool pf = s_next < S;
     int pslot = slot + XW_NS - 1; if (pslot >= XW_NS) pslot -= XW_NS;
@@ -160,6 +173,7 @@ __global__ __launch_bounds__(256, 2) void xattn_head_kernel(NrXAttnWParams p) {
 #pragma unroll
     for (int n = XW_NT / 2; n < XW_NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[n], xa, acc[n], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+    XW_STAMP(4 + 3 * s);
     slot = slot + 1 == XW_NS ? 0 : slot + 1;
   }
 
@@ -170,12 +184,14 @@ __global__ __launch_bounds__(256, 2) void xattn_head_kernel(NrXAttnWParams p) {
 #pragma unroll
     for (int i = 0; i < XW_KV_PIECES; ++i) glds16(kvsrc + (size_t)i * 1024, lds0 + (unsigned)((wave * XW_KV_PIECES + i) * 1024));
   }
+  XW_STAMP(123);
   // LayerNorm statistics of the wave's 16 rows (lane (fr, fg) holds a quarter of row fr's sums) while the images land
   const float mu = xsum_rows(s1) * (1.0f / C);
   const float rstd = rsqrtf(fmaxf(xsum_rows(s2) * (1.0f / C) - mu * mu, 0.f) + p.ln_eps);
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
+  XW_STAMP(124);
   const float* tb = reinterpret_cast<const float*>(smem + XW_NS * XW_STAGE);
   s16x4 qa[XW_NT];
 #pragma unroll
@@ -236,6 +252,7 @@ __global__ __launch_bounds__(256, 2) void xattn_head_kernel(NrXAttnWParams p) {
       nr_store8(orow + 16 * (hh * DT + g), o);
     }
   }
+  XW_STAMP(125);
 }
 
 // fragment-major q weights from the LayerNorm-folded [C][C] bf16 matrix: chunk -> (column block, k-step, fragment n, lane)
@@ -298,6 +315,16 @@ __global__ __launch_bounds__(256) void xattnw_table_pack_kernel(const float* __r
 unsigned long long g_xw_attr = 0;
 
 }  // namespace
+
+#ifdef NR_STAMP
+extern "C" int nr_xattnw_stamp_read(void* dst, size_t bytes, int clear) {
+  const size_t n = bytes < sizeof(xattnw_stamp_buf) ? bytes : sizeof(xattnw_stamp_buf);
+  int rc = 0;
+  if (dst) rc = (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(xattnw_stamp_buf), n, 0, hipMemcpyDeviceToHost);
+  if (clear) { void* d = nullptr; (void)hipGetSymbolAddress(&d, HIP_SYMBOL(xattnw_stamp_buf)); (void)hipMemset(d, 0, sizeof(xattnw_stamp_buf)); }
+  return rc;
+}
+#endif
 
 extern "C" size_t nr_xattnw_wstream_bytes(int C) { return (C == 640 || C == 1280) ? (size_t)(C / XW_COLS) * (C / 32) * XW_W_STAGE : 0; }
 extern "C" size_t nr_xattnw_kvstream_bytes(int C, int nctx) { return (C == 640 || C == 1280) ? (size_t)nctx * (C / XW_COLS) * XW_KV_BLOCK + 4096 : 0; }

@@ -416,6 +416,25 @@ def test_fused_temporal_attention_block_matches_torch(cuda, nbatch, hw, F):
     assert torch.equal(out, ops.tattn_fused(t2, nbatch, hw, gamma, beta, wq, wk, wv, wo, bo, frames=F))
 
 
+@pytest.mark.parametrize("M,N,K,res", [(8192, 640, 640, True), (8192, 640, 640, False), (2048, 1280, 1280, True), (4096, 1280, 640, False), (2112, 640, 1280, True),
+                                        (65536, 640, 640, True), (2048, 320, 640, False)])
+def test_short_k_linear_stage_stream_kernel_matches_torch(cuda, M, N, K, res):
+    """lin160.hip (round 6): the proj_in / to_out Linears of the C = 640 / 1280 levels (K = 640 / 1280, N % 160 == 0, >= 2048 rows) through nr_op_gemm,
+    which routes them as the engine does; against fp32 torch on the same bf16 operands.  Shapes: the headline's two (128-row and 64-row workgroups),
+    mixed N / K, a row count that is a multiple of 64 but not of 128 and not of 8 row groups (the other workgroup order), a large M, N = 320 (two
+    column blocks); with and without the in-place-able residual.  Tolerance as the other MFMA ops."""
+    from neurons_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g, device="cuda")
+    r = torch.randn(M, N, generator=g, device="cuda").to(torch.bfloat16) if res else None
+    ref = a.float() @ w.float().t() + bias + (r.float() if res else 0.0)
+    out = ops.gemm(a, w, bias=bias, res=r)
+    _cmp(f"short-K Linear M={M} N={N} K={K} res={res}", out, ref)
+    assert torch.equal(out, ops.gemm(a, w, bias=bias, res=r))
+
+
 @pytest.mark.parametrize("C,nbatch,hw", [(640, 2, 256), (640, 1, 24), (640, 3, 8), (1280, 2, 64), (1280, 1, 16), (1280, 5, 4), (1280, 3, 12)])
 def test_temporal_attention_head_kernel_matches_torch(cuda, C, nbatch, hw):
     """tattnw.hip (round 6): norm -> (+ positional encoding) -> to_q|k|v -> softmax(q k^T / sqrt(d)) v over the 16 frames of each pixel, d = 80 / 160,

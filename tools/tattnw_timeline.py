@@ -17,6 +17,36 @@ lib = _lib.load()
 lib.nr_tattnw_stamp_read.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
 lib.nr_tattnw_stamp_read.restype = C.c_int
 dev = torch.device("cuda", 0)
+if len(sys.argv) > 1 and sys.argv[1] == "xattn":
+    # the cross-attention head kernel (xattnw.hip): same stamps, + the K | V image wait behind the loop
+    lib.nr_xattnw_stamp_read.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    lib.nr_xattnw_stamp_read.restype = C.c_int
+    for Cc, nimg, hw in ((640, 32, 256), (1280, 32, 64)):
+        S = Cc // 32
+        g = torch.Generator(device=dev).manual_seed(0)
+        t = torch.randn(nimg * hw, Cc, generator=g, device=dev).to(torch.bfloat16)
+        gamma, beta = torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev)
+        wq = torch.randn(Cc, Cc, generator=g, device=dev) * Cc ** -0.5
+        kv = torch.randn(2 * 77, 2 * Cc, generator=g, device=dev).to(torch.bfloat16)
+        buf = np.zeros((512, 128), dtype=np.uint64)
+        rows = []
+        for it in range(8):
+            ops.xattn_head(t, nimg, hw, 16, gamma, beta, wq, kv, 77, reuse_streams=it > 0)
+            torch.cuda.synchronize()
+            assert lib.nr_xattnw_stamp_read(buf.ctypes.data, buf.nbytes, 1) == 0
+            if it < 3:
+                continue
+            st = buf.astype(np.int64)
+            st = st[st[:, 0] > 0]
+            wait = np.mean([st[:, 2 + 3 * s] - (st[:, 1] if s == 0 else st[:, 4 + 3 * (s - 1)]) for s in range(S)], axis=0)
+            bar = np.mean([st[:, 3 + 3 * s] - st[:, 2 + 3 * s] for s in range(S)], axis=0)
+            comp = np.mean([st[:, 4 + 3 * s] - st[:, 3 + 3 * s] for s in range(S)], axis=0)
+            rows.append(dict(wgs=len(st), prologue=np.median(st[:, 1] - st[:, 0]), wait=np.median(wait), barrier=np.median(bar), compute=np.median(comp),
+                             loop=np.median(st[:, 1 + 3 * S] - st[:, 1]), kv_issue=np.median(st[:, 123] - st[:, 1 + 3 * S]), kv_wait=np.median(st[:, 124] - st[:, 123]),
+                             attention=np.median(st[:, 125] - st[:, 124]), life=np.median(st[:, 125] - st[:, 0])))
+        med = {k: float(np.median([r[k] for r in rows])) for k in rows[0]}
+        print(f"xattn_head C={Cc} M={nimg * hw} ({int(med['wgs'])} stamped workgroups, {S} stages): " + " ".join(f"{k}={v:.0f}" for k, v in med.items() if k != "wgs"))
+    sys.exit(0)
 for Cc, nbatch, hw in ((640, 2, 256), (1280, 2, 64), (1280, 2, 16)):
     S = Cc // 32
     g = torch.Generator(device=dev).manual_seed(0)
