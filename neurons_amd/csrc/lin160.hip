@@ -115,24 +115,47 @@ __global__ __launch_bounds__(512) void lin160_kernel(NrLin160Params p) {
     slot = slot + 1 == L1_NS ? 0 : slot + 1;
   }
 
-  // ---- epilogue: lane holds out[r0 + 16 rt + fr][cb 160 + 16 (n0 + n) + 4 fg .. + 3] ----
+  // ---- epilogue: lane holds out[r0 + 16 rt + fr][cb 160 + 16 (n0 + n) + 4 fg .. + 3]: 8 bytes per lane in 32-byte row segments.  v_permlane16_swap between the
+  // column tiles (2 k, 2 k + 1) hands every lane 8 CONSECUTIVE channels (even lane rows: tile 2 k, channels 4 fg .. 4 fg + 7; odd rows: tile 2 k + 1,
+  // channels 4 (fg - 1) ..): 16-byte residual loads and stores in 64-byte row segments (as tattn.hip); an odd last tile keeps the 8-byte form ----
   const int row = r0 + 16 * rt + fr;
-  const int col0 = cb * L1_BN + 16 * n0 + 4 * fg;
-  bf16* orow = p.out + (size_t)row * p.ldo + col0;
-  const bf16* rrow = p.res ? p.res + (size_t)row * p.ldr + col0 : nullptr;
+  const int cbase = cb * L1_BN + 16 * n0;
+  bf16* orow = p.out + (size_t)row * p.ldo + cbase;
+  const bf16* rrow = p.res ? p.res + (size_t)row * p.ldr + cbase : nullptr;
 #pragma unroll
-  for (int n = 0; n < NTW; ++n) {
-    f32x4 v = acc[n];
-    if (p.bias) v += *(const f32x4*)(p.bias + col0 + 16 * n);
+  for (int k = 0; k < NTW / 2; ++k) {
+    f32x4 lo = acc[2 * k], hi = acc[2 * k + 1];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo[e]), __float_as_uint(hi[e]), false, false);
+      lo[e] = __uint_as_float(sw[0]); hi[e] = __uint_as_float(sw[1]);
+    }
+    const int c = 16 * (2 * k + (fg & 1)) + 4 * (fg & 2);
+    if (p.bias) { lo += *(const f32x4*)(p.bias + cbase + c); hi += *(const f32x4*)(p.bias + cbase + c + 4); }
     if (rrow) {
-      const bf16x4 r = *(const bf16x4*)(rrow + 16 * n);
+      const bf16x8 r = *(const bf16x8*)(rrow + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { lo[e] += (float)r[e]; hi[e] += (float)r[4 + e]; }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = (bf16)lo[e]; o[4 + e] = (bf16)hi[e]; }
+    nr_store16(orow + c, o);
+  }
+  if constexpr (NTW % 2 == 1) {
+    constexpr int n = NTW - 1;
+    const int c = 16 * n + 4 * fg;
+    f32x4 v = acc[n];
+    if (p.bias) v += *(const f32x4*)(p.bias + cbase + c);
+    if (rrow) {
+      const bf16x4 r = *(const bf16x4*)(rrow + c);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
     }
     bf16x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-    nr_store8(orow + 16 * n, o);
+    nr_store8(orow + c, o);
   }
 }
 
@@ -168,7 +191,8 @@ extern "C" int nr_lin160_eligible(const NrGemmParams* pp) {
   if (p.out_scale != 1.0f || p.K != p.c0 || (p.K != 640 && p.K != 1280) || p.N % L1_BN != 0 || p.N > 1280) return 0;
   const int Mp = (p.plan_m > 0 && p.plan_m < p.M) ? p.plan_m : p.M;                 // NR_DETERMINISTIC_BATCH: the choice is made per clip
   if (p.M % 64 != 0 || Mp < 2048) return 0;
-  if (p.lda0 % 8 != 0 || p.ldo % 4 != 0 || (p.res && p.ldr % 4 != 0)) return 0;
+  if (p.lda0 % 8 != 0 || p.ldo % 8 != 0 || (p.res && p.ldr % 8 != 0)) return 0;
+  if (Mp > 8192) return 0;           // one round of the chip at the headline shapes; beyond it (config 4: M = 16384 / 65536) the tiled igemm with its 2-3 resident workgroups per CU wins (profiles/r06_lin160_ab.txt)
   return 1;
 }
 

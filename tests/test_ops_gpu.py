@@ -421,8 +421,8 @@ def test_fused_temporal_attention_block_matches_torch(cuda, nbatch, hw, F):
 def test_short_k_linear_stage_stream_kernel_matches_torch(cuda, M, N, K, res):
     """lin160.hip (round 6): the proj_in / to_out Linears of the C = 640 / 1280 levels (K = 640 / 1280, N % 160 == 0, >= 2048 rows) through nr_op_gemm,
     which routes them as the engine does; against fp32 torch on the same bf16 operands.  Shapes: the headline's two (128-row and 64-row workgroups),
-    mixed N / K, a row count that is a multiple of 64 but not of 128 and not of 8 row groups (the other workgroup order), a large M, N = 320 (two
-    column blocks); with and without the in-place-able residual.  Tolerance as the other MFMA ops."""
+    mixed N / K, a row count that is a multiple of 64 but not of 128 and not of 8 row groups (the other workgroup order), N = 320 (two column blocks),
+    a large M (beyond the kernel's 8192-row rule: the tiled igemm serves it); with and without the in-place-able residual.  Tolerance as the other MFMA ops."""
     from neurons_amd import ops
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     a = torch.randn(M, K, generator=g, device="cuda").to(torch.bfloat16)
