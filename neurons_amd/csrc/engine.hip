@@ -3034,6 +3034,23 @@ static void op_fragmajor(NrGemmParams& p, hipStream_t s) {
   p.w_fm = scratch;
 }
 
+// the engine's choice for short-K Linears on 2048..8192 rows (lin160.hip): the stage stream is packed on the launch stream on every call
+static bool op_lin160(const NrGemmParams& p, hipStream_t s) {
+  if (!nr_lin160_eligible(&p)) return false;
+  static bf16* l160 = nullptr;
+  static size_t l160_cap = 0;
+  const size_t need = nr_lin160_stream_bytes(p.N, p.K);
+  if (need > l160_cap) {
+    HIP_OK(hipDeviceSynchronize());
+    if (l160) (void)hipFree(l160);
+    HIP_OK(hipMalloc((void**)&l160, need));
+    l160_cap = need;
+  }
+  LAUNCH_OK(nr_launch_lin160_w_pack(p.w, p.N, p.K, l160, s));
+  LAUNCH_OK(nr_launch_lin160(&p, l160, s));
+  return true;
+}
+
 extern "C" nr_status nr_op_gemm(nr_stream stream, const void* a, int32_t lda, const void* w, const float* bias,
                                 const void* res, int32_t ldr, void* out, int32_t ldo, int32_t M, int32_t N, int32_t K,
                                 int32_t geglu) {
@@ -3043,20 +3060,7 @@ extern "C" nr_status nr_op_gemm(nr_stream stream, const void* a, int32_t lda, co
   p.a0 = (const bf16*)a; p.c0 = K; p.lda0 = lda; p.H = p.W = p.OH = p.OW = 1; p.ksize = 1; p.stride = 1;
   p.w = (const bf16*)w; p.M = M; p.N = N; p.K = K; p.bias = bias; p.res = (const bf16*)res; p.ldr = ldr;
   p.out = (bf16*)out; p.ldo = ldo; p.out_scale = 1.f; p.geglu = geglu; p.rowvec_div = 1;
-  if (nr_lin160_eligible(&p)) {          // the engine's choice for short-K Linears on >= 2048 rows (lin160.hip): stream packed per call
-    static bf16* l160 = nullptr;
-    static size_t l160_cap = 0;
-    const size_t need = nr_lin160_stream_bytes(N, K);
-    if (need > l160_cap) {
-      HIP_OK(hipDeviceSynchronize());
-      if (l160) (void)hipFree(l160);
-      HIP_OK(hipMalloc((void**)&l160, need));
-      l160_cap = need;
-    }
-    LAUNCH_OK(nr_launch_lin160_w_pack(p.w, N, K, l160, (hipStream_t)stream));
-    LAUNCH_OK(nr_launch_lin160(&p, l160, (hipStream_t)stream));
-    return NR_OK;
-  }
+  if (op_lin160(p, (hipStream_t)stream)) return NR_OK;
   op_fragmajor(p, (hipStream_t)stream);
   LAUNCH_OK(nr_launch_igemm(&p, op_workspace(p), (hipStream_t)stream));
   NR_CATCH

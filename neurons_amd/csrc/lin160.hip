@@ -22,6 +22,15 @@ __device__ __forceinline__ void glds16(const void* src, unsigned lds_wave_base) 
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+#ifdef NR_STAMP
+// diagnostic build only (make stamp, tools/tattnw_timeline.py lin160): shader-clock stamps of wave 0 of the first 512 workgroups.  Slots: 0 entry, 1 prologue issued,
+// 2 + 3 s / 3 + 3 s / 4 + 3 s = stage s (< 40) after its DMA wait / barrier / MFMAs, 125 loop end, 126 kernel end
+__device__ unsigned long long lin160_stamp_buf[512][128];
+#define L1_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 512 && (slot) < 128) lin160_stamp_buf[blockIdx.x][(slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define L1_STAMP(slot) do { } while (0)
+#endif
+
 constexpr int L1_BN = 160, L1_NT = 10;
 constexpr int L1_W_STAGE = 24 * 1024;            // 2 k-steps x 10 fragments of 1 KiB + 4 KiB pad: 3 pieces per wave
 constexpr int L1_NS = 3;
@@ -53,6 +62,7 @@ __global__ __launch_bounds__(512) void lin160_kernel(NrLin160Params p) {
   const int rt = BM == 128 ? wave : (wave & 3);          // this wave's row tile
   const int n0 = BM == 128 ? 0 : (wave >> 2) * NTW;     // its first column tile
 
+  L1_STAMP(0);
   const int NCB = p.N / L1_BN, S = p.K >> 6;
   const int nrg = p.M / BM;
   int rg, cb;
@@ -83,6 +93,7 @@ __global__ __launch_bounds__(512) void lin160_kernel(NrLin160Params p) {
 #pragma unroll
     for (int i = 0; i < PPW; ++i) issue_piece(s, s, i);
 
+  L1_STAMP(1);
   f32x4 acc[NTW];
 #pragma unroll
   for (int n = 0; n < NTW; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -92,7 +103,9 @@ __global__ __launch_bounds__(512) void lin160_kernel(NrLin160Params p) {
   int slot = 0;
   for (int s = 0; s < S; ++s) {
     if (s + 1 < S) wait_vmcnt<(L1_NS - 2) * PPW>(); else wait_vmcnt<0>();      // in flight behind stage s: the one stage issued after it
+    if (s < 40) L1_STAMP(2 + 3 * s);
     __builtin_amdgcn_s_barrier();             // every wave's pieces landed; every wave has left stage s - 1 (its slot may be refilled)
+    if (s < 40) L1_STAMP(3 + 3 * s);
     const int s_next = s + L1_NS - 1;
     const bool pf = s_next < S;
     int pslot = slot + L1_NS - 1; if (pslot >= L1_NS) pslot -= L1_NS;
@@ -112,8 +125,10 @@ __global__ __launch_bounds__(512) void lin160_kernel(NrLin160Params p) {
       for (int n = 0; n < NTW; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[n], xa, acc[n], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (s < 40) L1_STAMP(4 + 3 * s);
     slot = slot + 1 == L1_NS ? 0 : slot + 1;
   }
+  L1_STAMP(125);
 
   // ---- epilogue: lane holds out[r0 + 16 rt + fr][cb 160 + 16 (n0 + n) + 4 fg .. + 3]: 8 bytes per lane in 32-byte row segments.  v_permlane16_swap between the
   // column tiles (2 k, 2 k + 1) hands every lane 8 CONSECUTIVE channels (even lane rows: tile 2 k, channels 4 fg .. 4 fg + 7; odd rows: tile 2 k + 1,
@@ -157,6 +172,7 @@ __global__ __launch_bounds__(512) void lin160_kernel(NrLin160Params p) {
     for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
     nr_store8(orow + c, o);
   }
+  L1_STAMP(126);
 }
 
 // fragment-major stream from the row-major [N][K] bf16 matrix: chunk -> (column block, stage, k-step kk, fragment n, lane)
@@ -180,6 +196,16 @@ unsigned long long g_l1_attr = 0;
 
 }  // namespace
 
+#ifdef NR_STAMP
+extern "C" int nr_lin160_stamp_read(void* dst, size_t bytes, int clear) {
+  const size_t n = bytes < sizeof(lin160_stamp_buf) ? bytes : sizeof(lin160_stamp_buf);
+  int rc = 0;
+  if (dst) rc = (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(lin160_stamp_buf), n, 0, hipMemcpyDeviceToHost);
+  if (clear) { void* d = nullptr; (void)hipGetSymbolAddress(&d, HIP_SYMBOL(lin160_stamp_buf)); (void)hipMemset(d, 0, sizeof(lin160_stamp_buf)); }
+  return rc;
+}
+#endif
+
 extern "C" size_t nr_lin160_stream_bytes(int N, int K) { return (N % L1_BN == 0 && K % 64 == 0) ? (size_t)(N / L1_BN) * (K / 64) * L1_W_STAGE : 0; }
 
 // The shapes this kernel is chosen for: plain Linear (one source, no GEGLU / LayerNorm fold / row vector / activation / scale), K = 640 or 1280
@@ -188,6 +214,7 @@ extern "C" int nr_lin160_eligible(const NrGemmParams* pp) {
   static const bool off = getenv("NR_LIN160") && getenv("NR_LIN160")[0] == '0';   // A/B switch
   const NrGemmParams& p = *pp;
   if (off || p.ksize != 1 || p.stride != 1 || p.ups || p.a1 || p.c1 || p.geglu || p.ln_c || p.rowvec || p.act || p.out_f32 || p.tap_inner) return 0;
+  // K = 640 / 1280 only: the long-K folded net.2 | proj_out operand (K = 3200, built as a two-source variant and measured: 54.8 vs 55 us) gains nothing
   if (p.out_scale != 1.0f || p.K != p.c0 || (p.K != 640 && p.K != 1280) || p.N % L1_BN != 0 || p.N > 1280) return 0;
   const int Mp = (p.plan_m > 0 && p.plan_m < p.M) ? p.plan_m : p.M;                 // NR_DETERMINISTIC_BATCH: the choice is made per clip
   if (p.M % 64 != 0 || Mp < 2048) return 0;

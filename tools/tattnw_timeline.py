@@ -47,6 +47,36 @@ if len(sys.argv) > 1 and sys.argv[1] == "xattn":
         med = {k: float(np.median([r[k] for r in rows])) for k in rows[0]}
         print(f"xattn_head C={Cc} M={nimg * hw} ({int(med['wgs'])} stamped workgroups, {S} stages): " + " ".join(f"{k}={v:.0f}" for k, v in med.items() if k != "wgs"))
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "lin160":
+    # the short-K Linear kernel (lin160.hip): 64-channel stages
+    lib.nr_lin160_stamp_read.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    lib.nr_lin160_stamp_read.restype = C.c_int
+    for M, N, K in ((8192, 640, 640), (2048, 1280, 1280)):
+        S = K // 64
+        g = torch.Generator(device=dev).manual_seed(0)
+        a = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16)
+        w = (torch.randn(N, K, generator=g, device=dev) * K ** -0.5).to(torch.bfloat16)
+        r = torch.randn(M, N, generator=g, device=dev).to(torch.bfloat16)
+        bias = torch.zeros(N, device=dev)
+        buf = np.zeros((512, 128), dtype=np.uint64)
+        for res in (None, r):
+            rows = []
+            for it in range(8):
+                ops.gemm(a, w, bias=bias, res=res)
+                torch.cuda.synchronize()
+                assert lib.nr_lin160_stamp_read(buf.ctypes.data, buf.nbytes, 1) == 0
+                if it < 3:
+                    continue
+                st = buf.astype(np.int64)
+                st = st[st[:, 0] > 0]
+                wait = np.mean([st[:, 2 + 3 * s] - (st[:, 1] if s == 0 else st[:, 4 + 3 * (s - 1)]) for s in range(S)], axis=0)
+                bar = np.mean([st[:, 3 + 3 * s] - st[:, 2 + 3 * s] for s in range(S)], axis=0)
+                comp = np.mean([st[:, 4 + 3 * s] - st[:, 3 + 3 * s] for s in range(S)], axis=0)
+                rows.append(dict(wgs=len(st), prologue=np.median(st[:, 1] - st[:, 0]), first_wait=np.median(st[:, 2] - st[:, 1]), wait=np.median(wait), barrier=np.median(bar),
+                                 compute=np.median(comp), loop=np.median(st[:, 125] - st[:, 1]), epilogue=np.median(st[:, 126] - st[:, 125]), life=np.median(st[:, 126] - st[:, 0])))
+            med = {k: float(np.median([q[k] for q in rows])) for k in rows[0]}
+            print(f"lin160 M={M} N={N} K={K} res={int(res is not None)} ({int(med['wgs'])} stamped workgroups, {S} stages): " + " ".join(f"{k}={v:.0f}" for k, v in med.items() if k != "wgs"))
+    sys.exit(0)
 for Cc, nbatch, hw in ((640, 2, 256), (1280, 2, 64), (1280, 2, 16)):
     S = Cc // 32
     g = torch.Generator(device=dev).manual_seed(0)
