@@ -785,7 +785,7 @@ struct nr_net {
       // short-K Linear (K = 640 / 1280) on >= 2048 rows: the stage-stream kernel (lin160.hip) instead of the tiled igemm
       const bf16* stream = dry ? reinterpret_cast<const bf16*>(uintptr_t(16)) : w_lin160(w, Cout, p.K);
       char d[160];
-      snprintf(d, sizeof(d), "lin160 M=%d N=%d K=%d res=%d", p.M, p.N, p.K, o.res ? 1 : 0);
+      snprintf(d, sizeof(d), "lin160 M=%d N=%d K=%d res=%d geglu=%d", p.M, p.N, p.K, o.res ? 1 : 0, p.geglu);
       const double bytes = 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N * (o.res ? 2.0 : 1.0));
       emit([p, stream](hipStream_t s) { LAUNCH_OK(nr_launch_lin160(&p, stream, s)); }, NR_PROF_IGEMM, 2.0 * p.M * (double)p.N * p.K, bytes, d);
       op_tap("lin160", out);
@@ -3091,6 +3091,7 @@ extern "C" nr_status nr_op_ln_gemm(nr_stream stream, const void* a, int32_t lda,
   p.a0 = (const bf16*)a; p.c0 = K; p.lda0 = lda; p.H = p.W = p.OH = p.OW = 1; p.ksize = 1; p.stride = 1;
   p.w = (const bf16*)w_scaled; p.M = M; p.N = N; p.K = K; p.bias = bias_folded; p.res = (const bf16*)res; p.ldr = ldr;
   p.out = (bf16*)out; p.ldo = ldo; p.out_scale = 1.f; p.geglu = geglu; p.rowvec_div = 1; p.ln_c = ln_c; p.ln_eps = eps; p.act = act;
+  if (op_lin160(p, (hipStream_t)stream)) return NR_OK;
   op_fragmajor(p, (hipStream_t)stream);
   LAUNCH_OK(nr_launch_igemm(&p, nullptr, (hipStream_t)stream));
   NR_CATCH

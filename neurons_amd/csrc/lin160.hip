@@ -42,11 +42,18 @@ struct NrLin160Params {
   const bf16* res; int ldr;   // residual [M][ldr] or null (may alias out)
   bf16* out; int ldo;
   int M, N, K;
+  const float* ln_c; float ln_eps;   // GLN variant: LayerNorm folded (W' = gamma W, ln_c[n] = sum_k W'[n][k], bias holds beta . W + b); W rows (16 value | 16 gate)-interleaved
   int norot;               // 1: every workgroup walks the stages from stage 0 (results independent of the row position: NR_DETERMINISTIC_BATCH)
 };
 
-template <int BM>
+// GLN: the LayerNorm-folded GEGLU projection (FeedForward.net[0] behind norm3, motion_module_new.py:441-518): row statistics from the fragments that pass
+// (a wave owns whole rows: BM = 128 only), epilogue out[m][80 cb + 16 i + ..] = v_i gelu(g_i) on the (value, gate) tile pairs a lane holds anyway
+// MODE 0: plain Linear (+ bias, + residual); 1 (GLN): LayerNorm folded + GEGLU (BM = 128).  (A LayerNorm-folded PLAIN mode for the q|k|v projection at
+// M = 512 -- 8 x 24 workgroups of 64 rows -- was built and measured: it costs the keyframe step 0.14 ms against the 128 x 64 igemm tile; removed.)
+template <int BM, int MODE = 0>
 __global__ __launch_bounds__(512) void lin160_kernel(NrLin160Params p) {
+  constexpr bool GLN = MODE == 1;
+  static_assert(!GLN || BM == 128, "the GEGLU variant pairs the (value, gate) tiles inside one wave");
   constexpr int RT = BM / 16;                    // row tiles: 8 / 4
   constexpr int NTW = BM == 128 ? L1_NT : L1_NT / 2;   // column tiles per wave: 10 / 5
   constexpr int A_STAGE = BM * 128;              // rows x 2 k-steps x 64 B: 16 / 8 KiB
@@ -97,6 +104,8 @@ __global__ __launch_bounds__(512) void lin160_kernel(NrLin160Params p) {
   f32x4 acc[NTW];
 #pragma unroll
   for (int n = 0; n < NTW; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float s1 = 0.f, s2 = 0.f;
+  const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
   const unsigned wl = (unsigned)(n0 * 1024 + lane * 16);
   const unsigned al = (unsigned)(L1_W_STAGE + rt * 1024 + fr * 64 + ((fg ^ ((-(fr >> 2)) & 3)) << 4));
 
@@ -113,6 +122,14 @@ __global__ __launch_bounds__(512) void lin160_kernel(NrLin160Params p) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const bf16x8 xa = *(const bf16x8*)(base + al + kk * (RT * 1024));
+      if constexpr (GLN) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bf16x2 pr = {xa[2 * e], xa[2 * e + 1]};
+          s1 = __builtin_amdgcn_fdot2_f32_bf16(pr, one2, s1, false);
+          s2 = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, s2, false);
+        }
+      }
       bf16x8 w[NTW];
 #pragma unroll
       for (int n = 0; n < NTW; ++n) w[n] = *(const bf16x8*)(base + (unsigned)((kk * L1_NT + n) * 1024) + wl);
@@ -130,6 +147,37 @@ __global__ __launch_bounds__(512) void lin160_kernel(NrLin160Params p) {
   }
   L1_STAMP(125);
 
+  if constexpr (GLN) {
+    auto rows_sum = [](float v) {
+      auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+      v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+      auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+      return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+    };
+    const float inv_k = 1.0f / (float)p.K;
+    const float mu = rows_sum(s1) * inv_k;
+    const float rstd = rsqrtf(fmaxf(rows_sum(s2) * inv_k - mu * mu, 0.f) + p.ln_eps);
+    const int row = r0 + 16 * rt + fr;
+    // ---- LayerNorm fold + GEGLU: tiles (2 i, 2 i + 1) of the block are the values / gates of output columns 80 cb + 16 i .. ----
+    const int nb = cb * L1_BN + 4 * fg;
+    bf16* orow = p.out + (size_t)row * p.ldo + cb * (L1_BN / 2) + 4 * fg;
+#pragma unroll
+    for (int i = 0; i < L1_NT / 2; ++i) {
+      const int nv = nb + 32 * i, ng = nv + 16;
+      const f32x4 cv = *(const f32x4*)(p.ln_c + nv), cg = *(const f32x4*)(p.ln_c + ng);
+      const f32x4 bv = *(const f32x4*)(p.bias + nv), bg = *(const f32x4*)(p.bias + ng);
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = (acc[2 * i][e] - mu * cv[e]) * rstd + bv[e];
+        const float g = (acc[2 * i + 1][e] - mu * cg[e]) * rstd + bg[e];
+        o[e] = (bf16)(v * gelu_erf_fast(g));
+      }
+      nr_store8(orow + 16 * i, o);
+    }
+    L1_STAMP(126);
+    return;
+  }
   // ---- epilogue: lane holds out[r0 + 16 rt + fr][cb 160 + 16 (n0 + n) + 4 fg .. + 3]: 8 bytes per lane in 32-byte row segments.  v_permlane16_swap between the
   // column tiles (2 k, 2 k + 1) hands every lane 8 CONSECUTIVE channels (even lane rows: tile 2 k, channels 4 fg .. 4 fg + 7; odd rows: tile 2 k + 1,
   // channels 4 (fg - 1) ..): 16-byte residual loads and stores in 64-byte row segments (as tattn.hip); an odd last tile keeps the 8-byte form ----
@@ -213,6 +261,16 @@ extern "C" size_t nr_lin160_stream_bytes(int N, int K) { return (N % L1_BN == 0 
 extern "C" int nr_lin160_eligible(const NrGemmParams* pp) {
   static const bool off = getenv("NR_LIN160") && getenv("NR_LIN160")[0] == '0';   // A/B switch
   const NrGemmParams& p = *pp;
+  // GLN: the LayerNorm-folded GEGLU projection on FEW rows (the keyframe model's depth-10 levels and the 4 x 4 level of the headline: M = 512, N = 10240,
+  // K = 1280): 4 x 64 workgroups = one round of the chip, each streams its 160 W rows once for 128 rows (tiled igemm: 27-32 us)
+  {
+    static const bool gln_off = getenv("NR_LIN160_GEGLU") && getenv("NR_LIN160_GEGLU")[0] == '0';
+    const int Mg = (p.plan_m > 0 && p.plan_m < p.M) ? p.plan_m : p.M;
+    if (!off && !gln_off && p.geglu && p.ln_c && p.bias && p.ksize == 1 && p.stride == 1 && !p.ups && !p.a1 && !p.c1 && !p.rowvec && !p.act && !p.out_f32 && !p.res &&
+        p.out_scale == 1.0f && p.K == p.c0 && p.K == 1280 && p.N % L1_BN == 0 && p.N >= 8192 && p.M % 128 == 0 && Mg <= 1024 && (long long)(Mg / 128) * (p.N / L1_BN) >= 192 &&
+        p.lda0 % 8 == 0 && p.ldo % 4 == 0)
+      return 2;
+  }
   if (off || p.ksize != 1 || p.stride != 1 || p.ups || p.a1 || p.c1 || p.geglu || p.ln_c || p.rowvec || p.act || p.out_f32 || p.tap_inner) return 0;
   // K = 640 / 1280 only: the long-K folded net.2 | proj_out operand (K = 3200, built as a two-source variant and measured: 54.8 vs 55 us) gains nothing
   if (p.out_scale != 1.0f || p.K != p.c0 || (p.K != 640 && p.K != 1280) || p.N % L1_BN != 0 || p.N > 1280) return 0;
@@ -237,17 +295,31 @@ extern "C" int nr_launch_lin160(const NrGemmParams* pp, const bf16* stream, hipS
   p.x = g.a0; p.lda = g.lda0; p.stream = stream; p.bias = g.bias; p.res = g.res; p.ldr = g.ldr; p.out = g.out; p.ldo = g.ldo; p.M = g.M; p.N = g.N; p.K = g.K; p.norot = g.plan_m > 0 ? 1 : 0;
   const int Mp = (g.plan_m > 0 && g.plan_m < g.M) ? g.plan_m : g.M;
   const int ncb = g.N / L1_BN;
+  p.ln_c = g.ln_c; p.ln_eps = g.ln_eps;
+  if (g.geglu) {
+    if (!g.ln_c || !g.bias || g.M % 128 != 0) return 1;
+    constexpr size_t shm = (size_t)L1_NS * (L1_W_STAGE + 128 * 128);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static unsigned long long done = 0;
+    if (!(done >> (dev & 63) & 1ull)) {
+      if (hipFuncSetAttribute((const void*)lin160_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return 2;
+      done |= 1ull << (dev & 63);
+    }
+    hipLaunchKernelGGL((lin160_kernel<128, 1>), dim3((unsigned)((g.M / 128) * ncb)), dim3(512), shm, s, p);
+    return 0;
+  }
   // 128-row tiles when they still fill the chip (and the row count allows), else 64-row tiles
   const bool big = g.M % 128 == 0 && (long long)(Mp / 128) * ncb >= 256;
   constexpr size_t shm128 = (size_t)L1_NS * (L1_W_STAGE + 128 * 128), shm64 = (size_t)L1_NS * (L1_W_STAGE + 64 * 128);
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!(g_l1_attr >> (dev & 63) & 1ull)) {
-    if (hipFuncSetAttribute((const void*)lin160_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm128) != hipSuccess) return 2;
-    if (hipFuncSetAttribute((const void*)lin160_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm64) != hipSuccess) return 2;
+    if (hipFuncSetAttribute((const void*)lin160_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm128) != hipSuccess) return 2;
+    if (hipFuncSetAttribute((const void*)lin160_kernel<64, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm64) != hipSuccess) return 2;
     g_l1_attr |= 1ull << (dev & 63);
   }
-  if (big) hipLaunchKernelGGL(lin160_kernel<128>, dim3((unsigned)((g.M / 128) * ncb)), dim3(512), shm128, s, p);
-  else hipLaunchKernelGGL(lin160_kernel<64>, dim3((unsigned)((g.M / 64) * ncb)), dim3(512), shm64, s, p);
+  if (big) hipLaunchKernelGGL((lin160_kernel<128, 0>), dim3((unsigned)((g.M / 128) * ncb)), dim3(512), shm128, s, p);
+  else hipLaunchKernelGGL((lin160_kernel<64, 0>), dim3((unsigned)((g.M / 64) * ncb)), dim3(512), shm64, s, p);
   return 0;
 }

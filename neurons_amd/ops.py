@@ -69,11 +69,14 @@ def ff_waves(n):
     _lib.load().nr_ff_set_waves(int(n))
 
 
-def ln_gemm(a, w, gamma, beta, bias=None, res=None, eps=1e-5, act=0):
+def ln_gemm(a, w, gamma, beta, bias=None, res=None, eps=1e-5, act=0, geglu=False):
     """out = Linear(LayerNorm(a)) with the LayerNorm folded into the GEMM (engine: ln_linear).  The folding of gamma / beta
-    into (w_scaled, ln_c, bias_folded) is done here on the host exactly as engine.hip's w_ln_linear does."""
+    into (w_scaled, ln_c, bias_folded) is done here on the host exactly as engine.hip's w_ln_linear does.  ``geglu``: w is a GEGLU projection
+    [value(inner) | gate(inner)] (rows re-ordered here to the engine's 16 / 16 interleave); out = value * gelu(gate), inner columns."""
     _chk_bf16(a, res)
     M, K = a.shape
+    if geglu:
+        w, bias = geglu_permute(w, bias)
     N = w.shape[0]
     wf = w.float()
     ws = (wf * gamma.float()[None]).to(torch.bfloat16).contiguous()
@@ -82,9 +85,10 @@ def ln_gemm(a, w, gamma, beta, bias=None, res=None, eps=1e-5, act=0):
     if bias is not None:
         b = b + bias.float()
     b = b.contiguous()
-    out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    No = N // 2 if geglu else N
+    out = torch.empty(M, No, dtype=torch.bfloat16, device=a.device)
     lib = _lib.load()
-    _lib.check(lib.nr_op_ln_gemm(_stream(), _ptr(a), K, _ptr(ws), _ptr(c), _ptr(b), float(eps), _ptr(res), N, _ptr(out), N, M, N, K, 0,
+    _lib.check(lib.nr_op_ln_gemm(_stream(), _ptr(a), K, _ptr(ws), _ptr(c), _ptr(b), float(eps), _ptr(res), No, _ptr(out), No, M, N, K, 1 if geglu else 0,
                                  int(act)))
     return out
 

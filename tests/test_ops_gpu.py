@@ -435,6 +435,28 @@ def test_short_k_linear_stage_stream_kernel_matches_torch(cuda, M, N, K, res):
     assert torch.equal(out, ops.gemm(a, w, bias=bias, res=r))
 
 
+@pytest.mark.parametrize("M,inner", [(512, 5120), (1024, 5120), (512, 4160), (384, 5120), (256, 5120)])
+def test_layernorm_geglu_projection_on_few_rows_matches_torch(cuda, M, inner):
+    """lin160.hip, LayerNorm-folded GEGLU variant (round 6): FeedForward.net[0] behind norm3 (motion_module_new.py:441-518: hidden, gate = proj(LN(x)).chunk(2);
+    hidden * gelu(gate)) at K = 1280 on few rows -- the keyframe model's depth-10 levels and the 4 x 4 level of the headline (M = 512, N = 2 x 5120) --
+    through nr_op_ln_gemm, which routes as the engine does (other widths / row counts inside the rule too; M = 256 falls outside it -- 128 workgroups -- and runs on the
+    tiled igemm: same expectation).
+    Against fp32 torch on the same bf16 input; tolerance as the other GEGLU tests (erf approximated to 2.5e-5)."""
+    from neurons_amd import ops
+    K = 1280
+    g = torch.Generator(device="cuda").manual_seed(M + inner)
+    a = (torch.randn(M, K, generator=g, device="cuda") * 1.3 + 0.2).to(torch.bfloat16)
+    w = torch.randn(2 * inner, K, generator=g, device="cuda") * K ** -0.5
+    bias = 0.1 * torch.randn(2 * inner, generator=g, device="cuda")
+    gamma = 1.0 + 0.2 * torch.randn(K, generator=g, device="cuda")
+    beta = 0.1 * torch.randn(K, generator=g, device="cuda")
+    h = torch.nn.functional.linear(torch.nn.functional.layer_norm(a.float(), (K,), gamma, beta, 1e-5), w, bias)
+    ref = h[:, :inner] * torch.nn.functional.gelu(h[:, inner:])
+    out = ops.ln_gemm(a, w, gamma, beta, bias=bias, geglu=True)
+    _cmp(f"LayerNorm-folded GEGLU projection M={M} inner={inner}", out, ref, max_tol=3e-2, mean_tol=6e-3)
+    assert torch.equal(out, ops.ln_gemm(a, w, gamma, beta, bias=bias, geglu=True))
+
+
 @pytest.mark.parametrize("C,nbatch,hw", [(640, 2, 256), (640, 1, 24), (640, 3, 8), (1280, 2, 64), (1280, 1, 16), (1280, 5, 4), (1280, 3, 12)])
 def test_temporal_attention_head_kernel_matches_torch(cuda, C, nbatch, hw):
     """tattnw.hip (round 6): norm -> (+ positional encoding) -> to_q|k|v -> softmax(q k^T / sqrt(d)) v over the 16 frames of each pixel, d = 80 / 160,
