@@ -34,6 +34,9 @@ int nr_igemm_splitk_l2_tiles(const NrGemmParams* pp);
 // lin160.hip: short-K Linears (K = 640 / 1280, N % 160 == 0, >= 2048 rows) on fragment-major weights
 size_t nr_lin160_stream_bytes(int N, int K);
 int nr_lin160_eligible(const NrGemmParams* pp);
+int nr_lin160_panel_rule(int Mp, int N, int K);
+size_t nr_lin128q_stream_bytes(int N, int K);
+int nr_launch_lin128q_w_pack(const bf16* w, int N, int K, bf16* stream, hipStream_t s);
 int nr_launch_lin160_w_pack(const bf16* w, int N, int K, bf16* stream, hipStream_t s);
 int nr_launch_lin160(const NrGemmParams* pp, const bf16* stream, hipStream_t s);
 int nr_gn_workspace_floats(int nimg, int hw, int groups, int* pix_per_blk_out, int* nchunk_out);
@@ -416,17 +419,19 @@ struct nr_net {
       return d;
     });
   }
-  // stage stream (lin160.hip) of a converted [N][K] weight matrix, cached as "l160:<its name>"; the row-major matrix stays (other row counts use it)
-  const bf16* w_lin160(const bf16* w, int N, int K) {
+  // stage stream (lin160.hip) of a converted [N][K] weight matrix, cached as "l160:<its name>" ("l128:": the 128-column layout of the register-panel kernel);
+  // the row-major matrix stays (other row counts use it)
+  const bf16* w_lin160(const bf16* w, int N, int K, bool panel = false) {
     std::string src;
     for (const auto& kv : dev) if (kv.second == (const void*)w) { src = kv.first; break; }
     if (src.empty()) throw NrError(NR_ERR_STATE, "w_lin160: not a converted weight matrix");
-    const std::string name = "l160:" + src;
+    const std::string name = (panel ? "l128:" : "l160:") + src;
     return (const bf16*)cached(name, [&]() {
       void* d = nullptr;
-      const size_t nb = nr_lin160_stream_bytes(N, K);
+      const size_t nb = panel ? nr_lin128q_stream_bytes(N, K) : nr_lin160_stream_bytes(N, K);
+      if (!nb) throw NrError(NR_ERR_STATE, "w_lin160: shape has no stage stream");
       HIP_OK(hipMalloc(&d, nb));
-      LAUNCH_OK(nr_launch_lin160_w_pack(w, N, K, (bf16*)d, nullptr));
+      LAUNCH_OK(panel ? nr_launch_lin128q_w_pack(w, N, K, (bf16*)d, nullptr) : nr_launch_lin160_w_pack(w, N, K, (bf16*)d, nullptr));
       HIP_OK(hipDeviceSynchronize());
       dev[name] = d; dev_bytes[name] = nb; weight_bytes += nb;
       return d;
@@ -781,12 +786,12 @@ struct nr_net {
     p.out = out.ptr; p.ldo = out.ld;
     if (ksize == 1 && nr_smallm_eligible(&p))               // M <= 512 Linears: the panel-resident kernel reads fragment-major weights
       p.w_fm = dry ? reinterpret_cast<const bf16*>(uintptr_t(16)) : w_fragmajor(w, Cout, p.K);
-    if (ksize == 1 && !p.w_fm && nr_lin160_eligible(&p)) {
-      // short-K Linear (K = 640 / 1280) on >= 2048 rows: the stage-stream kernel (lin160.hip) instead of the tiled igemm
-      const bf16* stream = dry ? reinterpret_cast<const bf16*>(uintptr_t(16)) : w_lin160(w, Cout, p.K);
+    if (const int l1 = (ksize == 1 && !p.w_fm) ? nr_lin160_eligible(&p) : 0) {
+      // short-K Linear (K = 640 / 1280) on >= 2048 rows: the stage-stream kernel (lin160.hip) instead of the tiled igemm; 4 = its register-panel form
+      const bf16* stream = dry ? reinterpret_cast<const bf16*>(uintptr_t(16)) : w_lin160(w, Cout, p.K, l1 == 4);
       char d[160];
-      snprintf(d, sizeof(d), "lin160 M=%d N=%d K=%d res=%d geglu=%d", p.M, p.N, p.K, o.res ? 1 : 0, p.geglu);
-      const double bytes = 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N * (o.res ? 2.0 : 1.0));
+      snprintf(d, sizeof(d), "%s M=%d N=%d K=%d res=%d geglu=%d ln=%d", l1 == 4 ? "lin160 panel" : "lin160", p.M, p.N, p.K, o.res ? 1 : 0, p.geglu, p.ln_c ? 1 : 0);
+      const double bytes = 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * outC * (o.res ? 2.0 : 1.0));
       emit([p, stream](hipStream_t s) { LAUNCH_OK(nr_launch_lin160(&p, stream, s)); }, NR_PROF_IGEMM, 2.0 * p.M * (double)p.N * p.K, bytes, d);
       op_tap("lin160", out);
       return out;
@@ -982,6 +987,9 @@ struct nr_net {
     // per workgroup, so the folded LayerNorm is free there
     static const bool rowpanel_on = !(getenv("NR_ROWPANEL") && getenv("NR_ROWPANEL")[0] == '0');
     if (rowpanel_on && K == 320 && M >= 4096) fuse = true;
+    // K = 640 wide projections (N >= 3 K) on 2048 .. 8192 rows run on the register-panel form of lin160.hip: statistics from the
+    // register-resident rows once per workgroup, so the fold is free there too (and the LayerNorm launch goes)
+    if (!temporal_pe && !act && nr_lin160_panel_rule((int)M, N, K) && x.rows() % 128 == 0 && x.ld % 8 == 0) fuse = true;
     if (mode) fuse = mode[0] == '1';
     GemmOpt o;
     o.geglu = geglu ? 1 : 0; o.act = act;
@@ -3036,17 +3044,18 @@ static void op_fragmajor(NrGemmParams& p, hipStream_t s) {
 
 // the engine's choice for short-K Linears on 2048..8192 rows (lin160.hip): the stage stream is packed on the launch stream on every call
 static bool op_lin160(const NrGemmParams& p, hipStream_t s) {
-  if (!nr_lin160_eligible(&p)) return false;
+  const int l1 = nr_lin160_eligible(&p);
+  if (!l1) return false;
   static bf16* l160 = nullptr;
   static size_t l160_cap = 0;
-  const size_t need = nr_lin160_stream_bytes(p.N, p.K);
+  const size_t need = l1 == 4 ? nr_lin128q_stream_bytes(p.N, p.K) : nr_lin160_stream_bytes(p.N, p.K);
   if (need > l160_cap) {
     HIP_OK(hipDeviceSynchronize());
     if (l160) (void)hipFree(l160);
     HIP_OK(hipMalloc((void**)&l160, need));
     l160_cap = need;
   }
-  LAUNCH_OK(nr_launch_lin160_w_pack(p.w, p.N, p.K, l160, s));
+  LAUNCH_OK(l1 == 4 ? nr_launch_lin128q_w_pack(p.w, p.N, p.K, l160, s) : nr_launch_lin160_w_pack(p.w, p.N, p.K, l160, s));
   LAUNCH_OK(nr_launch_lin160(&p, l160, s));
   return true;
 }

@@ -27,8 +27,16 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // 2 + 3 s / 3 + 3 s / 4 + 3 s = stage s (< 40) after its DMA wait / barrier / MFMAs, 125 loop end, 126 kernel end
 __device__ unsigned long long lin160_stamp_buf[512][128];
 #define L1_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 512 && (slot) < 128) lin160_stamp_buf[blockIdx.x][(slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+// panel kernel, fine stamps of ONE steady-state stage (g = 11) for wave 0 (rows 0 .. 255 of the buffer) and its SIMD-mate wave 4 (rows 256 .. 511): slots 64 + 3 kk = k-step kk
+// begins, 65 + 3 kk = its DMA burst (if any) issued, 66 + 3 kk = its MFMAs issued; 76 / 77 / 78 = in front of the DMA wait / behind it / behind the barrier (inside k-step 3)
+#ifdef NR_STAMP_FINE
+#define Q_STAMPW(slot) do { if ((threadIdx.x & 63) == 0 && (wave == 0 || wave == 4) && blockIdx.x < 256) lin160_stamp_buf[blockIdx.x + (wave ? 256 : 0)][(slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define Q_STAMPW(slot) do { } while (0)      // (they perturb the stage they measure: every stamp's store drains the DMA ring; kept for relative order only)
+#endif
 #else
 #define L1_STAMP(slot) do { } while (0)
+#define Q_STAMPW(slot) do { } while (0)
 #endif
 
 constexpr int L1_BN = 160, L1_NT = 10;
@@ -240,6 +248,265 @@ __global__ __launch_bounds__(256) void lin160_w_pack_kernel(const bf16* __restri
   *(bf16x8*)(stream + (size_t)idx * 8) = v;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// Row-PANEL form for the LayerNorm-folded wide projections of the C = 640 level (GEGLU projection N = 8 C, fused q|k|v N = 3 C; K = C) on 2048 .. 8192 rows.
+// What bounds lin160_kernel on these shapes is the LDS read port, not the MFMAs: a wave that owns 16 rows reads one 1-KiB W fragment per MFMA
+// (8 waves x 20 fragments = 160 KiB per 64-channel stage = 640 cycles at 256 B/clk against 640 MFMA cycles per SIMD), every workgroup pays prologue and
+// epilogue per 160 columns, and x travels through the ring beside W.  Here:
+//   * the workgroup's 128 rows stay in REGISTERS for the whole launch: wave w holds rows 32 (w & 3) .. + 31 as MFMA B fragments for all of K (2 x 20 x 4 =
+//     160 VGPRs) and computes column half w >> 2 of every 128-column block -- each W fragment read from LDS feeds TWO MFMAs (half the LDS bytes per flop);
+//   * only W streams: J consecutive 128-column blocks per workgroup (column group = blockIdx mod NCG, so the workgroups of an XCD share their J blocks in its
+//     L2; x is read once and needs no locality) as 32-KiB stages of 128 channels (4 k-steps x 8 fragments, no padding; 4 one-KiB LDS-DMA pieces per wave)
+//     through a 4-slot ring that never drains between blocks; every row group starts each block at its own stage (L2 channel spread): the register panel
+//     is loaded in that rotated k order, the unrolled MFMA loop indexes it statically;
+//   * fragment reads run one k-step ahead of the MFMAs (two register banks), across the stage barrier too: the barrier of stage g + 1 sits in front of the
+//     LAST k-step of stage g, whose fragments are in registers by then;
+//   * LayerNorm statistics from the register panel on the matrix unit (x . 1 and the diagonal of x . x^T), once; fold constants (ln_c | bias') of the workgroup's columns in an LDS table;
+//   * block epilogue: out = rstd (acc - mean c) + b' (GEGLU: v . gelu(g) on the (value, gate) tile pairs a wave holds).
+// KS = K / 32 (20).  Grid (M / 128) x NCG, one workgroup per CU.
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+constexpr int Q_BN = 128, Q_NT = 8;
+constexpr int Q_STAGE = 32 * 1024;               // 128 channels: 4 k-steps x 8 fragments of 1 KiB
+constexpr int Q_NS = 4;                          // ring slots (a power of two)
+// Stages between the two column halves of a workgroup.  2 was built and measured (the SIMD-mates' GEGLU epilogues 40 % of a block apart, each under the other's
+// MFMAs): the MFMA wave loses more issue slots to its mate's VALU stream than the serial epilogue costs -- stage 2 217 -> 2 744 cycles, launch 139 k -> 168 k
+// (profiles/r06_lin160p_timeline.txt).  0 = in step.
+constexpr int Q_LAG = 0;
+
+struct NrLin128QParams {
+  const bf16* x; int lda;
+  const bf16* stream;      // [N / 128][K / 128][4 k-steps][8 tiles][64 lanes][8]
+  const float* ln_c; const float* bias; float ln_eps;
+  bf16* out; int ldo;
+  int M, N, J, NCG;
+  int norot;               // 1: every workgroup walks the stages from stage 0 (NR_DETERMINISTIC_BATCH)
+};
+
+template <int KS, bool GEGLU>
+__global__ __launch_bounds__(512) void lin128q_kernel(NrLin128QParams p) {
+  constexpr int K = 32 * KS, S = KS / 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // Q_NS stages of Q_STAGE bytes, then float tab[2][J * 128] (ln_c | bias')
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int rp = wave & 3, ch = wave >> 2;
+  L1_STAMP(0);
+  const int J = p.J;
+  // workgroup -> (row group, column group): the column groups of a row group on ONE XCD (blockIdx mod 8), so x (read once per workgroup, all in the prologue)
+  // crosses the fabric once; every XCD then streams all of W, block by block in step with its row groups (working set: NCG blocks of 160 KiB)
+  int rg, cg;
+  const int nrg = p.M >> 7;
+  if ((nrg & 7) == 0) { const int i = blockIdx.x >> 3; cg = i % p.NCG; rg = (i / p.NCG) * 8 + (int)(blockIdx.x & 7); }
+  else { cg = (int)(blockIdx.x % p.NCG); rg = (int)(blockIdx.x / p.NCG); }
+  const int row0 = rg * 128 + 32 * rp + fr;            // + 16 rt
+  const int rot = p.norot ? 0 : rg % S;                // first stage of every block for this row group
+  const int G = J * S;                                 // stages of this workgroup (>= Q_NS - 1: host)
+
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lptr_t)smem);
+  const char* wbase = reinterpret_cast<const char*>(p.stream) + (size_t)cg * J * ((size_t)S * Q_STAGE) + (size_t)(wave * 4) * 1024 + (size_t)lane * 16;
+  // The two column halves run TWO STAGES APART: ring buffer g carries tiles 0 .. 3 of stream stage g and tiles 4 .. 7 of stream stage g - 2 (a 1-KiB piece is one
+  // (k-step, tile) fragment, so the source is chosen per piece: the odd waves fetch the column-half-1 tiles), the waves of column half 1 hold their panel two stages
+  // further round the rotation, and the loop runs G + 2 stages.  The two waves of a SIMD (w, w + 4) then reach their block epilogues (for GEGLU ~1.7 k cycles of
+  // VALU work per wave against 5 k cycles of MFMAs per block) 40 % of a block apart: each epilogue runs under its SIMD-mate's MFMAs instead of beside its epilogue.
+  const int GT = G + Q_LAG;
+  const int plag = (wave & 1) * Q_LAG;                 // this wave FETCHES tiles of column half (wave & 1)
+  auto issue_piece = [&](int g, int i) {               // piece i (0 .. 3) of this wave for ring stage g -> slot g mod Q_NS
+    int gs = g - plag;                                 // its stream stage; outside 0 .. G - 1 nobody consumes the piece: any valid source keeps the vmcnt bookkeeping uniform
+    gs = gs < 0 ? 0 : (gs >= G ? G - 1 : gs);
+    const int j = gs / S;
+    int st = gs - j * S + rot; if (st >= S) st -= S;
+    glds16(wbase + ((size_t)j * S + st) * Q_STAGE + (size_t)i * 1024, lds0 + (unsigned)((g & (Q_NS - 1)) * Q_STAGE + (wave * 4 + i) * 1024));
+  };
+#pragma unroll
+  for (int g = 0; g < Q_NS - 1; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_piece(g, i);
+
+  L1_STAMP(122);
+  // ---- fold constants of the workgroup's J x 128 columns -> LDS table ----
+  float* tab = reinterpret_cast<float*>(smem + Q_NS * Q_STAGE);
+  for (int i = tid; i < J * Q_BN; i += 512) {
+    tab[i] = p.ln_c[cg * J * Q_BN + i];
+    tab[J * Q_BN + i] = p.bias[cg * J * Q_BN + i];
+  }
+
+  L1_STAMP(123);
+  int rotx = rot - ch * Q_LAG; if (rotx < 0) rotx += S;          // column half 1 meets stream stage s at loop position s + 2
+  // ---- the row panel -> registers (k-step ks of the panel = k-step ks + 4 rotx of the row).  Issued BEHIND the prologue's DMA pieces: the compiler's own
+  // vmcnt for these loads does not know the asm pieces, so they must be the older operations (its waits are then conservative) ----
+  bf16x8 xb[2][KS];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const bf16* xr = p.x + (size_t)(row0 + 16 * rt) * p.lda + 8 * fg;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      int kq = ks + 4 * rotx; if (kq >= KS) kq -= KS;
+      xb[rt][ks] = *(const bf16x8*)(xr + 32 * kq);
+    }
+  }
+  auto rows_sum = [](float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+  };
+  L1_STAMP(124);
+  // row statistics on the MATRIX unit, one pass over the register panel: with A = ones, D[i][r] = sum_k x[r][k] for every i (each lane gets its row's sum);
+  // with A = the fragment itself (the A and B register images of v_mfma_f32_16x16x32_bf16 coincide), D[i][r] = x_i . x_r, whose diagonal is sum_k x[r][k]^2 --
+  // 80 MFMAs per wave (1.3 k cycles) where cvt / add / fma chains cost 2 560 VALU instructions and the dot unit 640 (two waves per SIMD: 20 k / 10 k cycles of prologue)
+  float mu[2], rstd[2];
+  {
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xb[rt][ks], a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb[rt][ks], xb[rt][ks], a2, 0, 0, 0);
+      }
+      // lane (fr, fg) holds D[4 fg + e][fr]: the diagonal element of row fr sits in lane group fg = fr / 4 at e = fr mod 4
+      const int e_d = fr & 3;
+      float d = e_d == 0 ? a2[0] : e_d == 1 ? a2[1] : e_d == 2 ? a2[2] : a2[3];
+      d = (fg == (fr >> 2)) ? d : 0.f;
+      mu[rt] = a1[0] * (1.0f / K);
+      rstd[rt] = rsqrtf(fmaxf(rows_sum(d) * (1.0f / K) - mu[rt] * mu[rt], 0.f) + p.ln_eps);
+    }
+  }
+  L1_STAMP(127);
+  wait_vmcnt<0>();                                   // the panel is the youngest: stages 0 .. Q_NS - 2 of this wave have landed
+  __builtin_amdgcn_s_barrier();                      // ... of every wave, and the table
+  L1_STAMP(1);
+
+  const unsigned wl = (unsigned)((4 * ch) * 1024 + lane * 16);
+  // element offset of this lane's first output of a block's column 0 (32 bits: M ldo < 2^31 elements, host-checked), uniform base + lane offset addressing
+  const unsigned oofs = (unsigned)row0 * (unsigned)p.ldo + (unsigned)((GEGLU ? 16 * (2 * ch) : 16 * (4 * ch)) + 4 * fg);
+  bf16x8 w[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) w[n] = *(const bf16x8*)(smem + (unsigned)(n * 1024) + wl);
+  f32x4 acc[2][4];
+  // block epilogue: lane holds out channels 16 (4 ch + n) + 4 fg .. + 3 of rows row0, row0 + 16 of block jb of the group
+  auto epilogue = [&](int jb) {
+    const int cb = cg * J + jb;
+    const float* tc = tab + jb * Q_BN + 16 * (4 * ch) + 4 * fg;
+    const float* tb = tc + J * Q_BN;
+    if constexpr (GEGLU) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const f32x4 cv = *(const f32x4*)(tc + 32 * i), cgv = *(const f32x4*)(tc + 32 * i + 16);
+        const f32x4 bv = *(const f32x4*)(tb + 32 * i), bg = *(const f32x4*)(tb + 32 * i + 16);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = (acc[rt][2 * i][e] - mu[rt] * cv[e]) * rstd[rt] + bv[e];
+            const float gt = (acc[rt][2 * i + 1][e] - mu[rt] * cgv[e]) * rstd[rt] + bg[e];
+            o[e] = (bf16)(v * gelu_erf_fast(gt));
+          }
+          nr_store8(p.out + (oofs + (unsigned)(16 * rt) * (unsigned)p.ldo + (unsigned)(cb * (Q_BN / 2) + 16 * i)), o);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const f32x4 c4 = *(const f32x4*)(tc + 16 * n), b4 = *(const f32x4*)(tb + 16 * n);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (bf16)((acc[rt][n][e] - mu[rt] * c4[e]) * rstd[rt] + b4[e]);
+          nr_store8(p.out + (oofs + (unsigned)(16 * rt) * (unsigned)p.ldo + (unsigned)(cb * Q_BN + 16 * n)), o);
+        }
+      }
+    }
+  };
+  int g = 0;
+  for (int jj = 0; jj <= J; ++jj) {
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+      if (g >= GT) break;                               // the last pass holds only the Q_LAG stages column half 1 still owes
+      // a block of this wave begins at loop position Q_LAG ch
+      if (st == 0 || st == Q_LAG) {
+        if (st == Q_LAG * ch) {
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[rt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        // ---- where the fragments of the NEXT k-step come from (kk = 3: the next stage, behind its barrier); w[n] is refilled as soon as its two MFMAs are issued ----
+        const unsigned char* nbase = nullptr;
+        if (g == 11) Q_STAMPW(64 + 3 * kk);
+        if (kk < 3) nbase = smem + (g & (Q_NS - 1)) * Q_STAGE + (kk + 1) * (Q_NT * 1024);
+        else if (g + 1 < GT) {
+          if (g == 11) Q_STAMPW(76);
+          // ring stage g + 1 landed: younger pieces of this wave in flight = stages g + 2 and g + 3 (4 each)
+          if (g + 3 < GT) wait_vmcnt<8>();
+          else if (g + 2 < GT) wait_vmcnt<4>();
+          else wait_vmcnt<0>();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of slot g are in registers: the slot may be refilled behind the barrier
+          if (g == 11) Q_STAMPW(77);
+          if (g < 40) L1_STAMP(2 + 3 * g);
+          __builtin_amdgcn_s_barrier();
+          if (g < 40) L1_STAMP(3 + 3 * g);
+          if (g == 11) Q_STAMPW(78);
+          nbase = smem + ((g + 1) & (Q_NS - 1)) * Q_STAGE;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the wave's four DMA pieces of ring stage g + 3 in ONE burst: column half 0 at the head of the stage, column half 1 in its middle
+        if (kk == 2 * ch && g + Q_NS - 1 < GT) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) issue_piece(g + Q_NS - 1, i);
+        }
+        if (g == 11) Q_STAMPW(65 + 3 * kk);
+        __builtin_amdgcn_sched_barrier(0);
+        // (outside a wave's own G stages -- column half 1 in the first Q_LAG, column half 0 in the last Q_LAG -- the MFMAs run on whatever the ring holds: the
+        // accumulators are cleared at the wave's next block start / never read again; a branch round them costs hipcc 900 register copies)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[n], xb[rt][4 * st + kk], acc[rt][n], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (nbase) w[n] = *(const bf16x8*)(nbase + (unsigned)(n * 1024) + wl);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (g == 11) Q_STAMPW(66 + 3 * kk);
+      }
+      if (g < 40) L1_STAMP(4 + 3 * g);
+      ++g;
+      // a block of this wave ends behind loop position S - 1 (column half 0: block jj) / Q_LAG - 1 (column half 1: block jj - 1)
+      if constexpr (Q_LAG == 0) {
+        if (st == S - 1) epilogue(jj);
+      } else {
+        if (st == S - 1) { if (ch == 0 && jj < J) epilogue(jj); }
+        if (st == Q_LAG - 1) { if (ch == 1 && jj > 0) epilogue(jj - 1); }
+      }
+    }
+  }
+  L1_STAMP(125);
+  L1_STAMP(126);
+}
+
+// fragment-major stream of the panel kernel from the row-major [N][K] bf16 matrix: 16-byte chunk -> (column block, stage, k-step, tile, lane)
+__global__ __launch_bounds__(256) void lin128q_w_pack_kernel(const bf16* __restrict__ w, bf16* __restrict__ stream, int N, int K) {
+  const int S = K >> 7, CH_STAGE = Q_STAGE / 16;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)(N / Q_BN) * S * CH_STAGE) return;
+  const int cb = (int)(idx / ((long long)S * CH_STAGE));
+  int c = (int)(idx - (long long)cb * S * CH_STAGE);
+  const int st = c / CH_STAGE;
+  c -= st * CH_STAGE;
+  const int kk = c / (Q_NT * 64), n = (c / 64) % Q_NT, lane = c & 63;
+  *(bf16x8*)(stream + (size_t)idx * 8) = *(const bf16x8*)(w + (size_t)(cb * Q_BN + 16 * n + (lane & 15)) * K + 128 * st + 32 * kk + 8 * (lane >> 4));
+}
+
 unsigned long long g_l1_attr = 0;
 
 }  // namespace
@@ -258,9 +525,30 @@ extern "C" size_t nr_lin160_stream_bytes(int N, int K) { return (N % L1_BN == 0 
 
 // The shapes this kernel is chosen for: plain Linear (one source, no GEGLU / LayerNorm fold / row vector / activation / scale), K = 640 or 1280
 // (the short-K regime), N a multiple of 160, >= 2048 rows in whole 64-row groups
+// PANEL rule (rows of one clip, N, K): the LayerNorm-folded wide projections (GEGLU N = 8 C, q|k|v N = 3 C) at K = C = 640 on 2048 .. NR_LIN160_PANEL_MAXM rows
+extern "C" int nr_lin160_panel_rule(int Mp, int N, int K) {
+  static const bool off = (getenv("NR_LIN160") && getenv("NR_LIN160")[0] == '0') || (getenv("NR_LIN160_PANEL") && getenv("NR_LIN160_PANEL")[0] == '0');   // A/B switches
+  static const int maxm = getenv("NR_LIN160_PANEL_MAXM") ? atoi(getenv("NR_LIN160_PANEL_MAXM")) : 8192;
+  return !off && K == 640 && N % Q_BN == 0 && N >= 3 * K && Mp >= 2048 && Mp <= maxm;
+}
+extern "C" size_t nr_lin128q_stream_bytes(int N, int K) { return (N % Q_BN == 0 && K % 128 == 0) ? (size_t)N * K * sizeof(bf16) : 0; }
+extern "C" int nr_launch_lin128q_w_pack(const bf16* w, int N, int K, bf16* stream, hipStream_t s) {
+  const long long total = (long long)(nr_lin128q_stream_bytes(N, K) / 16);
+  if (!total) return 1;
+  hipLaunchKernelGGL(lin128q_w_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, stream, N, K);
+  return 0;
+}
+
 extern "C" int nr_lin160_eligible(const NrGemmParams* pp) {
   static const bool off = getenv("NR_LIN160") && getenv("NR_LIN160")[0] == '0';   // A/B switch
   const NrGemmParams& p = *pp;
+  // PANEL: register-resident rows, W streamed
+  {
+    const int Mq = (p.plan_m > 0 && p.plan_m < p.M) ? p.plan_m : p.M;
+    if (p.ln_c && p.bias && p.ksize == 1 && p.stride == 1 && !p.ups && !p.a1 && !p.c1 && !p.rowvec && !p.act && !p.out_f32 && !p.res &&
+        p.out_scale == 1.0f && p.K == p.c0 && nr_lin160_panel_rule(Mq, p.N, p.K) && p.M % 128 == 0 && p.lda0 % 8 == 0 && p.ldo % 4 == 0)
+      return 4;
+  }
   // GLN: the LayerNorm-folded GEGLU projection on FEW rows (the keyframe model's depth-10 levels and the 4 x 4 level of the headline: M = 512, N = 10240,
   // K = 1280): 4 x 64 workgroups = one round of the chip, each streams its 160 W rows once for 128 rows (tiled igemm: 27-32 us)
   {
@@ -290,10 +578,42 @@ extern "C" int nr_launch_lin160_w_pack(const bf16* w, int N, int K, bf16* stream
 
 extern "C" int nr_launch_lin160(const NrGemmParams* pp, const bf16* stream, hipStream_t s) {
   const NrGemmParams& g = *pp;
-  if (!stream || g.M % 64 != 0 || g.N % L1_BN != 0 || g.K % 64 != 0 || g.K / 64 < L1_NS) return 1;
+  if (!stream) return 1;
+  const int Mp = (g.plan_m > 0 && g.plan_m < g.M) ? g.plan_m : g.M;
+  if (g.ln_c && nr_lin160_panel_rule(Mp, g.N, g.K)) {            // PANEL form (stream = the nr_lin128q layout)
+    if (!g.bias || g.M % 128 != 0 || g.K != 640 || (long long)g.M * g.ldo >= (1ll << 31)) return 1;
+    NrLin128QParams q;
+    q.x = g.a0; q.lda = g.lda0; q.stream = stream; q.ln_c = g.ln_c; q.bias = g.bias; q.ln_eps = g.ln_eps; q.out = g.out; q.ldo = g.ldo; q.M = g.M; q.N = g.N; q.norot = g.plan_m > 0 ? 1 : 0;
+    // J column blocks per workgroup (NCG = ncb / J column groups): the divisor of ncb with the fewest stage-times for the launch -- rounds of the chip x (J S stages + ~6
+    // stage-times of prologue / epilogue); ties -> the larger J
+    const int ncq = g.N / Q_BN, S = g.K / 128, nrg = g.M / 128;
+    static const int j_force = getenv("NR_LIN160_PANEL_J") ? atoi(getenv("NR_LIN160_PANEL_J")) : 0;   // sweep aid
+    int J = 0; long long best = 0;
+    for (int c = 1; c <= 16 && c <= ncq; ++c) {
+      if (ncq % c != 0 || c * S < Q_NS - 1) continue;
+      const long long wgs = (long long)nrg * (ncq / c), cost = ((wgs + 255) / 256) * (c * S + 6);
+      if (!J || cost <= best) { J = c; best = cost; }
+    }
+    if (j_force > 0 && ncq % j_force == 0 && j_force <= 16) J = j_force;
+    if (!J) return 1;
+    q.J = J; q.NCG = ncq / J;
+    const size_t shm = (size_t)Q_NS * Q_STAGE + (size_t)2 * J * Q_BN * sizeof(float);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static unsigned long long done = 0;
+    if (!(done >> (dev & 63) & 1ull)) {
+      const void* ks[2] = {(const void*)lin128q_kernel<20, true>, (const void*)lin128q_kernel<20, false>};
+      for (const void* kf : ks) if (hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)Q_NS * Q_STAGE + 2 * 16 * Q_BN * sizeof(float))) != hipSuccess) return 2;
+      done |= 1ull << (dev & 63);
+    }
+    const dim3 grid((unsigned)(nrg * q.NCG));
+    if (g.geglu) hipLaunchKernelGGL((lin128q_kernel<20, true>), grid, dim3(512), shm, s, q);
+    else hipLaunchKernelGGL((lin128q_kernel<20, false>), grid, dim3(512), shm, s, q);
+    return 0;
+  }
+  if (g.M % 64 != 0 || g.N % L1_BN != 0 || g.K % 64 != 0 || g.K / 64 < L1_NS) return 1;
   NrLin160Params p;
   p.x = g.a0; p.lda = g.lda0; p.stream = stream; p.bias = g.bias; p.res = g.res; p.ldr = g.ldr; p.out = g.out; p.ldo = g.ldo; p.M = g.M; p.N = g.N; p.K = g.K; p.norot = g.plan_m > 0 ? 1 : 0;
-  const int Mp = (g.plan_m > 0 && g.plan_m < g.M) ? g.plan_m : g.M;
   const int ncb = g.N / L1_BN;
   p.ln_c = g.ln_c; p.ln_eps = g.ln_eps;
   if (g.geglu) {

@@ -457,6 +457,28 @@ def test_layernorm_geglu_projection_on_few_rows_matches_torch(cuda, M, inner):
     assert torch.equal(out, ops.ln_gemm(a, w, gamma, beta, bias=bias, geglu=True))
 
 
+@pytest.mark.parametrize("M,K,N,geglu", [(8192, 640, 5120, True), (8192, 640, 1920, False), (2176, 640, 5120, True), (4096, 640, 2560, True), (3072, 640, 2048, False),
+                                           (2048, 640, 5120, True), (2048, 640, 1920, False), (2048, 1280, 10240, True), (2048, 1280, 3840, False)])
+def test_layernorm_wide_projection_register_panel_matches_torch(cuda, M, K, N, geglu):
+    """lin160.hip, register-panel form (round 6): the LayerNorm-folded wide projections of the C = 640 level on 2048 .. 8192 rows -- FeedForward.net[0]
+    (GEGLU, N = 8 C; motion_module_new.py:441-518) and the spatial self-attention's fused to_q|to_k|to_v (N = 3 C; motion_module_new.py:201-230 behind norm1,
+    attention.py:272-285) -- through nr_op_ln_gemm, which routes as the engine does.  The headline's two shapes, an odd row-group count, column-block counts
+    with other divisors (J = 10 / 5 / 4 / 16), few row groups (several rounds of workgroups); the K = 1280 shapes run on the tiled igemm (same expectation).
+    Against fp32 torch on the same bf16 input; rows offset from zero mean so that the two-pass statistics matter."""
+    from neurons_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g, device="cuda") * 1.3 + 0.7).to(torch.bfloat16)
+    w = torch.randn(N, K, generator=g, device="cuda") * K ** -0.5
+    bias = 0.1 * torch.randn(N, generator=g, device="cuda")
+    gamma = 1.0 + 0.2 * torch.randn(K, generator=g, device="cuda")
+    beta = 0.1 * torch.randn(K, generator=g, device="cuda")
+    h = torch.nn.functional.linear(torch.nn.functional.layer_norm(a.float(), (K,), gamma, beta, 1e-5), w, bias)
+    ref = h[:, :N // 2] * torch.nn.functional.gelu(h[:, N // 2:]) if geglu else h
+    out = ops.ln_gemm(a, w, gamma, beta, bias=bias, geglu=geglu)
+    _cmp(f"LayerNorm-folded wide projection (register panel) M={M} N={N} K={K} geglu={geglu}", out, ref, max_tol=3e-2, mean_tol=6e-3)
+    assert torch.equal(out, ops.ln_gemm(a, w, gamma, beta, bias=bias, geglu=geglu))
+
+
 @pytest.mark.parametrize("C,nbatch,hw", [(640, 2, 256), (640, 1, 24), (640, 3, 8), (1280, 2, 64), (1280, 1, 16), (1280, 5, 4), (1280, 3, 12)])
 def test_temporal_attention_head_kernel_matches_torch(cuda, C, nbatch, hw):
     """tattnw.hip (round 6): norm -> (+ positional encoding) -> to_q|k|v -> softmax(q k^T / sqrt(d)) v over the 16 frames of each pixel, d = 80 / 160,

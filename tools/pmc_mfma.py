@@ -26,7 +26,7 @@ for k in busy:
     if act[k] <= 0:
         continue
     util = busy[k] / (1024.0 * act[k] / 8.0)
-    if "igemm" in k or "g8p_kernel" in k or "rowpanel" in k or "ff_fused" in k or "tattn_fused" in k or "tattn_head" in k or "xattn_fused" in k or "xattn_head" in k or "lin160_kernel" in k or "smallm_kernel" in k:
+    if "igemm" in k or "g8p_kernel" in k or "rowpanel" in k or "ff_fused" in k or "tattn_fused" in k or "tattn_head" in k or "xattn_fused" in k or "xattn_head" in k or "lin160_kernel" in k or "lin128q_kernel" in k or "smallm_kernel" in k:
         tb += busy[k]; ta += act[k]
     res[k] = {"launches": calls[k], "mfma_util": round(util, 4)}
 res["_igemm_class"] = {"mfma_util": round(tb / (1024.0 * ta / 8.0), 4) if ta else None}

@@ -35,7 +35,7 @@ def load(d, counter):
             e[0] += v
             e[1] += 1
             if ("igemm_bf16_kernel" in name or "splitk_reduce" in name or "rowpanel_kernel" in name or "ff_fused_kernel" in name
-                    or "tattn_fused_kernel" in name or "tattn_head_kernel" in name or "xattn_head_kernel" in name or "lin160_kernel" in name or "g8p_kernel" in name or "smallm_kernel" in name or "xattn_fused_kernel" in name):
+                    or "tattn_fused_kernel" in name or "tattn_head_kernel" in name or "xattn_head_kernel" in name or "lin160_kernel" in name or "lin128q_kernel" in name or "g8p_kernel" in name or "smallm_kernel" in name or "xattn_fused_kernel" in name):
                 ig += v
                 n_ig += 1
     return tot, ig, n_ig

@@ -47,6 +47,53 @@ if len(sys.argv) > 1 and sys.argv[1] == "xattn":
         med = {k: float(np.median([r[k] for r in rows])) for k in rows[0]}
         print(f"xattn_head C={Cc} M={nimg * hw} ({int(med['wgs'])} stamped workgroups, {S} stages): " + " ".join(f"{k}={v:.0f}" for k, v in med.items() if k != "wgs"))
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "lin160p":
+    # the register-panel form of lin160.hip (LayerNorm-folded wide projections): the first 40 stages of a workgroup are stamped; "block_gap" = from the last
+    # stage of a column block to the first wait of the next one (the block's epilogue)
+    lib.nr_lin160_stamp_read.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    lib.nr_lin160_stamp_read.restype = C.c_int
+    for M, K, N, geglu in ((8192, 640, 5120, True), (8192, 640, 1920, False)):
+        S = K // 128                      # 128-channel stages
+        g = torch.Generator(device=dev).manual_seed(0)
+        a = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16)
+        w = torch.randn(N, K, generator=g, device=dev) * K ** -0.5
+        bias = torch.zeros(N, device=dev)
+        gamma, beta = torch.ones(K, device=dev), torch.zeros(K, device=dev)
+        buf = np.zeros((512, 128), dtype=np.uint64)
+        rows = []
+        for it in range(8):
+            ops.ln_gemm(a, w, gamma, beta, bias=bias, geglu=geglu)
+            torch.cuda.synchronize()
+            assert lib.nr_lin160_stamp_read(buf.ctypes.data, buf.nbytes, 1) == 0
+            if it < 3:
+                continue
+            st = buf.astype(np.int64)
+            st = st[st[:, 0] > 0]
+            NST = 40 if st[:, 2 + 3 * 39].min() > 0 else S * int((st[0, 2:122:3] > 0).sum() // S)
+            inblock = [s_ for s_ in range(NST) if s_ % S != 0]
+            wait = np.mean([st[:, 2 + 3 * s_] - st[:, 4 + 3 * (s_ - 1)] for s_ in inblock], axis=0)
+            gaps = [st[:, 2 + 3 * s_] - st[:, 4 + 3 * (s_ - 1)] for s_ in range(S, NST, S)]
+            bar = np.mean([st[:, 3 + 3 * s_] - st[:, 2 + 3 * s_] for s_ in range(NST)], axis=0)
+            comp = np.mean([st[:, 4 + 3 * s_] - st[:, 3 + 3 * s_] for s_ in range(NST)], axis=0)
+            # stamps of stage g: 2 + 3 g = in front of the barrier of stage g + 1 (which sits before the LAST k-step of stage g), 3 + 3 g behind it, 4 + 3 g = stage g's MFMAs issued.
+            # "k012" = end of stage g - 1 -> that barrier (k-steps 0 .. 2 of stage g + the DMA wait), "k3" = the last k-step; "block_first" = k012 of the first stage of a
+            # block (it holds the previous block's epilogue)
+            rows.append(dict(wgs=len(st), stamped_stages=NST, prologue=np.median(st[:, 1] - st[:, 0]), pro_dma_issue=np.median(st[:, 122] - st[:, 0]), pro_table=np.median(st[:, 123] - st[:, 122]),
+                             pro_x_issue=np.median(st[:, 124] - st[:, 123]), pro_stats=np.median(st[:, 127] - st[:, 124]), pro_barrier=np.median(st[:, 1] - st[:, 127]),
+                             k012=np.median(wait), barrier=np.median(bar),
+                             k3=np.median(comp), block_first=np.median(np.mean(gaps, axis=0)) if gaps else 0.0,
+                             stage_avg=np.median((st[:, 4 + 3 * (NST - 1)] - st[:, 1]) / NST), life=np.median(st[:, 126] - st[:, 0])))
+            if it == 7 and (buf[256:512, 64] > 0).any():
+                # fine stamps of stage 11: wave 0 (rows < 256) and its SIMD-mate wave 4, relative to wave 0's k-step 0 begin
+                full = buf.astype(np.int64)
+                w0, w4 = full[:256], full[256:512]
+                ok = (w0[:, 64] > 0) & (w4[:, 64] > 0)
+                t0 = w0[ok, 64]
+                names = ["k0", "k0 dma", "k0 mfma", "k1", "k1 dma", "k1 mfma", "k2", "k2 dma", "k2 mfma", "k3", "k3 dma", "k3 mfma", "pre-wait", "post-wait", "post-barrier"]
+                print("   stage 11, medians rel. to wave 0's k0: " + "  ".join(f"{n_}: {np.median(w0[ok, 64 + i_] - t0):.0f}/{np.median(w4[ok, 64 + i_] - t0):.0f}" for i_, n_ in enumerate(names)))
+        med = {k: float(np.median([q[k] for q in rows])) for k in rows[0]}
+        print(f"lin160p M={M} N={N} K={K} geglu={int(geglu)} ({int(med['wgs'])} stamped workgroups, {S} stages per block): " + " ".join(f"{k}={v:.0f}" for k, v in med.items() if k != "wgs"))
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "lin160":
     # the short-K Linear kernel (lin160.hip): 64-channel stages
     lib.nr_lin160_stamp_read.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
