@@ -27,6 +27,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // 2 + 3 s / 3 + 3 s / 4 + 3 s = stage s (< 40) after its DMA wait / barrier / MFMAs, 125 loop end, 126 kernel end
 __device__ unsigned long long lin160_stamp_buf[512][128];
 #define L1_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 512 && (slot) < 128) lin160_stamp_buf[blockIdx.x][(slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+// panel kernel, TIMING-ONLY ablations of its stage loop (results wrong; stamp build only, compile-time template argument chosen by NR_Q_DBG at launch; bits: 1 no stage
+// barrier, 2 no DMA pieces in the loop, 4 no fragment reads in the loop, 8 no MFMAs, 16 no DMA wait, 32 no block epilogue)
+#define Q_DBG(bit) (DBG & (bit))
 // panel kernel, fine stamps of ONE steady-state stage (g = 11) for wave 0 (rows 0 .. 255 of the buffer) and its SIMD-mate wave 4 (rows 256 .. 511): slots 64 + 3 kk = k-step kk
 // begins, 65 + 3 kk = its DMA burst (if any) issued, 66 + 3 kk = its MFMAs issued; 76 / 77 / 78 = in front of the DMA wait / behind it / behind the barrier (inside k-step 3)
 #ifdef NR_STAMP_FINE
@@ -37,6 +40,7 @@ __device__ unsigned long long lin160_stamp_buf[512][128];
 #else
 #define L1_STAMP(slot) do { } while (0)
 #define Q_STAMPW(slot) do { } while (0)
+#define Q_DBG(bit) 0
 #endif
 
 constexpr int L1_BN = 160, L1_NT = 10;
@@ -269,10 +273,9 @@ __global__ __launch_bounds__(256) void lin160_w_pack_kernel(const bf16* __restri
 constexpr int Q_BN = 128, Q_NT = 8;
 constexpr int Q_STAGE = 32 * 1024;               // 128 channels: 4 k-steps x 8 fragments of 1 KiB
 constexpr int Q_NS = 4;                          // ring slots (a power of two)
-// Stages between the two column halves of a workgroup.  2 was built and measured (the SIMD-mates' GEGLU epilogues 40 % of a block apart, each under the other's
-// MFMAs): the MFMA wave loses more issue slots to its mate's VALU stream than the serial epilogue costs -- stage 2 217 -> 2 744 cycles, launch 139 k -> 168 k
-// (profiles/r06_lin160p_timeline.txt).  0 = in step.
-constexpr int Q_LAG = 0;
+// (Built, measured and removed: the two column halves of a workgroup TWO STAGES APART -- ring buffer g carrying tiles 0 .. 3 of stream stage g and tiles 4 .. 7 of
+// stage g - 2, so that the GEGLU epilogues of the two waves of a SIMD fall 40 % of a block apart, each under its mate's MFMAs: the MFMA wave lost more issue slots to
+// its mate's VALU stream than the serial epilogue costs, launch 139 k -> 168 k cycles.)
 
 struct NrLin128QParams {
   const bf16* x; int lda;
@@ -283,7 +286,7 @@ struct NrLin128QParams {
   int norot;               // 1: every workgroup walks the stages from stage 0 (NR_DETERMINISTIC_BATCH)
 };
 
-template <int KS, bool GEGLU>
+template <int KS, bool GEGLU, int DBG = 0>
 __global__ __launch_bounds__(512) void lin128q_kernel(NrLin128QParams p) {
   constexpr int K = 32 * KS, S = KS / 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // Q_NS stages of Q_STAGE bytes, then float tab[2][J * 128] (ln_c | bias')
@@ -306,15 +309,8 @@ __global__ __launch_bounds__(512) void lin128q_kernel(NrLin128QParams p) {
 
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lptr_t)smem);
   const char* wbase = reinterpret_cast<const char*>(p.stream) + (size_t)cg * J * ((size_t)S * Q_STAGE) + (size_t)(wave * 4) * 1024 + (size_t)lane * 16;
-  // The two column halves run TWO STAGES APART: ring buffer g carries tiles 0 .. 3 of stream stage g and tiles 4 .. 7 of stream stage g - 2 (a 1-KiB piece is one
-  // (k-step, tile) fragment, so the source is chosen per piece: the odd waves fetch the column-half-1 tiles), the waves of column half 1 hold their panel two stages
-  // further round the rotation, and the loop runs G + 2 stages.  The two waves of a SIMD (w, w + 4) then reach their block epilogues (for GEGLU ~1.7 k cycles of
-  // VALU work per wave against 5 k cycles of MFMAs per block) 40 % of a block apart: each epilogue runs under its SIMD-mate's MFMAs instead of beside its epilogue.
-  const int GT = G + Q_LAG;
-  const int plag = (wave & 1) * Q_LAG;                 // this wave FETCHES tiles of column half (wave & 1)
-  auto issue_piece = [&](int g, int i) {               // piece i (0 .. 3) of this wave for ring stage g -> slot g mod Q_NS
-    int gs = g - plag;                                 // its stream stage; outside 0 .. G - 1 nobody consumes the piece: any valid source keeps the vmcnt bookkeeping uniform
-    gs = gs < 0 ? 0 : (gs >= G ? G - 1 : gs);
+  auto issue_piece = [&](int g, int i) {               // piece i (0 .. 3) of this wave for stage g -> slot g mod Q_NS
+    const int gs = g < G ? g : G - 1;                  // behind the last stage nobody consumes the piece: a valid source keeps the loop branch-free and its vmcnt constant
     const int j = gs / S;
     int st = gs - j * S + rot; if (st >= S) st -= S;
     glds16(wbase + ((size_t)j * S + st) * Q_STAGE + (size_t)i * 1024, lds0 + (unsigned)((g & (Q_NS - 1)) * Q_STAGE + (wave * 4 + i) * 1024));
@@ -333,7 +329,7 @@ __global__ __launch_bounds__(512) void lin128q_kernel(NrLin128QParams p) {
   }
 
   L1_STAMP(123);
-  int rotx = rot - ch * Q_LAG; if (rotx < 0) rotx += S;          // column half 1 meets stream stage s at loop position s + 2
+  const int rotx = rot;
   // ---- the row panel -> registers (k-step ks of the panel = k-step ks + 4 rotx of the row).  Issued BEHIND the prologue's DMA pieces: the compiler's own
   // vmcnt for these loads does not know the asm pieces, so they must be the older operations (its waits are then conservative) ----
   bf16x8 xb[2][KS];
@@ -425,72 +421,51 @@ __global__ __launch_bounds__(512) void lin128q_kernel(NrLin128QParams p) {
       }
     }
   };
+  // The stage loop is STRAIGHT-LINE code: no branch inside a stage (hipcc loses its lgkmcnt bookkeeping at every join and waits for ALL fragment reads in front of the
+  // next MFMA pair: a k-step cost 360 cycles for 256 of MFMAs).  Hence: the fragments of the next k-step are always read (behind the last stage: stale bytes nobody uses),
+  // the DMA burst and the stage barrier are unconditional (pieces behind the last stage re-fetch its bytes), the first k-step of a block accumulates onto one zero quad.
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   int g = 0;
-  for (int jj = 0; jj <= J; ++jj) {
+  for (int j = 0; j < J; ++j) {
 #pragma unroll
     for (int st = 0; st < S; ++st) {
-      if (g >= GT) break;                               // the last pass holds only the Q_LAG stages column half 1 still owes
-      // a block of this wave begins at loop position Q_LAG ch
-      if (st == 0 || st == Q_LAG) {
-        if (st == Q_LAG * ch) {
-#pragma unroll
-          for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) acc[rt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      }
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         // ---- where the fragments of the NEXT k-step come from (kk = 3: the next stage, behind its barrier); w[n] is refilled as soon as its two MFMAs are issued ----
-        const unsigned char* nbase = nullptr;
-        if (g == 11) Q_STAMPW(64 + 3 * kk);
+        const unsigned char* nbase;
         if (kk < 3) nbase = smem + (g & (Q_NS - 1)) * Q_STAGE + (kk + 1) * (Q_NT * 1024);
-        else if (g + 1 < GT) {
-          if (g == 11) Q_STAMPW(76);
-          // ring stage g + 1 landed: younger pieces of this wave in flight = stages g + 2 and g + 3 (4 each)
-          if (g + 3 < GT) wait_vmcnt<8>();
-          else if (g + 2 < GT) wait_vmcnt<4>();
-          else wait_vmcnt<0>();
+        else {
+          if (!Q_DBG(16)) wait_vmcnt<8>();                       // stage g + 1 landed: younger pieces of this wave in flight = stages g + 2 and g + 3 (4 each)
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of slot g are in registers: the slot may be refilled behind the barrier
-          if (g == 11) Q_STAMPW(77);
           if (g < 40) L1_STAMP(2 + 3 * g);
-          __builtin_amdgcn_s_barrier();
+          if (!Q_DBG(1)) __builtin_amdgcn_s_barrier();
           if (g < 40) L1_STAMP(3 + 3 * g);
-          if (g == 11) Q_STAMPW(78);
           nbase = smem + ((g + 1) & (Q_NS - 1)) * Q_STAGE;
         }
         __builtin_amdgcn_sched_barrier(0);
-        // the wave's four DMA pieces of ring stage g + 3 in ONE burst: column half 0 at the head of the stage, column half 1 in its middle
-        if (kk == 2 * ch && g + Q_NS - 1 < GT) {
+        // the wave's four DMA pieces of stage g + 3 in one burst at the head of the stage (staggering the two waves of a SIMD measured the same)
+        if (kk == 0 && !Q_DBG(2)) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) issue_piece(g + Q_NS - 1, i);
         }
-        if (g == 11) Q_STAMPW(65 + 3 * kk);
         __builtin_amdgcn_sched_barrier(0);
-        // (outside a wave's own G stages -- column half 1 in the first Q_LAG, column half 0 in the last Q_LAG -- the MFMAs run on whatever the ring holds: the
-        // accumulators are cleared at the wave's next block start / never read again; a branch round them costs hipcc 900 register copies)
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
 #pragma unroll
-          for (int rt = 0; rt < 2; ++rt) acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[n], xb[rt][4 * st + kk], acc[rt][n], 0, 0, 0);
+          for (int rt = 0; rt < 2; ++rt)
+            if (!Q_DBG(8)) acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[n], xb[rt][4 * st + kk], (st == 0 && kk == 0) ? zero4 : acc[rt][n], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
-          if (nbase) w[n] = *(const bf16x8*)(nbase + (unsigned)(n * 1024) + wl);
+          if (!Q_DBG(4)) w[n] = *(const bf16x8*)(nbase + (unsigned)(n * 1024) + wl);
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (g == 11) Q_STAMPW(66 + 3 * kk);
       }
       if (g < 40) L1_STAMP(4 + 3 * g);
       ++g;
-      // a block of this wave ends behind loop position S - 1 (column half 0: block jj) / Q_LAG - 1 (column half 1: block jj - 1)
-      if constexpr (Q_LAG == 0) {
-        if (st == S - 1) epilogue(jj);
-      } else {
-        if (st == S - 1) { if (ch == 0 && jj < J) epilogue(jj); }
-        if (st == Q_LAG - 1) { if (ch == 1 && jj > 0) epilogue(jj - 1); }
-      }
     }
+    if (!Q_DBG(32)) epilogue(j);
   }
   L1_STAMP(125);
+  wait_vmcnt<0>();                                   // the pieces issued behind the last stage still write this workgroup's LDS
   L1_STAMP(126);
 }
 
@@ -525,10 +500,10 @@ extern "C" size_t nr_lin160_stream_bytes(int N, int K) { return (N % L1_BN == 0 
 
 // The shapes this kernel is chosen for: plain Linear (one source, no GEGLU / LayerNorm fold / row vector / activation / scale), K = 640 or 1280
 // (the short-K regime), N a multiple of 160, >= 2048 rows in whole 64-row groups
-// PANEL rule (rows of one clip, N, K): the LayerNorm-folded wide projections (GEGLU N = 8 C, q|k|v N = 3 C) at K = C = 640 on 2048 .. NR_LIN160_PANEL_MAXM rows
+// PANEL rule (rows of one clip, N, K): the LayerNorm-folded wide projections (GEGLU N = 8 C, q|k|v N = 3 C) at K = C = 640 on >= 2048 rows (NR_LIN160_PANEL_MAXM: sweep aid)
 extern "C" int nr_lin160_panel_rule(int Mp, int N, int K) {
   static const bool off = (getenv("NR_LIN160") && getenv("NR_LIN160")[0] == '0') || (getenv("NR_LIN160_PANEL") && getenv("NR_LIN160_PANEL")[0] == '0');   // A/B switches
-  static const int maxm = getenv("NR_LIN160_PANEL_MAXM") ? atoi(getenv("NR_LIN160_PANEL_MAXM")) : 8192;
+  static const int maxm = getenv("NR_LIN160_PANEL_MAXM") ? atoi(getenv("NR_LIN160_PANEL_MAXM")) : (1 << 30);   // no row ceiling: J = 10 blocks per workgroup amortise prologue and epilogue over any number of rounds (config 4: +1.6 %)
   return !off && K == 640 && N % Q_BN == 0 && N >= 3 * K && Mp >= 2048 && Mp <= maxm;
 }
 extern "C" size_t nr_lin128q_stream_bytes(int N, int K) { return (N % Q_BN == 0 && K % 128 == 0) ? (size_t)N * K * sizeof(bf16) : 0; }
@@ -607,6 +582,24 @@ extern "C" int nr_launch_lin160(const NrGemmParams* pp, const bf16* stream, hipS
       done |= 1ull << (dev & 63);
     }
     const dim3 grid((unsigned)(nrg * q.NCG));
+#ifdef NR_STAMP
+    if (const int bits = getenv("NR_Q_DBG") ? atoi(getenv("NR_Q_DBG")) : 0) {      // timing-only ablation arms of the GEGLU form
+      auto go = [&](auto kf) { (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)Q_NS * Q_STAGE + 2 * 16 * Q_BN * sizeof(float))); hipLaunchKernelGGL(kf, grid, dim3(512), shm, s, q); };
+      switch (bits) {
+        case 1: go(lin128q_kernel<20, true, 1>); break;
+        case 2: go(lin128q_kernel<20, true, 2>); break;
+        case 4: go(lin128q_kernel<20, true, 4>); break;
+        case 8: go(lin128q_kernel<20, true, 8>); break;
+        case 14: go(lin128q_kernel<20, true, 14>); break;
+        case 16: go(lin128q_kernel<20, true, 16>); break;
+        case 17: go(lin128q_kernel<20, true, 17>); break;
+        case 32: go(lin128q_kernel<20, true, 32>); break;
+        case 47: go(lin128q_kernel<20, true, 47>); break;
+        default: return 1;
+      }
+      return 0;
+    }
+#endif
     if (g.geglu) hipLaunchKernelGGL((lin128q_kernel<20, true>), grid, dim3(512), shm, s, q);
     else hipLaunchKernelGGL((lin128q_kernel<20, false>), grid, dim3(512), shm, s, q);
     return 0;

@@ -1,5 +1,5 @@
 # same-box A/B of the register-panel form of lin160.hip (NR_LIN160_PANEL=0: LayerNorm launch / folded tiled igemm as before) on the headline, interleaved (ABAB),
-# + per-launch times of one U-Net forward in both arms (tools/per_op_profile.py), + config 4 with the row ceiling lifted
+# + per-launch times of one U-Net forward in both arms (tools/per_op_profile.py), + config 4
 cd $GRAFT_REPO_ROOT
 out=${1:-gpurun_out/lin160_panel_ab.txt}
 : > $out
@@ -16,8 +16,8 @@ d=json.loads(sys.stdin.read()); print('headline  NR_LIN160_PANEL=$arm rep $rep:'
   done
 done
 for arm in 0 1; do
-  NR_LIN160_PANEL=$arm NR_LIN160_PANEL_MAXM=65536 python bench.py --workload video --batch 8 --steps 1 --warmup 1 --no-cpu-baseline --no-psnr --no-end-to-end 2>/dev/null | tail -1 | python -c "
+  NR_LIN160_PANEL=$arm python bench.py --workload video --batch 8 --steps 1 --warmup 1 --no-cpu-baseline --no-psnr --no-end-to-end 2>/dev/null | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('config 4 (8 clips, panel ceiling lifted)  NR_LIN160_PANEL=$arm:', d['value'], 'frames/s; class frac', d['roofline']['frac'])" >> $out
+d=json.loads(sys.stdin.read()); print('config 4 (8 clips)  NR_LIN160_PANEL=$arm:', d['value'], 'frames/s; class frac', d['roofline']['frac'])" >> $out
 done
 cat $out
