@@ -286,15 +286,27 @@ struct NrLin128QParams {
   int norot;               // 1: every workgroup walks the stages from stage 0 (NR_DETERMINISTIC_BATCH)
 };
 
-template <int KS, bool GEGLU, int DBG = 0>
+// KSPLIT (K = 1280): a wave cannot hold 32 rows x 1280 channels (320 VGPRs), so the two waves of a SIMD split K instead of the columns: wave (rp, ch) holds the
+// k-steps 4 ch .. 4 ch + 3 of every 256-channel stage of its 32 rows (160 VGPRs again, and no row is loaded twice), the column block is 64 wide (4 tiles: both
+// waves accumulate all of them over their half of K), a stage is still 32 KiB (8 k-steps x 4 fragments), the ring has 3 slots, and at the end of a block the pair
+// swaps partial sums through 32 KiB of LDS (each wave hands over the two tiles the other one finishes, one extra barrier per block); the row statistics are
+// combined the same way once.
+template <int KS, bool GEGLU, bool KSPLIT = false, int DBG = 0>
 __global__ __launch_bounds__(512) void lin128q_kernel(NrLin128QParams p) {
-  constexpr int K = 32 * KS, S = KS / 4;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // Q_NS stages of Q_STAGE bytes, then float tab[2][J * 128] (ln_c | bias')
+  constexpr int K = 32 * KS;
+  constexpr int KSL = KSPLIT ? KS / 2 : KS;            // k-steps a wave holds
+  constexpr int KPS = KSPLIT ? 8 : 4;                  // k-steps per stage
+  constexpr int S = KS / KPS;                          // stages per column block
+  constexpr int BN = KSPLIT ? 64 : Q_BN, NTB = BN / 16;   // column block, its tiles
+  constexpr int NS = KSPLIT ? 3 : Q_NS;                // ring slots
+  constexpr int XCH = KSPLIT ? 32 * 1024 : 0;          // partial-sum exchange behind the ring
+  static_assert(KSL == 20 && S == 5, "20 k-steps per wave in 5 stages of 4");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NS stages of Q_STAGE bytes, [the exchange area,] then float tab[2][J * BN] (ln_c | bias')
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
-  const int rp = wave & 3, ch = wave >> 2;
+  const int rp = wave & 3, ch = wave >> 2;             // ch: column half (tiles 4 ch ..) or, KSPLIT, K half (k-steps 4 ch .. of every stage)
   L1_STAMP(0);
   const int J = p.J;
   // workgroup -> (row group, column group): the column groups of a row group on ONE XCD (blockIdx mod 8), so x (read once per workgroup, all in the prologue)
@@ -305,40 +317,40 @@ __global__ __launch_bounds__(512) void lin128q_kernel(NrLin128QParams p) {
   else { cg = (int)(blockIdx.x % p.NCG); rg = (int)(blockIdx.x / p.NCG); }
   const int row0 = rg * 128 + 32 * rp + fr;            // + 16 rt
   const int rot = p.norot ? 0 : rg % S;                // first stage of every block for this row group
-  const int G = J * S;                                 // stages of this workgroup (>= Q_NS - 1: host)
+  const int G = J * S;                                 // stages of this workgroup (>= NS - 1: host)
 
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lptr_t)smem);
   const char* wbase = reinterpret_cast<const char*>(p.stream) + (size_t)cg * J * ((size_t)S * Q_STAGE) + (size_t)(wave * 4) * 1024 + (size_t)lane * 16;
-  auto issue_piece = [&](int g, int i) {               // piece i (0 .. 3) of this wave for stage g -> slot g mod Q_NS
+  auto issue_piece = [&](int g, int i) {               // piece i (0 .. 3) of this wave for stage g -> slot g mod NS
     const int gs = g < G ? g : G - 1;                  // behind the last stage nobody consumes the piece: a valid source keeps the loop branch-free and its vmcnt constant
     const int j = gs / S;
     int st = gs - j * S + rot; if (st >= S) st -= S;
-    glds16(wbase + ((size_t)j * S + st) * Q_STAGE + (size_t)i * 1024, lds0 + (unsigned)((g & (Q_NS - 1)) * Q_STAGE + (wave * 4 + i) * 1024));
+    glds16(wbase + ((size_t)j * S + st) * Q_STAGE + (size_t)i * 1024, lds0 + (unsigned)((g % NS) * Q_STAGE + (wave * 4 + i) * 1024));
   };
 #pragma unroll
-  for (int g = 0; g < Q_NS - 1; ++g)
+  for (int g = 0; g < NS - 1; ++g)
 #pragma unroll
     for (int i = 0; i < 4; ++i) issue_piece(g, i);
 
   L1_STAMP(122);
-  // ---- fold constants of the workgroup's J x 128 columns -> LDS table ----
-  float* tab = reinterpret_cast<float*>(smem + Q_NS * Q_STAGE);
-  for (int i = tid; i < J * Q_BN; i += 512) {
-    tab[i] = p.ln_c[cg * J * Q_BN + i];
-    tab[J * Q_BN + i] = p.bias[cg * J * Q_BN + i];
+  // ---- fold constants of the workgroup's J x BN columns -> LDS table ----
+  float* tab = reinterpret_cast<float*>(smem + NS * Q_STAGE + XCH);
+  for (int i = tid; i < J * BN; i += 512) {
+    tab[i] = p.ln_c[cg * J * BN + i];
+    tab[J * BN + i] = p.bias[cg * J * BN + i];
   }
 
   L1_STAMP(123);
-  const int rotx = rot;
-  // ---- the row panel -> registers (k-step ks of the panel = k-step ks + 4 rotx of the row).  Issued BEHIND the prologue's DMA pieces: the compiler's own
-  // vmcnt for these loads does not know the asm pieces, so they must be the older operations (its waits are then conservative) ----
-  bf16x8 xb[2][KS];
+  // ---- the row panel -> registers: register k-step 4 st + kk = channel k-step KPS ((st + rot) mod S) + [4 ch +] kk of the row.  Issued BEHIND the prologue's
+  // DMA pieces: the compiler's own vmcnt for these loads does not know the asm pieces, so they must be the older operations (its waits are then conservative) ----
+  bf16x8 xb[2][KSL];
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
     const bf16* xr = p.x + (size_t)(row0 + 16 * rt) * p.lda + 8 * fg;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      int kq = ks + 4 * rotx; if (kq >= KS) kq -= KS;
+    for (int ks = 0; ks < KSL; ++ks) {
+      int sq = (ks >> 2) + rot; if (sq >= S) sq -= S;
+      const int kq = KPS * sq + (KSPLIT ? 4 * ch : 0) + (ks & 3);
       xb[rt][ks] = *(const bf16x8*)(xr + 32 * kq);
     }
   }
@@ -357,11 +369,12 @@ __global__ __launch_bounds__(512) void lin128q_kernel(NrLin128QParams p) {
     bf16x8 ones;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+    float sx[2], sq2[2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
       f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
+      for (int ks = 0; ks < KSL; ++ks) {
         a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xb[rt][ks], a1, 0, 0, 0);
         a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb[rt][ks], xb[rt][ks], a2, 0, 0, 0);
       }
@@ -369,30 +382,77 @@ __global__ __launch_bounds__(512) void lin128q_kernel(NrLin128QParams p) {
       const int e_d = fr & 3;
       float d = e_d == 0 ? a2[0] : e_d == 1 ? a2[1] : e_d == 2 ? a2[2] : a2[3];
       d = (fg == (fr >> 2)) ? d : 0.f;
-      mu[rt] = a1[0] * (1.0f / K);
-      rstd[rt] = rsqrtf(fmaxf(rows_sum(d) * (1.0f / K) - mu[rt] * mu[rt], 0.f) + p.ln_eps);
+      sx[rt] = a1[0];
+      sq2[rt] = rows_sum(d);
+    }
+    if constexpr (KSPLIT) {                            // the other half of K lives in the SIMD-mate (wave ^ 4)
+      float* xs = reinterpret_cast<float*>(smem + NS * Q_STAGE);          // [8 waves][2 rt][2][16 rows]
+      if (fg == 0) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) { xs[((wave * 2 + rt) * 2 + 0) * 16 + fr] = sx[rt]; xs[((wave * 2 + rt) * 2 + 1) * 16 + fr] = sq2[rt]; }
+      }
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) { sx[rt] += xs[(((wave ^ 4) * 2 + rt) * 2 + 0) * 16 + fr]; sq2[rt] += xs[(((wave ^ 4) * 2 + rt) * 2 + 1) * 16 + fr]; }
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      mu[rt] = sx[rt] * (1.0f / K);
+      rstd[rt] = rsqrtf(fmaxf(sq2[rt] * (1.0f / K) - mu[rt] * mu[rt], 0.f) + p.ln_eps);
     }
   }
   L1_STAMP(127);
-  wait_vmcnt<0>();                                   // the panel is the youngest: stages 0 .. Q_NS - 2 of this wave have landed
-  __builtin_amdgcn_s_barrier();                      // ... of every wave, and the table
+  wait_vmcnt<0>();                                   // the panel is the youngest: stages 0 .. NS - 2 of this wave have landed
+  __builtin_amdgcn_s_barrier();                      // ... of every wave, and the table (and, KSPLIT, everyone has read the statistics exchange)
   L1_STAMP(1);
 
-  const unsigned wl = (unsigned)((4 * ch) * 1024 + lane * 16);
-  // element offset of this lane's first output of a block's column 0 (32 bits: M ldo < 2^31 elements, host-checked), uniform base + lane offset addressing
-  const unsigned oofs = (unsigned)row0 * (unsigned)p.ldo + (unsigned)((GEGLU ? 16 * (2 * ch) : 16 * (4 * ch)) + 4 * fg);
+  // this wave's first fragment of a k-step: column half ch (tiles 4 ch ..) / K half ch (k-steps 4 ch .. of the stage, all 4 tiles)
+  const unsigned wl = (unsigned)((KSPLIT ? 16 * ch : 4 * ch) * 1024 + lane * 16);
+  // element offset of this lane's first output of a block's column 0 (32 bits: M ldo < 2^31 elements, host-checked), uniform base + lane offset addressing;
+  // the tiles a wave FINISHES: 4 ch .. 4 ch + 3 / KSPLIT 2 ch, 2 ch + 1
+  const unsigned oofs = (unsigned)row0 * (unsigned)p.ldo + (unsigned)((KSPLIT ? (GEGLU ? 16 * ch : 32 * ch) : (GEGLU ? 32 * ch : 64 * ch)) + 4 * fg);
   bf16x8 w[4];
 #pragma unroll
   for (int n = 0; n < 4; ++n) w[n] = *(const bf16x8*)(smem + (unsigned)(n * 1024) + wl);
   f32x4 acc[2][4];
-  // block epilogue: lane holds out channels 16 (4 ch + n) + 4 fg .. + 3 of rows row0, row0 + 16 of block jb of the group
+  // block epilogue: lane holds out channels 16 t + 4 fg .. + 3 of rows row0, row0 + 16 for the tiles t it finishes of block jb of the group
   auto epilogue = [&](int jb) {
     const int cb = cg * J + jb;
-    const float* tc = tab + jb * Q_BN + 16 * (4 * ch) + 4 * fg;
-    const float* tb = tc + J * Q_BN;
-    if constexpr (GEGLU) {
+    constexpr int NF = KSPLIT ? 2 : 4;                 // tiles this wave finishes
+    const float* tc = tab + jb * BN + 16 * (NF * ch) + 4 * fg;
+    const float* tb = tc + J * BN;
+    if constexpr (KSPLIT) {
+      // the pair swaps partial sums: [wave][rt][nn][lane] f32x4 -- the two tiles the OTHER wave finishes go out, its sums of this wave's two tiles come in
+      f32x4* ex = reinterpret_cast<f32x4*>(smem + NS * Q_STAGE);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn) {
+          f32x4 theirs;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) theirs[e] = ch ? acc[rt][nn][e] : acc[rt][2 + nn][e];
+          ex[((wave * 2 + rt) * 2 + nn) * 64 + lane] = theirs;
+        }
+      __builtin_amdgcn_s_barrier();
+      const f32x4 c0 = *(const f32x4*)(tc), c1 = *(const f32x4*)(tc + 16), b0 = *(const f32x4*)(tb), b1 = *(const f32x4*)(tb + 16);
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const f32x4 o0 = ex[(((wave ^ 4) * 2 + rt) * 2 + 0) * 64 + lane], o1 = ex[(((wave ^ 4) * 2 + rt) * 2 + 1) * 64 + lane];
+        bf16x4 r0, r1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t0 = ((ch ? acc[rt][2][e] : acc[rt][0][e]) + o0[e] - mu[rt] * c0[e]) * rstd[rt] + b0[e];
+          const float t1 = ((ch ? acc[rt][3][e] : acc[rt][1][e]) + o1[e] - mu[rt] * c1[e]) * rstd[rt] + b1[e];
+          if constexpr (GEGLU) r0[e] = (bf16)(t0 * gelu_erf_fast(t1));
+          else { r0[e] = (bf16)t0; r1[e] = (bf16)t1; }
+        }
+        bf16* orow = p.out + (oofs + (unsigned)(16 * rt) * (unsigned)p.ldo + (unsigned)(cb * (GEGLU ? BN / 2 : BN)));
+        nr_store8(orow, r0);
+        if constexpr (!GEGLU) nr_store8(orow + 16, r1);
+      }
+    } else if constexpr (GEGLU) {
+#pragma unroll
+      for (int i = 0; i < NF / 2; ++i) {
         const f32x4 cv = *(const f32x4*)(tc + 32 * i), cgv = *(const f32x4*)(tc + 32 * i + 16);
         const f32x4 bv = *(const f32x4*)(tb + 32 * i), bg = *(const f32x4*)(tb + 32 * i + 16);
 #pragma unroll
@@ -404,19 +464,19 @@ __global__ __launch_bounds__(512) void lin128q_kernel(NrLin128QParams p) {
             const float gt = (acc[rt][2 * i + 1][e] - mu[rt] * cgv[e]) * rstd[rt] + bg[e];
             o[e] = (bf16)(v * gelu_erf_fast(gt));
           }
-          nr_store8(p.out + (oofs + (unsigned)(16 * rt) * (unsigned)p.ldo + (unsigned)(cb * (Q_BN / 2) + 16 * i)), o);
+          nr_store8(p.out + (oofs + (unsigned)(16 * rt) * (unsigned)p.ldo + (unsigned)(cb * (BN / 2) + 16 * i)), o);
         }
       }
     } else {
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
+      for (int n = 0; n < NF; ++n) {
         const f32x4 c4 = *(const f32x4*)(tc + 16 * n), b4 = *(const f32x4*)(tb + 16 * n);
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
           bf16x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (bf16)((acc[rt][n][e] - mu[rt] * c4[e]) * rstd[rt] + b4[e]);
-          nr_store8(p.out + (oofs + (unsigned)(16 * rt) * (unsigned)p.ldo + (unsigned)(cb * Q_BN + 16 * n)), o);
+          nr_store8(p.out + (oofs + (unsigned)(16 * rt) * (unsigned)p.ldo + (unsigned)(cb * BN + 16 * n)), o);
         }
       }
     }
@@ -425,28 +485,29 @@ __global__ __launch_bounds__(512) void lin128q_kernel(NrLin128QParams p) {
   // next MFMA pair: a k-step cost 360 cycles for 256 of MFMAs).  Hence: the fragments of the next k-step are always read (behind the last stage: stale bytes nobody uses),
   // the DMA burst and the stage barrier are unconditional (pieces behind the last stage re-fetch its bytes), the first k-step of a block accumulates onto one zero quad.
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  int g = 0;
+  int g = 0, slot = 0;
   for (int j = 0; j < J; ++j) {
 #pragma unroll
     for (int st = 0; st < S; ++st) {
+      const int nslot = slot + 1 == NS ? 0 : slot + 1;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         // ---- where the fragments of the NEXT k-step come from (kk = 3: the next stage, behind its barrier); w[n] is refilled as soon as its two MFMAs are issued ----
         const unsigned char* nbase;
-        if (kk < 3) nbase = smem + (g & (Q_NS - 1)) * Q_STAGE + (kk + 1) * (Q_NT * 1024);
+        if (kk < 3) nbase = smem + slot * Q_STAGE + (kk + 1) * (NTB * 1024);
         else {
-          if (!Q_DBG(16)) wait_vmcnt<8>();                       // stage g + 1 landed: younger pieces of this wave in flight = stages g + 2 and g + 3 (4 each)
+          if (!Q_DBG(16)) wait_vmcnt<(NS - 2) * 4>();            // stage g + 1 landed: younger pieces of this wave in flight = stages g + 2 .. g + NS - 1 (4 each)
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of slot g are in registers: the slot may be refilled behind the barrier
           if (g < 40) L1_STAMP(2 + 3 * g);
           if (!Q_DBG(1)) __builtin_amdgcn_s_barrier();
           if (g < 40) L1_STAMP(3 + 3 * g);
-          nbase = smem + ((g + 1) & (Q_NS - 1)) * Q_STAGE;
+          nbase = smem + nslot * Q_STAGE;
         }
         __builtin_amdgcn_sched_barrier(0);
-        // the wave's four DMA pieces of stage g + 3 in one burst at the head of the stage (staggering the two waves of a SIMD measured the same)
+        // the wave's four DMA pieces of stage g + NS - 1 in one burst at the head of the stage (staggering the two waves of a SIMD measured the same)
         if (kk == 0 && !Q_DBG(2)) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) issue_piece(g + Q_NS - 1, i);
+          for (int i = 0; i < 4; ++i) issue_piece(g + NS - 1, i);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -461,25 +522,34 @@ __global__ __launch_bounds__(512) void lin128q_kernel(NrLin128QParams p) {
       }
       if (g < 40) L1_STAMP(4 + 3 * g);
       ++g;
+      slot = nslot;
     }
     if (!Q_DBG(32)) epilogue(j);
+    if constexpr (KSPLIT) {
+      // the first fragments of the next block are read again BEHIND the epilogue: their registers are free across it (the exchange needs them: with the prefetched
+      // set live hipcc spills panel registers and rotates the whole panel by four registers per block, 140 v_mov_b64)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) w[n] = *(const bf16x8*)(smem + slot * Q_STAGE + (unsigned)(n * 1024) + wl);
+    }
   }
   L1_STAMP(125);
   wait_vmcnt<0>();                                   // the pieces issued behind the last stage still write this workgroup's LDS
   L1_STAMP(126);
 }
 
-// fragment-major stream of the panel kernel from the row-major [N][K] bf16 matrix: 16-byte chunk -> (column block, stage, k-step, tile, lane)
-__global__ __launch_bounds__(256) void lin128q_w_pack_kernel(const bf16* __restrict__ w, bf16* __restrict__ stream, int N, int K) {
-  const int S = K >> 7, CH_STAGE = Q_STAGE / 16;
+// fragment-major stream of the panel kernel from the row-major [N][K] bf16 matrix: 16-byte chunk -> (column block of BN, stage of 32 KPS channels, k-step, tile, lane);
+// a stage is Q_STAGE bytes for both forms (BN = 128, KPS = 4 / KSPLIT: BN = 64, KPS = 8)
+__global__ __launch_bounds__(256) void lin128q_w_pack_kernel(const bf16* __restrict__ w, bf16* __restrict__ stream, int N, int K, int BN, int KPS) {
+  const int S = K / (32 * KPS), CH_STAGE = Q_STAGE / 16, NTB = BN / 16;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long long)(N / Q_BN) * S * CH_STAGE) return;
+  if (idx >= (long long)(N / BN) * S * CH_STAGE) return;
   const int cb = (int)(idx / ((long long)S * CH_STAGE));
   int c = (int)(idx - (long long)cb * S * CH_STAGE);
   const int st = c / CH_STAGE;
   c -= st * CH_STAGE;
-  const int kk = c / (Q_NT * 64), n = (c / 64) % Q_NT, lane = c & 63;
-  *(bf16x8*)(stream + (size_t)idx * 8) = *(const bf16x8*)(w + (size_t)(cb * Q_BN + 16 * n + (lane & 15)) * K + 128 * st + 32 * kk + 8 * (lane >> 4));
+  const int kk = c / (NTB * 64), n = (c / 64) % NTB, lane = c & 63;
+  *(bf16x8*)(stream + (size_t)idx * 8) = *(const bf16x8*)(w + (size_t)(cb * BN + 16 * n + (lane & 15)) * K + 32 * (KPS * st + kk) + 8 * (lane >> 4));
 }
 
 unsigned long long g_l1_attr = 0;
@@ -500,17 +570,26 @@ extern "C" size_t nr_lin160_stream_bytes(int N, int K) { return (N % L1_BN == 0 
 
 // The shapes this kernel is chosen for: plain Linear (one source, no GEGLU / LayerNorm fold / row vector / activation / scale), K = 640 or 1280
 // (the short-K regime), N a multiple of 160, >= 2048 rows in whole 64-row groups
-// PANEL rule (rows of one clip, N, K): the LayerNorm-folded wide projections (GEGLU N = 8 C, q|k|v N = 3 C) at K = C = 640 on >= 2048 rows (NR_LIN160_PANEL_MAXM: sweep aid)
+// PANEL rule (rows of one clip, N, K): the LayerNorm-folded wide projections (GEGLU N = 8 C, q|k|v N = 3 C) at K = C = 640 / 1280 on >= 2048 rows (NR_LIN160_PANEL_MAXM: sweep aid;
+// NR_LIN160_PANEL_K1280=0: the K-split form of the C = 1280 level off)
 extern "C" int nr_lin160_panel_rule(int Mp, int N, int K) {
   static const bool off = (getenv("NR_LIN160") && getenv("NR_LIN160")[0] == '0') || (getenv("NR_LIN160_PANEL") && getenv("NR_LIN160_PANEL")[0] == '0');   // A/B switches
+  static const bool off1280 = getenv("NR_LIN160_PANEL_K1280") && getenv("NR_LIN160_PANEL_K1280")[0] == '0';
   static const int maxm = getenv("NR_LIN160_PANEL_MAXM") ? atoi(getenv("NR_LIN160_PANEL_MAXM")) : (1 << 30);   // no row ceiling: J = 10 blocks per workgroup amortise prologue and epilogue over any number of rounds (config 4: +1.6 %)
-  return !off && K == 640 && N % Q_BN == 0 && N >= 3 * K && Mp >= 2048 && Mp <= maxm;
+  if (off || Mp < 2048 || Mp > maxm || N < 3 * K) return 0;
+  if (K == 640) return N % Q_BN == 0;
+  if (K == 1280) return !off1280 && N % 64 == 0;
+  return 0;
 }
-extern "C" size_t nr_lin128q_stream_bytes(int N, int K) { return (N % Q_BN == 0 && K % 128 == 0) ? (size_t)N * K * sizeof(bf16) : 0; }
+extern "C" size_t nr_lin128q_stream_bytes(int N, int K) {
+  if (K == 640) return N % Q_BN == 0 ? (size_t)N * K * sizeof(bf16) : 0;
+  if (K == 1280) return N % 64 == 0 ? (size_t)N * K * sizeof(bf16) : 0;
+  return 0;
+}
 extern "C" int nr_launch_lin128q_w_pack(const bf16* w, int N, int K, bf16* stream, hipStream_t s) {
   const long long total = (long long)(nr_lin128q_stream_bytes(N, K) / 16);
   if (!total) return 1;
-  hipLaunchKernelGGL(lin128q_w_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, stream, N, K);
+  hipLaunchKernelGGL(lin128q_w_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, stream, N, K, K == 1280 ? 64 : Q_BN, K == 1280 ? 8 : 4);
   return 0;
 }
 
@@ -556,52 +635,57 @@ extern "C" int nr_launch_lin160(const NrGemmParams* pp, const bf16* stream, hipS
   if (!stream) return 1;
   const int Mp = (g.plan_m > 0 && g.plan_m < g.M) ? g.plan_m : g.M;
   if (g.ln_c && nr_lin160_panel_rule(Mp, g.N, g.K)) {            // PANEL form (stream = the nr_lin128q layout)
-    if (!g.bias || g.M % 128 != 0 || g.K != 640 || (long long)g.M * g.ldo >= (1ll << 31)) return 1;
+    if (!g.bias || g.M % 128 != 0 || (long long)g.M * g.ldo >= (1ll << 31)) return 1;
+    const bool ksplit = g.K == 1280;                               // K = 1280: the two waves of a SIMD split K, 64-column blocks
     NrLin128QParams q;
     q.x = g.a0; q.lda = g.lda0; q.stream = stream; q.ln_c = g.ln_c; q.bias = g.bias; q.ln_eps = g.ln_eps; q.out = g.out; q.ldo = g.ldo; q.M = g.M; q.N = g.N; q.norot = g.plan_m > 0 ? 1 : 0;
     // J column blocks per workgroup (NCG = ncb / J column groups): the divisor of ncb with the fewest stage-times for the launch -- rounds of the chip x (J S stages + ~6
     // stage-times of prologue / epilogue); ties -> the larger J
-    const int ncq = g.N / Q_BN, S = g.K / 128, nrg = g.M / 128;
+    const int bn = ksplit ? 64 : Q_BN, ncq = g.N / bn, S = 5, nrg = g.M / 128, ns = ksplit ? 3 : Q_NS;
     static const int j_force = getenv("NR_LIN160_PANEL_J") ? atoi(getenv("NR_LIN160_PANEL_J")) : 0;   // sweep aid
     int J = 0; long long best = 0;
     for (int c = 1; c <= 16 && c <= ncq; ++c) {
-      if (ncq % c != 0 || c * S < Q_NS - 1) continue;
+      if (ncq % c != 0 || c * S < ns - 1) continue;
       const long long wgs = (long long)nrg * (ncq / c), cost = ((wgs + 255) / 256) * (c * S + 6);
       if (!J || cost <= best) { J = c; best = cost; }
     }
     if (j_force > 0 && ncq % j_force == 0 && j_force <= 16) J = j_force;
     if (!J) return 1;
     q.J = J; q.NCG = ncq / J;
-    const size_t shm = (size_t)Q_NS * Q_STAGE + (size_t)2 * J * Q_BN * sizeof(float);
+    const size_t shm_max = (size_t)Q_NS * Q_STAGE + 2 * 16 * Q_BN * sizeof(float);      // either form: ring [+ exchange] + the table of 16 blocks
+    const size_t shm = (size_t)ns * Q_STAGE + (ksplit ? 32 * 1024 : 0) + (size_t)2 * J * bn * sizeof(float);
     int dev = 0;
     (void)hipGetDevice(&dev);
     static unsigned long long done = 0;
     if (!(done >> (dev & 63) & 1ull)) {
-      const void* ks[2] = {(const void*)lin128q_kernel<20, true>, (const void*)lin128q_kernel<20, false>};
-      for (const void* kf : ks) if (hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)Q_NS * Q_STAGE + 2 * 16 * Q_BN * sizeof(float))) != hipSuccess) return 2;
+      const void* ks[4] = {(const void*)lin128q_kernel<20, true>, (const void*)lin128q_kernel<20, false>, (const void*)lin128q_kernel<40, true, true>, (const void*)lin128q_kernel<40, false, true>};
+      for (const void* kf : ks) if (hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_max) != hipSuccess) return 2;
       done |= 1ull << (dev & 63);
     }
     const dim3 grid((unsigned)(nrg * q.NCG));
 #ifdef NR_STAMP
-    if (const int bits = getenv("NR_Q_DBG") ? atoi(getenv("NR_Q_DBG")) : 0) {      // timing-only ablation arms of the GEGLU form
-      auto go = [&](auto kf) { (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)Q_NS * Q_STAGE + 2 * 16 * Q_BN * sizeof(float))); hipLaunchKernelGGL(kf, grid, dim3(512), shm, s, q); };
+    if (const int bits = (!ksplit && getenv("NR_Q_DBG")) ? atoi(getenv("NR_Q_DBG")) : 0) {      // timing-only ablation arms of the GEGLU form
+      auto go = [&](auto kf) { (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_max); hipLaunchKernelGGL(kf, grid, dim3(512), shm, s, q); };
       switch (bits) {
-        case 1: go(lin128q_kernel<20, true, 1>); break;
-        case 2: go(lin128q_kernel<20, true, 2>); break;
-        case 4: go(lin128q_kernel<20, true, 4>); break;
-        case 8: go(lin128q_kernel<20, true, 8>); break;
-        case 14: go(lin128q_kernel<20, true, 14>); break;
-        case 16: go(lin128q_kernel<20, true, 16>); break;
-        case 17: go(lin128q_kernel<20, true, 17>); break;
-        case 32: go(lin128q_kernel<20, true, 32>); break;
-        case 47: go(lin128q_kernel<20, true, 47>); break;
+        case 1: go(lin128q_kernel<20, true, false, 1>); break;
+        case 2: go(lin128q_kernel<20, true, false, 2>); break;
+        case 4: go(lin128q_kernel<20, true, false, 4>); break;
+        case 8: go(lin128q_kernel<20, true, false, 8>); break;
+        case 14: go(lin128q_kernel<20, true, false, 14>); break;
+        case 16: go(lin128q_kernel<20, true, false, 16>); break;
+        case 17: go(lin128q_kernel<20, true, false, 17>); break;
         default: return 1;
       }
       return 0;
     }
 #endif
-    if (g.geglu) hipLaunchKernelGGL((lin128q_kernel<20, true>), grid, dim3(512), shm, s, q);
-    else hipLaunchKernelGGL((lin128q_kernel<20, false>), grid, dim3(512), shm, s, q);
+    if (ksplit) {
+      if (g.geglu) hipLaunchKernelGGL((lin128q_kernel<40, true, true>), grid, dim3(512), shm, s, q);
+      else hipLaunchKernelGGL((lin128q_kernel<40, false, true>), grid, dim3(512), shm, s, q);
+    } else {
+      if (g.geglu) hipLaunchKernelGGL((lin128q_kernel<20, true>), grid, dim3(512), shm, s, q);
+      else hipLaunchKernelGGL((lin128q_kernel<20, false>), grid, dim3(512), shm, s, q);
+    }
     return 0;
   }
   if (g.M % 64 != 0 || g.N % L1_BN != 0 || g.K % 64 != 0 || g.K / 64 < L1_NS) return 1;

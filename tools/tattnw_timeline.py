@@ -52,8 +52,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "lin160p":
     # stage of a column block to the first wait of the next one (the block's epilogue)
     lib.nr_lin160_stamp_read.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
     lib.nr_lin160_stamp_read.restype = C.c_int
-    for M, K, N, geglu in ((8192, 640, 5120, True), (8192, 640, 1920, False)):
-        S = K // 128                      # 128-channel stages
+    for M, K, N, geglu in ((8192, 640, 5120, True), (8192, 640, 1920, False), (2048, 1280, 10240, True), (2048, 1280, 3840, False)):
+        S = 5                             # stages per column block (128 channels; K = 1280: 256)
         g = torch.Generator(device=dev).manual_seed(0)
         a = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16)
         w = torch.randn(N, K, generator=g, device=dev) * K ** -0.5
