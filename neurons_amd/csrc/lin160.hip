@@ -284,6 +284,7 @@ struct NrLin128QParams {
   bf16* out; int ldo;
   int M, N, J, NCG;
   int norot;               // 1: every workgroup walks the stages from stage 0 (NR_DETERMINISTIC_BATCH)
+  int cgmajor;             // 1: workgroup -> XCD by column group (blockIdx mod NCG) instead of by row group
 };
 
 // KSPLIT (K = 1280): a wave cannot hold 32 rows x 1280 channels (320 VGPRs), so the two waves of a SIMD split K instead of the columns: wave (rp, ch) holds the
@@ -311,9 +312,11 @@ __global__ __launch_bounds__(512) void lin128q_kernel(NrLin128QParams p) {
   const int J = p.J;
   // workgroup -> (row group, column group): the column groups of a row group on ONE XCD (blockIdx mod 8), so x (read once per workgroup, all in the prologue)
   // crosses the fabric once; every XCD then streams all of W, block by block in step with its row groups (working set: NCG blocks of 160 KiB)
+  // (few row groups and many column groups -- the 8 x 8 level at one clip: 16 x 16 -- turn it round, host flag: the column groups of an XCD stay in its L2 and x crosses
+  // the fabric eight times: 68 MB instead of 215 MB per launch for the C = 1280 GEGLU projection)
   int rg, cg;
   const int nrg = p.M >> 7;
-  if ((nrg & 7) == 0) { const int i = blockIdx.x >> 3; cg = i % p.NCG; rg = (i / p.NCG) * 8 + (int)(blockIdx.x & 7); }
+  if (!p.cgmajor && (nrg & 7) == 0) { const int i = blockIdx.x >> 3; cg = i % p.NCG; rg = (i / p.NCG) * 8 + (int)(blockIdx.x & 7); }
   else { cg = (int)(blockIdx.x % p.NCG); rg = (int)(blockIdx.x / p.NCG); }
   const int row0 = rg * 128 + 32 * rp + fr;            // + 16 rt
   const int rot = p.norot ? 0 : rg % S;                // first stage of every block for this row group
@@ -570,14 +573,16 @@ extern "C" size_t nr_lin160_stream_bytes(int N, int K) { return (N % L1_BN == 0 
 
 // The shapes this kernel is chosen for: plain Linear (one source, no GEGLU / LayerNorm fold / row vector / activation / scale), K = 640 or 1280
 // (the short-K regime), N a multiple of 160, >= 2048 rows in whole 64-row groups
-// PANEL rule (rows of one clip, N, K): the LayerNorm-folded wide projections (GEGLU N = 8 C, q|k|v N = 3 C) at K = C = 640 / 1280 on >= 2048 rows (NR_LIN160_PANEL_MAXM: sweep aid;
+// PANEL rule (rows of one clip, N, K): the LayerNorm-folded wide projections (GEGLU N = 8 C, q|k|v N = 3 C) at K = C = 640 (>= 4096 rows) / 1280 (>= 2048 rows) (NR_LIN160_PANEL_MAXM: sweep aid;
 // NR_LIN160_PANEL_K1280=0: the K-split form of the C = 1280 level off)
 extern "C" int nr_lin160_panel_rule(int Mp, int N, int K) {
   static const bool off = (getenv("NR_LIN160") && getenv("NR_LIN160")[0] == '0') || (getenv("NR_LIN160_PANEL") && getenv("NR_LIN160_PANEL")[0] == '0');   // A/B switches
   static const bool off1280 = getenv("NR_LIN160_PANEL_K1280") && getenv("NR_LIN160_PANEL_K1280")[0] == '0';
   static const int maxm = getenv("NR_LIN160_PANEL_MAXM") ? atoi(getenv("NR_LIN160_PANEL_MAXM")) : (1 << 30);   // no row ceiling: J = 10 blocks per workgroup amortise prologue and epilogue over any number of rounds (config 4: +1.6 %)
   if (off || Mp < 2048 || Mp > maxm || N < 3 * K) return 0;
-  if (K == 640) return N % Q_BN == 0;
+  // K = 640 needs >= 32 row groups: at 2048 rows (the sgm keyframe model's 32 x 32 level) the best partition has 160 workgroups of 20 stages and the prologue dominates
+  // (keyframe 10.55 -> 10.63 ms per Euler step with it, profiles/r06_lin160_panel_ab.txt); K = 1280 fills the chip from 2048 rows on (16 row groups x 16 column groups)
+  if (K == 640) return Mp >= 4096 && N % Q_BN == 0;
   if (K == 1280) return !off1280 && N % 64 == 0;
   return 0;
 }
@@ -652,6 +657,17 @@ extern "C" int nr_launch_lin160(const NrGemmParams* pp, const bf16* stream, hipS
     if (j_force > 0 && ncq % j_force == 0 && j_force <= 16) J = j_force;
     if (!J) return 1;
     q.J = J; q.NCG = ncq / J;
+    {
+      // workgroup -> XCD: by row group (every XCD streams all of W, x crosses the fabric once) or by column group (W once or 8 / NCG times, x NCG-or-8 times): the
+      // smaller fabric traffic; by column group only where blockIdx mod 8 fixes the column group
+      static const int cg_force = getenv("NR_LIN160_PANEL_CGMAJOR") ? atoi(getenv("NR_LIN160_PANEL_CGMAJOR")) : -1;   // A/B aid
+      const double wb = 2.0 * g.N * (double)g.K, xb = 2.0 * g.M * (double)g.K;
+      const bool can = q.NCG % 8 == 0 || 8 % q.NCG == 0;
+      const double by_rg = (nrg % 8 == 0 ? 8.0 : 8.0) * wb + xb;
+      const double by_cg = (q.NCG % 8 == 0 ? 1.0 : 8.0 / q.NCG) * wb + (q.NCG % 8 == 0 ? 8.0 : (double)q.NCG) * xb;
+      q.cgmajor = (can && by_cg < by_rg) ? 1 : 0;
+      if (cg_force >= 0) q.cgmajor = cg_force && can;
+    }
     const size_t shm_max = (size_t)Q_NS * Q_STAGE + 2 * 16 * Q_BN * sizeof(float);      // either form: ring [+ exchange] + the table of 16 blocks
     const size_t shm = (size_t)ns * Q_STAGE + (ksplit ? 32 * 1024 : 0) + (size_t)2 * J * bn * sizeof(float);
     int dev = 0;

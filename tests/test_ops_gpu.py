@@ -457,14 +457,14 @@ def test_layernorm_geglu_projection_on_few_rows_matches_torch(cuda, M, inner):
     assert torch.equal(out, ops.ln_gemm(a, w, gamma, beta, bias=bias, geglu=True))
 
 
-@pytest.mark.parametrize("M,K,N,geglu", [(8192, 640, 5120, True), (8192, 640, 1920, False), (2176, 640, 5120, True), (4096, 640, 2560, True), (3072, 640, 2048, False),
-                                           (2048, 640, 5120, True), (2048, 640, 1920, False), (2048, 1280, 10240, True), (2048, 1280, 3840, False),
+@pytest.mark.parametrize("M,K,N,geglu", [(8192, 640, 5120, True), (8192, 640, 1920, False), (4224, 640, 5120, True), (4096, 640, 2560, True), (5120, 640, 2048, False),
+                                           (2048, 640, 5120, True), (65536, 640, 1920, False), (2048, 1280, 10240, True), (2048, 1280, 3840, False),
                                            (2176, 1280, 5120, True), (4096, 1280, 4160, True), (16384, 1280, 10240, True), (3072, 1280, 3904, False)])
 def test_layernorm_wide_projection_register_panel_matches_torch(cuda, M, K, N, geglu):
     """lin160.hip, register-panel form (round 6): the LayerNorm-folded wide projections of the C = 640 level on 2048 .. 8192 rows -- FeedForward.net[0]
     (GEGLU, N = 8 C; motion_module_new.py:441-518) and the spatial self-attention's fused to_q|to_k|to_v (N = 3 C; motion_module_new.py:201-230 behind norm1,
     attention.py:272-285) -- through nr_op_ln_gemm, which routes as the engine does.  The headline's two shapes, an odd row-group count, column-block counts
-    with other divisors (J = 10 / 5 / 4 / 16), few row groups (several rounds of workgroups); at K = 1280 the K-split variant (the two waves of a SIMD hold half of K each
+    with other divisors (J = 10 / 5 / 16), config 4's row count (eight rounds of workgroups), 2048 rows (below the K = 640 rule: the tiled igemm, same expectation); at K = 1280 the K-split variant (the two waves of a SIMD hold half of K each
     and swap partial sums per 64-column block): the headline's two shapes, an odd row-group count, block counts 65 (J = 13) and 61 (prime: J = 1), config 4's row count.
     Against fp32 torch on the same bf16 input; rows offset from zero mean so that the two-pass statistics matter."""
     from neurons_amd import ops
