@@ -10,6 +10,9 @@
 //     piece per row tile and k-step, chunk-permuted: conflict-free fragment reads); every workgroup starts at its own stage (L2 channel spread);
 //   * accumulators as W . x^T (lane = 4 consecutive output channels of its row); epilogue: bias, residual, bf16, 8-byte stores (in place when
 //     the residual is the output).
+// Second kernel of this file, further down: lin128q_kernel, the REGISTER-PANEL form for the LayerNorm-folded wide projections of the same levels (FeedForward.net[0] with
+// GEGLU, N = 8 C, motion_module_new.py:441-518; the spatial self-attention's fused to_q|to_k|to_v, N = 3 C, motion_module_new.py:201-230 behind norm1 of attention.py:272-285):
+// the rows stay in registers for the whole launch and only W streams.
 #include "common.h"
 #include <cstdlib>
 
