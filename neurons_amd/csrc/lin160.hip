@@ -608,7 +608,8 @@ extern "C" int nr_lin160_eligible(const NrGemmParams* pp) {
   {
     const int Mq = (p.plan_m > 0 && p.plan_m < p.M) ? p.plan_m : p.M;
     if (p.ln_c && p.bias && p.ksize == 1 && p.stride == 1 && !p.ups && !p.a1 && !p.c1 && !p.rowvec && !p.act && !p.out_f32 && !p.res &&
-        p.out_scale == 1.0f && p.K == p.c0 && nr_lin160_panel_rule(Mq, p.N, p.K) && p.M % 128 == 0 && p.lda0 % 8 == 0 && p.ldo % 4 == 0)
+        p.out_scale == 1.0f && p.K == p.c0 && nr_lin160_panel_rule(Mq, p.N, p.K) && p.M % 128 == 0 && p.lda0 % 8 == 0 && p.ldo % 4 == 0 &&
+        (long long)p.M * p.ldo < (1ll << 31))          // 32-bit output offsets in the kernel: beyond that the tiled igemm serves the shape
       return 4;
   }
   // GLN: the LayerNorm-folded GEGLU projection on FEW rows (the keyframe model's depth-10 levels and the 4 x 4 level of the headline: M = 512, N = 10240,
