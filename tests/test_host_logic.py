@@ -29,6 +29,25 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
 
 
+def test_panel_kernel_rule_serves_the_shapes_it_was_measured_on():
+    """Host logic of the register-panel form of lin160.hip (no GPU call): the LayerNorm-folded wide projections (GEGLU N = 8 C, q|k|v N = 3 C; K = C) are routed
+    to it at C = 640 from 4096 rows of one clip and at C = 1280 from 2048 rows -- the headline's 16 x 16 and 8 x 8 levels, configs 4 / 5, SparseCtrl's grouped rows --
+    and NOT at the sgm keyframe model's 2048-row C = 640 level (measured slower there, profiles/r06_lin160_panel_ab.txt), on narrow projections (N < 3 K), at
+    other widths, or on the <= 1024-row shapes of the GEGLU variant."""
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    rule = lib.nr_lin160_panel_rule
+    rule.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    rule.restype = ctypes.c_int
+    if os.environ.get("NR_LIN160") == "0" or os.environ.get("NR_LIN160_PANEL") == "0":
+        pytest.skip("panel kernel switched off by the environment")
+    for M, N, K in ((8192, 5120, 640), (8192, 1920, 640), (65536, 5120, 640), (262144, 1920, 640), (40960, 5120, 640), (4096, 5120, 640),
+                    (2048, 10240, 1280), (2048, 3840, 1280), (16384, 10240, 1280), (10240, 3840, 1280)):
+        assert rule(M, N, K) == 1, (M, N, K)
+    for M, N, K in ((2048, 5120, 640), (2048, 1920, 640), (512, 10240, 1280), (1024, 10240, 1280), (8192, 640, 640), (2048, 1280, 1280), (8192, 1280, 640),
+                    (32768, 2560, 320), (8192, 5100, 640), (2048, 10250, 1280)):
+        assert rule(M, N, K) == 0, (M, N, K)
+
+
 def test_ctypes_structs_mirror_the_header():
     """nr_net_config / nr_profile in include/neurons_amd.h and their ctypes mirrors must agree field by field (name, order,
     array length); a drift would silently shift every later field across the ABI."""
